@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- quartets counted per second on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (N = 1): BASELINE.json configs[1] = 128 taxa, 1000 random evaluation trees, uint32
+C(128,4)x3 count table (~1.07e7 quartets), seeded synthetic trees (quartetscores_amd/synth.py).
+A step = one pass of the hot path over the batch of 1000 trees that is already resident in
+HBM: clear the table, build the pair-depth panel, run the count kernel; for N > 1 every rank
+counts its own 1000 trees (weak scaling: trees shard across GPUs) and the step ends with the
+RCCL all-reduce of the count table (BASELINE.json north_star). Exactly K steps are timed
+between barrier + torch.cuda.synchronize() on both sides; value = quartets counted by all
+ranks / max-over-ranks time.
+
+roofline: the dominant kernel is the count kernel. achieved = algorithmic bytes per launch
+(8 B per (tree, quartet) = one read + one write of a u32 counter) / its
+average launch duration measured with HIP events on the launch stream (qs_last_count_ms).
+cpu_baseline: the oracle (CPU restatement of the reference, kind "port") timed on this host
+on a bounded prefix of the same trees; reported, never the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--taxa", type=int, default=128)
+    ap.add_argument("--trees", type=int, default=1000)
+    ap.add_argument("--algo", choices=["gather", "scatter"], default="gather")
+    ap.add_argument("--count-bits", type=int, default=32)
+    ap.add_argument("--cpu-baseline-trees", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-score", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in quartetscores_amd)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from quartetscores_amd import engine, flatten, ranks, synth
+
+    n, m = args.taxa, args.trees
+    nq = ranks.n_quartets(n)
+    # seeded inputs: seed = 1000 * config + tree set id; rank r counts tree set r
+    ref_nw = synth.reference_tree(n, 2000)
+    trees = synth.tree_set(n, m, 2001 + rank)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = engine.Context(n, args.count_bits, device=local_rank, stream=stream.cuda_stream)
+    n_words = (ctx.table_bytes + 3) // 4
+    table = torch.zeros(n_words, dtype=torch.int32, device=dev)  # u16 tables all-reduce as packed words
+    ctx.table_attach(table)
+    hb = ctx.batch_upload(batch)  # inputs resident in HBM before the timed region
+    algo = engine.QS_ALGO_GATHER if args.algo == "gather" else engine.QS_ALGO_SCATTER
+
+    def step():
+        ctx.table_clear()
+        ctx.count_batch(hb, algo)
+        if world > 1:
+            dist.all_reduce(table, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    fence()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events are recorded on the launch stream inside qs_count_batch; reading them
+        # here would synchronise, so only the last step's events are read after the loop.
+    fence()
+    t1 = time.perf_counter()
+    ctx.sync()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel durations: an extra, untimed pass that reads the HIP events after every launch
+    for _ in range(max(3, min(args.steps, 10))):
+        ctx.table_clear()
+        ctx.count_batch(hb, algo)
+        kern_ms.append(ctx.last_count_ms())
+    panel_ms = float(np.mean([k[0] for k in kern_ms]))
+    count_ms = float(np.mean([k[1] for k in kern_ms]))
+    variant = ctx.last_count_variant()
+
+    # parity gate run with every measurement: table of this rank's trees, checked on rank 0
+    ctx.table_clear()
+    ctx.count_batch(hb, algo)
+    ctx.sync()
+    T = ctx.table_download()
+    parity = bool((T.sum(axis=1, dtype=np.uint64) == m).all())
+
+    score_ms = None
+    if not args.no_score and args.count_bits == 32:
+        torch.cuda.synchronize(dev)
+        s0 = time.perf_counter()
+        ctx.score(ref)
+        score_ms = (time.perf_counter() - s0) * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    units_per_step = m * nq * world
+    value = units_per_step * args.steps / elapsed
+    bytes_per_unit = 2 * (args.count_bits // 8)
+    achieved = (m * nq * bytes_per_unit) / (count_ms * 1e-3) / 1e9
+    out = {
+        "metric": "quartets counted/sec",
+        "value": value,
+        "unit": "quartets/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32" if args.count_bits == 32 else "u16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[1]: {n} taxa, {m} random eval trees per GPU, uint{args.count_bits} C(n,4)x3 table "
+                        f"({nq} quartets), seeds 2000/2001+rank",
+            "algo": variant,
+            "step": "table clear + pair-depth panel build + count kernel" + (" + RCCL all-reduce of the table" if world > 1 else ""),
+            "parity_tuple_sums_ok": parity,
+            "panel_kernel_ms": panel_ms,
+            "count_kernel_ms": count_ms,
+            "score_phase_ms": score_ms,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "count_gather_kernel" if args.algo == "gather" else "count_scatter_kernel",
+            "algorithmic_bytes_per_launch": m * nq * bytes_per_unit,
+            "avg_launch_ms": count_ms,
+            "note": "achieved = algorithmic RMW bytes of the reference formulation (8 B per tree x quartet) / kernel time; "
+                    "the gather kernel keeps counters in registers and writes each cell once, so real HBM traffic is far "
+                    "below this and frac can exceed 1 (its own limit is VALU issue, see DESIGN.md)",
+        },
+    }
+
+    if not args.no_cpu_baseline:
+        try:
+            from oracle_api import Oracle
+            cores = os.cpu_count() or 1
+            mp = args.cpu_baseline_trees or max(8, min(m, int(2.0e8 * cores * 15 / nq)))  # ~15 s at ~2e8 pairs/s/core-ish
+            mp = min(mp, m)
+            o = Oracle(ref_nw)
+            tc = o.count("\n".join(trees[:mp]), savemem=False, nthreads=cores)
+            cpu_val = mp * nq / tc
+            # the same prefix counted on the GPU must give the same table (bit-exact gate)
+            ctx.table_clear()
+            ctx.count_trees(batch.slice(0, mp), algo)
+            same = bool((ctx.table_download().astype(np.uint64) == o.counts()).all())
+            out["cpu_baseline"] = {
+                "value": cpu_val, "unit": "quartets/s", "cores": cores, "kind": "port",
+                "sample": f"first {mp} of the {m} trees, n={n}, reference fast (n^4) table, OpenMP -t {cores}, {tc:.2f} s",
+                "gpu_table_bit_exact_on_sample": same,
+            }
+            o.close()
+        except Exception as e:  # the baseline is reported, never required for the metric
+            out["cpu_baseline"] = {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/*
+ * quartetscores_hip.h -- C-ABI of the MI355X (gfx950) quartet-support engine.
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of
+ * lutteropp/QuartetScores: quartet-topology counting into the
+ * C(n,4) x 3 table and the LQ-/QP-/EQP-IC reduction. The reference has no FFI; the
+ * seam is the two class templates its main() uses. Each entry point below names the
+ * reference interface it replaces (paths relative to /root/reference/src):
+ *
+ *   qs_create / qs_destroy        QuartetCounterLookup<CINT> ctor/dtor: table allocation
+ *                                 (QuartetCounterLookup.hpp:245-273, quartet_lookup_table.hpp:59-63,135-139)
+ *   qs_count_trees                QuartetCounterLookup::countQuartets / updateQuartets /
+ *                                 updateQuartetsThreeLinks / updateQuartetsThreeClades
+ *                                 (QuartetCounterLookup.hpp:65-238), on pre-flattened trees
+ *   qs_lookup                     QuartetCounterLookup::countQuartetOccurrences
+ *                                 (QuartetCounterLookup.hpp:299-318)
+ *   qs_table_*                    QuartetLookupTable<T> storage (quartet_lookup_table.hpp:19-228)
+ *   qs_score                      QuartetScoreComputer: processNodePair /
+ *                                 computeQuartetScoresBifurcating / ...Multifurcating
+ *                                 (QuartetScoreComputer.hpp:379-593) + getLQIC/QPIC/EQPICScores (:106-125)
+ *   qs_raw_qic                    QuartetScoreComputer::printRawQICScores (:623-690), numeric part
+ *
+ * Conventions: plain pointers and sizes only; every function returns a status code
+ * (QS_OK == 0) and never throws; qs_last_error() gives the message. The caller owns
+ * all host buffers and lends them for the duration of a call; the library owns device
+ * memory except a table attached with qs_table_attach(). One context drives one GPU
+ * from one host thread; multi-GPU = one process (context) per GPU with the table
+ * all-reduced by the caller (RCCL through torch.distributed).
+ * There is NO CPU fallback: every entry point that computes needs a gfx950 device.
+ *
+ * Data model. Taxa have lookup ids 0..n-1 = the reference
+ * tree's leaf order in a depth-first tour (QuartetCounterLookup.hpp:252-258). The
+ * count table holds, for every 4-set s0<s1<s2<s3 at
+ *     rank = C(s3,4) + C(s2,3) + C(s1,2) + s0          (quartet_lookup_table.hpp:161-165)
+ * the tuple [ #s0s1|s2s3, #s0s2|s1s3, #s0s3|s1s2 ]     (quartet_lookup_table.hpp:87-111)
+ * as `count_bits`-wide unsigned integers, array-of-tuples exactly like the reference's
+ * std::vector<std::array<T,3>>. Counts are the SEMANTIC counts (number of evaluation
+ * trees displaying the topology) = the reference's fast-table values = half of what its
+ * --savemem table stores.
+ */
+#ifndef QUARTETSCORES_HIP_H
+#define QUARTETSCORES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qs_ctx qs_ctx;
+
+/* status codes */
+enum {
+    QS_OK = 0,
+    QS_ERR_ARG = -1,        /* bad argument / malformed flattened tree */
+    QS_ERR_HIP = -2,        /* HIP runtime error (message has the HIP string) */
+    QS_ERR_OOM = -3,        /* "Insufficient memory!" (QuartetScoreComputer.hpp:735-737) */
+    QS_ERR_STATE = -4,      /* call order (e.g. score before count) */
+    QS_ERR_OVERFLOW = -5,   /* a counter would exceed count_bits, or candidate buffer overflow */
+    QS_ERR_NO_DEVICE = -6,  /* no gfx950 device: the library does not fall back to the CPU */
+    QS_ERR_UNSUPPORTED = -7
+};
+
+/* qs_create flags */
+#define QS_FLAG_NONE 0u
+
+/* counting algorithm selector for qs_count_trees */
+#define QS_ALGO_AUTO 0u     /* = QS_ALGO_GATHER */
+#define QS_ALGO_GATHER 1u   /* quartet-major: each lane owns table cells, trees streamed as pair-depth panels */
+#define QS_ALGO_SCATTER 2u  /* tree-major: one wavefront per (tree, inner node, orientation), atomicAdd */
+
+/* qs_score flags */
+#define QS_SCORE_QP_WRAP32 0u   /* reference-compatible: QP sums kept mod 2^32 (QuartetScoreComputer.hpp:382) */
+#define QS_SCORE_QP_EXACT64 1u  /* 64-bit sums */
+
+/*
+ * A batch of evaluation trees, flattened by the host (see quartetscores_amd/csrc/host
+ * or quartetscores_amd/flatten.py). For tree t, with L_t = leaf_off[t+1]-leaf_off[t]:
+ *   leaf_ids [leaf_off[t] + i], i < L_t : lookup id of the i-th leaf in a depth-first tour
+ *                                         == eulerTourLeaves (QuartetCounterLookup.hpp:211-221)
+ *   adj_depth[leaf_off[t] + i], i < L_t-1: depth (edges from the tour's root) of the lowest
+ *                                         common ancestor of leaves i and i+1; entry L_t-1 is 0.
+ *                                         (leaf_ids, adj_depth) determine the tree.
+ * Inner nodes (needed by QS_ALGO_SCATTER only; may be NULL otherwise):
+ *   node_off[t] .. node_off[t+1]        : inner nodes of tree t
+ *   rng_off[v] .. rng_off[v+1]          : the links of inner node v
+ *   ranges[2*k], ranges[2*k+1]          : circular half-open [start,end) leaf positions behind
+ *                                         link k == subtreeLeafIndices (QuartetCounterLookup.hpp:117-121)
+ * A leaf label unknown to the reference is a host-side error (QuartetCounterLookup.hpp:218);
+ * taxa missing from a tree simply do not appear in leaf_ids.
+ */
+typedef struct {
+    uint32_t n_trees;
+    const uint32_t *leaf_off;  /* n_trees + 1 */
+    const uint16_t *leaf_ids;
+    const uint16_t *adj_depth;
+    const uint32_t *node_off;  /* n_trees + 1, or NULL */
+    const uint32_t *rng_off;   /* node_off[n_trees] + 1, or NULL */
+    const uint16_t *ranges;    /* 2 * rng_off[last], or NULL */
+} qs_tree_batch;
+
+/*
+ * The reference tree, flattened. Nodes 0..n_nodes-1, parent[root] = -1. leaf_node[i] is
+ * the node of the taxon with lookup id i; lookup ids must be in depth-first order (every
+ * node's leaves form one contiguous id interval), which qs_score verifies. A degree-2
+ * root is treated as an edge subdivision (SURVEY.md quirk Q5 is NOT reproduced; see
+ * DESIGN.md).
+ */
+typedef struct {
+    uint32_t n_nodes;
+    uint32_t n_taxa;
+    const int32_t *parent;     /* n_nodes */
+    const uint32_t *leaf_node; /* n_taxa */
+} qs_ref_tree;
+
+/* ---- lifecycle ----------------------------------------------------------------------- */
+
+/*
+ * n_taxa in [4, 4096]; count_bits 16 or 32 (the reference picks u8/u16/u32/u64 from m,
+ * QuartetScores.cpp:115-147; counts compare as integers). device = HIP
+ * device ordinal. stream = hipStream_t to launch on (NULL = the default stream).
+ * The table is not allocated until qs_table_alloc / qs_table_attach.
+ * d_lo/d_hi shard the table by the LARGEST taxon id of the 4-set: this context owns the
+ * ranks [C(d_lo,4), C(d_hi,4)); pass 0, n_taxa for the whole table.
+ */
+int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uint32_t flags, int device, void *stream,
+              uint32_t d_lo, uint32_t d_hi);
+void qs_destroy(qs_ctx *ctx);
+const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the last failed qs_create */
+const char *qs_version(void);
+
+/* ---- count table (QuartetLookupTable) ------------------------------------------------- */
+
+uint64_t qs_table_tuples(const qs_ctx *ctx); /* number of 4-sets owned = C(d_hi,4)-C(d_lo,4) */
+uint64_t qs_table_bytes(const qs_ctx *ctx);  /* tuples * 3 * count_bits/8 (compare quartet_lookup_table.hpp:69-71) */
+int qs_table_alloc(qs_ctx *ctx);             /* hipMalloc + zero; QS_ERR_OOM if it does not fit */
+int qs_table_attach(qs_ctx *ctx, void *device_ptr, uint64_t bytes); /* caller-owned device memory, e.g. a torch tensor */
+void *qs_table_device_ptr(const qs_ctx *ctx);
+int qs_table_clear(qs_ctx *ctx);
+int qs_table_download(qs_ctx *ctx, void *host_dst, uint64_t bytes);
+int qs_table_upload(qs_ctx *ctx, const void *host_src, uint64_t bytes);
+
+/* ---- counting (QuartetCounterLookup::countQuartets) ------------------------------------ */
+
+/* Opaque device-resident copy of a batch. */
+typedef struct qs_device_batch qs_device_batch;
+
+/* Validates and copies the batch into HBM (synchronous w.r.t. the host buffers). */
+int qs_batch_upload(qs_ctx *ctx, const qs_tree_batch *batch, qs_device_batch **out);
+void qs_batch_free(qs_ctx *ctx, qs_device_batch *b);
+
+/* Adds the quartet topologies of every tree of the batch to the table. Asynchronous on the
+ * context's stream; inputs already resident in HBM. */
+int qs_count_batch(qs_ctx *ctx, const qs_device_batch *b, uint32_t algo);
+
+/* Convenience = qs_batch_upload + qs_count_batch + qs_sync + qs_batch_free. */
+int qs_count_trees(qs_ctx *ctx, const qs_tree_batch *batch, uint32_t algo);
+
+int qs_sync(qs_ctx *ctx); /* hipStreamSynchronize + deferred error check */
+
+/* Total evaluation trees counted so far (the m of the reference). */
+uint64_t qs_trees_counted(const qs_ctx *ctx);
+
+/* countQuartetOccurrences for nq quartets: abcd[4*i..] are lookup ids (any order, distinct),
+ * out3[3*i..] = (#ab|cd, #ac|bd, #ad|bc). Quartets outside this context's shard give 0,0,0. */
+int qs_lookup(qs_ctx *ctx, uint64_t nq, const uint16_t *abcd, uint64_t *out3);
+
+/* ---- scoring (QuartetScoreComputer) ----------------------------------------------------- */
+
+/*
+ * LQ-IC, QP-IC, EQP-IC per edge. Output arrays have n_nodes entries, indexed by the CHILD
+ * node of each edge (entry of the root unused); untouched edges = +inf like the reference
+ * (QuartetScoreComputer.hpp:762-774). For a multifurcating reference only lqic is written
+ * (qpic/eqpic may be NULL) and *is_bifurcating = 0 (QuartetScoreComputer.hpp:760-765).
+ * The O(C(n,4)) enumeration, sums and minima run on the GPU; the final O(#node pairs)
+ * log_score evaluations use the host's libm so scores are bit-identical to the
+ * reference's CPU arithmetic (QuartetScoreComputer.hpp:135-159).
+ */
+int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, double *qpic, double *eqpic,
+             int *is_bifurcating);
+
+/*
+ * Raw per-quartet QIC (numeric part of printRawQICScores): for ranks [r0, r0+nq) of this
+ * context's shard, topo[i] = 0 (s0s1|s2s3), 2 (s0s3|s1s2) or 255 (unresolved in the
+ * reference tree: skipped by the reference, QuartetScoreComputer.hpp:669-672) and
+ * q[3*i..] = (q1,q2,q3) in the reference's argument order for log_score.
+ */
+int qs_raw_qic(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q);
+
+/* ---- measurement hooks ------------------------------------------------------------------ */
+
+/* Device time in milliseconds of the most recent qs_count_batch, split by kernel
+ * (HIP events on the context's stream): [0] pair-panel build, [1] count kernel, [2] total. */
+int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
+/* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
+const char *qs_last_count_variant(const qs_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUARTETSCORES_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of quartetscores_amd/lib/libquartetscores_hip.so (include/quartetscores_hip.h).
+
+Fails loudly when the library is missing: there is no CPU fallback in the product.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libquartetscores_hip.so")
+
+QS_OK = 0
+QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEVICE, QS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER = 0, 1, 2
+QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
+
+# every symbol include/quartetscores_hip.h declares
+EXPORTS = [
+    "qs_create", "qs_destroy", "qs_last_error", "qs_version", "qs_table_tuples", "qs_table_bytes", "qs_table_alloc",
+    "qs_table_attach", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
+    "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
+    "qs_score", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
+]
+
+
+class TreeBatchC(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("leaf_off", C.c_void_p), ("leaf_ids", C.c_void_p), ("adj_depth", C.c_void_p),
+                ("node_off", C.c_void_p), ("rng_off", C.c_void_p), ("ranges", C.c_void_p)]
+
+
+class RefTreeC(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_taxa", C.c_uint32), ("parent", C.c_void_p), ("leaf_node", C.c_void_p)]
+
+
+_lib = None
+
+
+class LibraryMissing(ImportError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises LibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C quartetscores_amd/csrc` (or __graft_entry__.build()). "
+            "quartetscores_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.qs_create.restype = i32
+    L.qs_create.argtypes = [C.POINTER(vp), u32, u32, u32, i32, vp, u32, u32]
+    L.qs_destroy.restype = None
+    L.qs_destroy.argtypes = [vp]
+    L.qs_last_error.restype = C.c_char_p
+    L.qs_last_error.argtypes = [vp]
+    L.qs_version.restype = C.c_char_p
+    L.qs_version.argtypes = []
+    L.qs_table_tuples.restype = u64
+    L.qs_table_tuples.argtypes = [vp]
+    L.qs_table_bytes.restype = u64
+    L.qs_table_bytes.argtypes = [vp]
+    L.qs_table_alloc.restype = i32
+    L.qs_table_alloc.argtypes = [vp]
+    L.qs_table_attach.restype = i32
+    L.qs_table_attach.argtypes = [vp, vp, u64]
+    L.qs_table_device_ptr.restype = vp
+    L.qs_table_device_ptr.argtypes = [vp]
+    L.qs_table_clear.restype = i32
+    L.qs_table_clear.argtypes = [vp]
+    L.qs_table_download.restype = i32
+    L.qs_table_download.argtypes = [vp, vp, u64]
+    L.qs_table_upload.restype = i32
+    L.qs_table_upload.argtypes = [vp, vp, u64]
+    L.qs_batch_upload.restype = i32
+    L.qs_batch_upload.argtypes = [vp, C.POINTER(TreeBatchC), C.POINTER(vp)]
+    L.qs_batch_free.restype = None
+    L.qs_batch_free.argtypes = [vp, vp]
+    L.qs_count_batch.restype = i32
+    L.qs_count_batch.argtypes = [vp, vp, u32]
+    L.qs_count_trees.restype = i32
+    L.qs_count_trees.argtypes = [vp, C.POINTER(TreeBatchC), u32]
+    L.qs_sync.restype = i32
+    L.qs_sync.argtypes = [vp]
+    L.qs_trees_counted.restype = u64
+    L.qs_trees_counted.argtypes = [vp]
+    L.qs_lookup.restype = i32
+    L.qs_lookup.argtypes = [vp, u64, vp, vp]
+    L.qs_score.restype = i32
+    L.qs_score.argtypes = [vp, C.POINTER(RefTreeC), u32, vp, vp, vp, C.POINTER(i32)]
+    L.qs_raw_qic.restype = i32
+    L.qs_raw_qic.argtypes = [vp, C.POINTER(RefTreeC), u64, u64, vp, vp]
+    L.qs_last_count_ms.restype = i32
+    L.qs_last_count_ms.argtypes = [vp, C.POINTER(C.c_float * 3)]
+    L.qs_last_count_variant.restype = C.c_char_p
+    L.qs_last_count_variant.argtypes = [vp]
+    _lib = L
+    return L

@@ -1,0 +1,603 @@
+// qs_abi.hip -- implementation of the C-ABI declared in include/quartetscores_hip.h.
+//
+// Host-side orchestration only: validation of the flattened trees, device memory, kernel
+// dispatch, and the O(#node pairs) finalisation of the scores. All O(m*C(n,4)) and O(C(n,4))
+// work runs in the HIP kernels of qs_count.hip / qs_score.hip. There is no CPU fallback.
+#include "../../include/quartetscores_hip.h"
+#include "qs_common.hpp"
+#include "qs_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace qs;
+
+struct qs_device_batch {
+    DeviceBatch d;
+};
+
+struct qs_ctx {
+    uint32_t n = 0, count_bits = 32, flags = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t d_lo = 0, d_hi = 0;
+    uint64_t rank_lo = 0, n_tuples = 0;
+    void *table = nullptr;
+    bool table_owned = false;
+    uint64_t trees_counted = 0;
+    // geometry
+    uint32_t *dprefix = nullptr, *cprefix = nullptr;
+    uint32_t n_dblk = 0, total_tiles = 0;
+    // workspace
+    void *panel = nullptr;
+    size_t panel_bytes = 0;
+    uint32_t *dev_flags = nullptr; // [0] counter overflow, [1] score flags
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    std::string variant;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static int fail(qs_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define QS_HIP(c, expr)                                                                                 \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail((c), e__ == hipErrorOutOfMemory ? QS_ERR_OOM : QS_ERR_HIP,                      \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+    } while (0)
+
+extern "C" const char *qs_version(void) { return "quartetscores_amd 0.1.0 (gfx950)"; }
+
+extern "C" const char *qs_last_error(const qs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uint32_t flags, int device, void *stream,
+                         uint32_t d_lo, uint32_t d_hi) {
+    if (!out) return fail(nullptr, QS_ERR_ARG, "qs_create: out is NULL");
+    *out = nullptr;
+    if (n_taxa < 4 || n_taxa > 4096) return fail(nullptr, QS_ERR_ARG, "qs_create: n_taxa must be in [4, 4096]");
+    if (count_bits != 16 && count_bits != 32) return fail(nullptr, QS_ERR_ARG, "qs_create: count_bits must be 16 or 32");
+    if (d_lo == 0 && d_hi == 0) d_hi = n_taxa;
+    if (d_hi > n_taxa || d_lo >= d_hi) return fail(nullptr, QS_ERR_ARG, "qs_create: bad shard [d_lo, d_hi)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, QS_ERR_NO_DEVICE,
+                    "qs_create: no HIP device (this library has no CPU fallback; it needs a gfx950 GPU)");
+    if (device < 0 || device >= ndev) return fail(nullptr, QS_ERR_ARG, "qs_create: bad device ordinal");
+    QS_HIP(nullptr, hipSetDevice(device));
+    qs_ctx *c = new qs_ctx();
+    c->n = n_taxa; c->count_bits = count_bits; c->flags = flags; c->device = device;
+    c->stream = (hipStream_t)stream;
+    c->d_lo = d_lo; c->d_hi = d_hi;
+    c->rank_lo = binom4(d_lo);
+    c->n_tuples = binom4(d_hi) - binom4(d_lo);
+    // tile geometry of the gather kernel
+    std::vector<uint32_t> cp(n_taxa + 2, 0);
+    for (uint32_t cc = 2; cc <= n_taxa; ++cc)
+        cp[cc + 1] = cp[cc] + (uint32_t)((binom2(cc) + kCountThreads - 1) / kCountThreads);
+    // note: cp[c] = tiles of all c' < c (c' >= 2)
+    const uint32_t d_start = std::max(d_lo, 3u);
+    c->n_dblk = d_hi > d_start ? (d_hi - d_start + kDB - 1) / kDB : 0;
+    std::vector<uint32_t> dp(c->n_dblk + 1, 0);
+    for (uint32_t k = 0; k < c->n_dblk; ++k) {
+        uint32_t d0 = d_start + k * kDB, d1 = std::min(d0 + (uint32_t)kDB, d_hi);
+        dp[k + 1] = dp[k] + cp[d1 - 1]; // c in [2, d1-1)
+    }
+    c->total_tiles = dp[c->n_dblk];
+    // the kernels take d_lo as the first d of block 0
+    c->d_lo = d_lo; // shard boundary for ranks
+    auto cleanup = [&](int code, const std::string &m) { qs_destroy(c); return fail(nullptr, code, m); };
+    if (hipMalloc(&c->cprefix, cp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix");
+    if (hipMalloc(&c->dprefix, dp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix");
+    if (hipMemcpy(c->cprefix, cp.data(), cp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix");
+    if (hipMemcpy(c->dprefix, dp.data(), dp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix");
+    if (hipMalloc(&c->dev_flags, 16) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc flags");
+    if (hipMemset(c->dev_flags, 0, 16) != hipSuccess) return cleanup(QS_ERR_HIP, "memset flags");
+    for (int i = 0; i < 3; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) return cleanup(QS_ERR_HIP, "hipEventCreate");
+    *out = c;
+    return QS_OK;
+}
+
+extern "C" void qs_destroy(qs_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->table && c->table_owned) (void)hipFree(c->table);
+    if (c->panel) (void)hipFree(c->panel);
+    if (c->dprefix) (void)hipFree(c->dprefix);
+    if (c->cprefix) (void)hipFree(c->cprefix);
+    if (c->dev_flags) (void)hipFree(c->dev_flags);
+    for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+// ---- table -------------------------------------------------------------------------------
+
+extern "C" uint64_t qs_table_tuples(const qs_ctx *c) { return c ? c->n_tuples : 0; }
+extern "C" uint64_t qs_table_bytes(const qs_ctx *c) { return c ? c->n_tuples * 3 * (c->count_bits / 8) : 0; }
+extern "C" void *qs_table_device_ptr(const qs_ctx *c) { return c ? c->table : nullptr; }
+extern "C" uint64_t qs_trees_counted(const qs_ctx *c) { return c ? c->trees_counted : 0; }
+
+extern "C" int qs_table_alloc(qs_ctx *c) {
+    if (!c) return QS_ERR_ARG;
+    QS_HIP(c, hipSetDevice(c->device));
+    if (c->table && c->table_owned) { (void)hipFree(c->table); c->table = nullptr; }
+    size_t bytes = (size_t)qs_table_bytes(c);
+    size_t freeb = 0, total = 0;
+    QS_HIP(c, hipMemGetInfo(&freeb, &total));
+    if (bytes + (64u << 20) > freeb) return fail(c, QS_ERR_OOM, "Insufficient memory!");
+    hipError_t e = hipMalloc(&c->table, bytes + 16);
+    if (e != hipSuccess) { c->table = nullptr; return fail(c, QS_ERR_OOM, "Insufficient memory!"); }
+    c->table_owned = true;
+    c->trees_counted = 0;
+    QS_HIP(c, hipMemsetAsync(c->table, 0, bytes + 16, c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_table_attach(qs_ctx *c, void *device_ptr, uint64_t bytes) {
+    if (!c || !device_ptr) return fail(c, QS_ERR_ARG, "qs_table_attach: NULL");
+    if (bytes < qs_table_bytes(c)) return fail(c, QS_ERR_ARG, "qs_table_attach: buffer smaller than qs_table_bytes()");
+    if ((uintptr_t)device_ptr & 3) return fail(c, QS_ERR_ARG, "qs_table_attach: pointer must be 4-byte aligned");
+    if (c->table && c->table_owned) (void)hipFree(c->table);
+    c->table = device_ptr;
+    c->table_owned = false;
+    return QS_OK;
+}
+
+extern "C" int qs_table_clear(qs_ctx *c) {
+    if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_table_clear: no table");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, hipMemsetAsync(c->table, 0, (size_t)qs_table_bytes(c), c->stream));
+    c->trees_counted = 0;
+    return QS_OK;
+}
+
+extern "C" int qs_table_download(qs_ctx *c, void *host_dst, uint64_t bytes) {
+    if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_table_download: no table");
+    if (bytes > qs_table_bytes(c)) return fail(c, QS_ERR_ARG, "qs_table_download: too many bytes");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, hipMemcpyAsync(host_dst, c->table, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_table_upload(qs_ctx *c, const void *host_src, uint64_t bytes) {
+    if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_table_upload: no table");
+    if (bytes > qs_table_bytes(c)) return fail(c, QS_ERR_ARG, "qs_table_upload: too many bytes");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, hipMemcpyAsync(c->table, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    QS_HIP(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+// ---- batches -----------------------------------------------------------------------------
+
+extern "C" void qs_batch_free(qs_ctx *c, qs_device_batch *b) {
+    if (!b) return;
+    if (c) (void)hipSetDevice(c->device);
+    (void)hipFree(b->d.leaf_off); (void)hipFree(b->d.leaf_ids); (void)hipFree(b->d.adj_depth);
+    (void)hipFree(b->d.node_off); (void)hipFree(b->d.rng_off); (void)hipFree(b->d.node_tree); (void)hipFree(b->d.ranges);
+    delete b;
+}
+
+template <typename T> static hipError_t to_device(T **dst, const T *src, size_t count) {
+    *dst = nullptr;
+    hipError_t e = hipMalloc((void **)dst, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (count) e = hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_batch **out) {
+    if (!c || !hb || !out) return fail(c, QS_ERR_ARG, "qs_batch_upload: NULL argument");
+    *out = nullptr;
+    if (!hb->leaf_off || (hb->n_trees && (!hb->leaf_ids || !hb->adj_depth)))
+        return fail(c, QS_ERR_ARG, "qs_batch_upload: leaf arrays missing");
+    const uint32_t nt = hb->n_trees, n = c->n;
+    // ---- validate (the reference dies on malformed input; we return a status) ----
+    uint32_t max_depth = 0;
+    bool all_full = true, all_binary = true;
+    std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
+    std::vector<uint32_t> stack;
+    for (uint32_t t = 0; t < nt; ++t) {
+        if (hb->leaf_off[t + 1] < hb->leaf_off[t]) return fail(c, QS_ERR_ARG, "qs_batch_upload: leaf_off not monotone");
+        const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
+        if (L > n) return fail(c, QS_ERR_ARG, "qs_batch_upload: tree " + std::to_string(t) + " has more leaves than taxa");
+        if (L != n) all_full = false;
+        for (uint32_t i = 0; i < L; ++i) {
+            const uint32_t id = hb->leaf_ids[base + i];
+            if (id >= n) return fail(c, QS_ERR_ARG, "qs_batch_upload: tree " + std::to_string(t) + ": taxon id out of range (unknown taxon)");
+            if (stamp[id] == t) return fail(c, QS_ERR_ARG, "qs_batch_upload: tree " + std::to_string(t) + ": duplicate taxon");
+            stamp[id] = t;
+        }
+        // internal nodes from the adjacent-LCA depth sequence
+        stack.clear();
+        uint32_t nodes = 0, zeros = 0;
+        for (uint32_t i = 0; i + 1 < L; ++i) {
+            const uint32_t dd = hb->adj_depth[base + i];
+            max_depth = std::max(max_depth, dd);
+            if (dd == 0) ++zeros;
+            while (!stack.empty() && stack.back() > dd) stack.pop_back();
+            if (stack.empty() || stack.back() < dd) { stack.push_back(dd); ++nodes; }
+        }
+        const bool binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
+        if (!binary) all_binary = false;
+    }
+    qs_device_batch *b = new qs_device_batch();
+    DeviceBatch &d = b->d;
+    d.n_trees = nt;
+    d.total_leaves = nt ? hb->leaf_off[nt] : 0;
+    d.max_depth = max_depth; d.all_full = all_full && nt > 0; d.all_binary = all_binary && nt > 0;
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = to_device(&d.leaf_off, hb->leaf_off, (size_t)nt + 1);
+    if (e == hipSuccess) e = to_device(&d.leaf_ids, hb->leaf_ids, d.total_leaves);
+    if (e == hipSuccess) e = to_device(&d.adj_depth, hb->adj_depth, d.total_leaves);
+    if (e == hipSuccess && hb->node_off && hb->rng_off && hb->ranges) {
+        d.n_nodes = hb->node_off[nt];
+        d.n_links = hb->rng_off[d.n_nodes];
+        std::vector<uint32_t> node_tree(d.n_nodes);
+        for (uint32_t t = 0; t < nt; ++t) {
+            const uint32_t L = hb->leaf_off[t + 1] - hb->leaf_off[t];
+            for (uint32_t v = hb->node_off[t]; v < hb->node_off[t + 1]; ++v) {
+                node_tree[v] = t;
+                for (uint32_t k = hb->rng_off[v]; k < hb->rng_off[v + 1]; ++k)
+                    if (hb->ranges[2 * k] >= std::max(L, 1u) || hb->ranges[2 * k + 1] >= std::max(L, 1u)) {
+                        qs_batch_free(c, b);
+                        return fail(c, QS_ERR_ARG, "qs_batch_upload: range position out of bounds");
+                    }
+            }
+        }
+        if (e == hipSuccess) e = to_device(&d.node_off, hb->node_off, (size_t)nt + 1);
+        if (e == hipSuccess) e = to_device(&d.rng_off, hb->rng_off, (size_t)d.n_nodes + 1);
+        if (e == hipSuccess) e = to_device(&d.node_tree, node_tree.data(), d.n_nodes);
+        if (e == hipSuccess) e = to_device(&d.ranges, hb->ranges, (size_t)2 * d.n_links);
+    }
+    if (e != hipSuccess) {
+        qs_batch_free(c, b);
+        return fail(c, e == hipErrorOutOfMemory ? QS_ERR_OOM : QS_ERR_HIP, std::string("qs_batch_upload: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return QS_OK;
+}
+
+extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo) {
+    if (!c || !b) return fail(c, QS_ERR_ARG, "qs_count_batch: NULL argument");
+    if (!c->table) return fail(c, QS_ERR_STATE, "qs_count_batch: no table (qs_table_alloc / qs_table_attach first)");
+    const DeviceBatch &d = b->d;
+    if (d.n_trees == 0) return QS_OK;
+    QS_HIP(c, hipSetDevice(c->device));
+    if (c->count_bits == 16 && c->trees_counted + d.n_trees > 0xFFFFull)
+        return fail(c, QS_ERR_OVERFLOW, "qs_count_batch: more than 65535 trees need count_bits = 32");
+    if (algo == QS_ALGO_AUTO) algo = QS_ALGO_GATHER;
+    QS_HIP(c, hipEventRecord(c->ev[0], c->stream));
+    if (algo == QS_ALGO_GATHER) {
+        int mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
+        const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
+        const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
+        int bits;
+        if (d.max_depth <= lim8) bits = 8;
+        else if (d.max_depth <= lim16) bits = 16;
+        else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(d.max_depth) + " exceeds the panel range; re-root the tree at its centre");
+        const uint32_t tpc = 16 / (bits / 8);
+        const uint32_t n_chunks = (d.n_trees + tpc - 1) / tpc;
+        const size_t need = (size_t)n_chunks * (size_t)binom2(c->n) * 16;
+        if (need > c->panel_bytes) {
+            if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
+            hipError_t e = hipMalloc(&c->panel, need);
+            if (e != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
+            c->panel_bytes = need;
+        }
+        if (gather_lds_bytes(c->d_hi) > 160 * 1024) return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: n_taxa too large for the LDS row tile");
+        QS_HIP(c, launch_build_panel(c->stream, d, c->n, bits, mode == MODE_PARTIAL, c->panel, n_chunks));
+        QS_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        CountGeometry g;
+        g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
+        g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
+        QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, n_chunks, d.n_trees, c->table, (int)c->count_bits, c->dev_flags));
+        static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
+        c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
+    } else if (algo == QS_ALGO_SCATTER) {
+        if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
+        if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");
+        QS_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        QS_HIP(c, launch_count_scatter(c->stream, d, c->n, c->d_lo, c->d_hi, c->rank_lo, c->table, (int)c->count_bits));
+        c->variant = std::string("scatter/atomic/count_u") + std::to_string(c->count_bits);
+    } else {
+        return fail(c, QS_ERR_ARG, "qs_count_batch: unknown algo");
+    }
+    QS_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    c->ev_valid = true;
+    c->trees_counted += d.n_trees;
+    return QS_OK;
+}
+
+extern "C" int qs_sync(qs_ctx *c) {
+    if (!c) return QS_ERR_ARG;
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t fl[4] = {0, 0, 0, 0};
+    QS_HIP(c, hipMemcpy(fl, c->dev_flags, 16, hipMemcpyDeviceToHost));
+    if (fl[0]) {
+        (void)hipMemset(c->dev_flags, 0, 4);
+        return fail(c, QS_ERR_OVERFLOW, "count table overflow: a counter exceeded count_bits");
+    }
+    return QS_OK;
+}
+
+extern "C" int qs_count_trees(qs_ctx *c, const qs_tree_batch *batch, uint32_t algo) {
+    qs_device_batch *b = nullptr;
+    int rc = qs_batch_upload(c, batch, &b);
+    if (rc != QS_OK) return rc;
+    rc = qs_count_batch(c, b, algo);
+    int rc2 = qs_sync(c);
+    qs_batch_free(c, b);
+    return rc != QS_OK ? rc : rc2;
+}
+
+extern "C" int qs_last_count_ms(qs_ctx *c, float out_ms[3]) {
+    if (!c || !c->ev_valid) return fail(c, QS_ERR_STATE, "qs_last_count_ms: no count yet");
+    QS_HIP(c, hipEventSynchronize(c->ev[2]));
+    QS_HIP(c, hipEventElapsedTime(&out_ms[0], c->ev[0], c->ev[1]));
+    QS_HIP(c, hipEventElapsedTime(&out_ms[1], c->ev[1], c->ev[2]));
+    QS_HIP(c, hipEventElapsedTime(&out_ms[2], c->ev[0], c->ev[2]));
+    return QS_OK;
+}
+
+extern "C" const char *qs_last_count_variant(const qs_ctx *c) { return c ? c->variant.c_str() : ""; }
+
+extern "C" int qs_lookup(qs_ctx *c, uint64_t nq, const uint16_t *abcd, uint64_t *out3) {
+    if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_lookup: no table");
+    if (nq == 0) return QS_OK;
+    if (!abcd || !out3) return fail(c, QS_ERR_ARG, "qs_lookup: NULL");
+    for (uint64_t i = 0; i < nq * 4; ++i)
+        if (abcd[i] >= c->n) return fail(c, QS_ERR_ARG, "qs_lookup: id out of range");
+    QS_HIP(c, hipSetDevice(c->device));
+    uint16_t *dq = nullptr; uint64_t *dout = nullptr;
+    QS_HIP(c, hipMalloc(&dq, nq * 8));
+    hipError_t e = hipMalloc(&dout, nq * 24);
+    if (e != hipSuccess) { (void)hipFree(dq); return fail(c, QS_ERR_OOM, "qs_lookup: hipMalloc"); }
+    e = hipMemcpyAsync(dq, abcd, nq * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_lookup(c->stream, c->n, c->d_lo, c->d_hi, c->rank_lo, c->table, (int)c->count_bits, nq, dq, dout);
+    if (e == hipSuccess) e = hipMemcpyAsync(out3, dout, nq * 24, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dq); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, QS_ERR_HIP, std::string("qs_lookup: ") + hipGetErrorString(e));
+    return QS_OK;
+}
+
+// ---- scoring -----------------------------------------------------------------------------
+
+// QuartetScoreComputer.hpp:135-159, evaluated with the host's libm like the reference.
+static double host_log_score(uint64_t q1, uint64_t q2, uint64_t q3) {
+    if (q1 == 0 && q2 == 0 && q3 == 0) return 0;
+    uint64_t sum = q1 + q2 + q3;
+    double p1 = (double)q1 / sum, p2 = (double)q2 / sum, p3 = (double)q3 / sum;
+    double qic = 1;
+    if (p1 != 0) qic += p1 * std::log(p1) / std::log(3);
+    if (p2 != 0) qic += p2 * std::log(p2) / std::log(3);
+    if (p3 != 0) qic += p3 * std::log(p3) / std::log(3);
+    return (q1 < q2 || q1 < q3) ? qic * -1 : qic;
+}
+
+struct RefHost {
+    uint32_t n_nodes = 0, n = 0, n_inner = 0, root = 0;
+    std::vector<int32_t> parent;
+    std::vector<uint32_t> depth, nchild, inner_id, inner_node;
+    std::vector<uint32_t> lca; // n*n
+    bool bifurcating = false;
+};
+
+static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
+    if (!ref || !ref->parent || !ref->leaf_node) return fail(c, QS_ERR_ARG, "reference tree: NULL arrays");
+    if (ref->n_taxa != c->n) return fail(c, QS_ERR_ARG, "reference tree: n_taxa differs from the context");
+    const uint32_t N = ref->n_nodes, n = ref->n_taxa;
+    if (N < n + 1 || N > 65535) return fail(c, QS_ERR_ARG, "reference tree: bad node count");
+    R.n_nodes = N; R.n = n;
+    R.parent.assign(ref->parent, ref->parent + N);
+    R.nchild.assign(N, 0); R.depth.assign(N, 0);
+    int root = -1;
+    for (uint32_t v = 0; v < N; ++v) {
+        int p = R.parent[v];
+        if (p < 0) { if (root >= 0) return fail(c, QS_ERR_ARG, "reference tree: several roots"); root = (int)v; }
+        else if ((uint32_t)p >= N || (uint32_t)p == v) return fail(c, QS_ERR_ARG, "reference tree: bad parent");
+        else R.nchild[p]++;
+    }
+    if (root < 0) return fail(c, QS_ERR_ARG, "reference tree: no root");
+    R.root = (uint32_t)root;
+    // depths (parents may come after children in the numbering: iterate with memo)
+    std::vector<int> dep(N, -1);
+    dep[root] = 0;
+    std::vector<uint32_t> chain;
+    for (uint32_t v = 0; v < N; ++v) {
+        chain.clear();
+        uint32_t x = v;
+        while (dep[x] < 0) { chain.push_back(x); x = (uint32_t)R.parent[x]; if (chain.size() > N) return fail(c, QS_ERR_ARG, "reference tree: cycle"); }
+        int dd = dep[x];
+        for (size_t i = chain.size(); i-- > 0;) dep[chain[i]] = ++dd;
+    }
+    for (uint32_t v = 0; v < N; ++v) R.depth[v] = (uint32_t)dep[v];
+    std::vector<uint8_t> is_leaf_taxon(N, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t v = ref->leaf_node[i];
+        if (v >= N || R.nchild[v] != 0 || is_leaf_taxon[v]) return fail(c, QS_ERR_ARG, "reference tree: leaf_node must list distinct leaves");
+        is_leaf_taxon[v] = 1;
+    }
+    uint32_t n_leaf_nodes = 0;
+    for (uint32_t v = 0; v < N; ++v) if (R.nchild[v] == 0) n_leaf_nodes++;
+    if (n_leaf_nodes != n) return fail(c, QS_ERR_ARG, "reference tree: number of leaves differs from n_taxa");
+    // depth-first order check: every node's leaves form one contiguous id interval
+    std::vector<uint32_t> lo(N, 0xFFFFFFFFu), hi(N, 0), cnt(N, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t x = ref->leaf_node[i];
+        for (;;) {
+            lo[x] = std::min(lo[x], i); hi[x] = std::max(hi[x], i); cnt[x]++;
+            if (R.parent[x] < 0) break;
+            x = (uint32_t)R.parent[x];
+        }
+    }
+    for (uint32_t v = 0; v < N; ++v)
+        if (cnt[v] && hi[v] - lo[v] + 1 != cnt[v])
+            return fail(c, QS_ERR_ARG, "reference tree: lookup ids are not in depth-first leaf order");
+    // is_bifurcating: max over nodes of (degree - 1) == 2 (QuartetScoreComputer.hpp:760)
+    uint32_t max_rank = 0;
+    for (uint32_t v = 0; v < N; ++v) {
+        uint32_t deg = R.nchild[v] + (R.parent[v] >= 0 ? 1 : 0);
+        if (deg >= 1) max_rank = std::max(max_rank, deg - 1);
+    }
+    R.bifurcating = (max_rank == 2);
+    R.inner_id.assign(N, 0xFFFFFFFFu);
+    R.inner_node.clear();
+    for (uint32_t v = 0; v < N; ++v)
+        if (R.nchild[v] > 0) { R.inner_id[v] = (uint32_t)R.inner_node.size(); R.inner_node.push_back(v); }
+    R.n_inner = (uint32_t)R.inner_node.size();
+    // LCA of leaves with adjacent ids, then running minima per row
+    std::vector<uint32_t> adj(n > 0 ? n - 1 : 0);
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        uint32_t x = ref->leaf_node[i], y = ref->leaf_node[i + 1];
+        while (x != y) {
+            if (R.depth[x] >= R.depth[y]) x = (uint32_t)R.parent[x]; else y = (uint32_t)R.parent[y];
+        }
+        adj[i] = x;
+    }
+    R.lca.assign((size_t)n * n, 0);
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        uint32_t cur = adj[i];
+        for (uint32_t j = i + 1; j < n; ++j) {
+            if (j > i + 1 && R.depth[adj[j - 1]] < R.depth[cur]) cur = adj[j - 1];
+            uint32_t e = (R.depth[cur] << 16) | R.inner_id[cur];
+            R.lca[(size_t)i * n + j] = e;
+            R.lca[(size_t)j * n + i] = e;
+        }
+    }
+    return QS_OK;
+}
+
+struct ScoreBuffers {
+    uint32_t *lca = nullptr;
+    unsigned long long *sums = nullptr, *mn = nullptr, *cand = nullptr;
+    ~ScoreBuffers() { (void)hipFree(lca); (void)hipFree(sums); (void)hipFree(mn); (void)hipFree(cand); }
+};
+
+static void fill_score_device(const qs_ctx *c, const RefHost &R, const ScoreBuffers &B, ScoreDevice &sd) {
+    sd.ref_lca = B.lca; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
+    sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
+    sd.pair_sums = B.sums; sd.pair_min = B.mn; sd.pair_cand = B.cand; sd.flags = c->dev_flags + 1;
+    sd.frame = R.bifurcating ? 0 : 1;
+}
+
+extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, double *lqic, double *qpic, double *eqpic,
+                        int *is_bifurcating) {
+    if (!c || !lqic) return fail(c, QS_ERR_ARG, "qs_score: NULL");
+    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score: no table");
+    if (c->d_lo != 0 || c->d_hi != c->n) return fail(c, QS_ERR_UNSUPPORTED, "qs_score: needs the whole table on this context (table-sharded scoring is not implemented yet)");
+    RefHost R;
+    int rc = build_ref(c, ref, R);
+    if (rc != QS_OK) return rc;
+    if (is_bifurcating) *is_bifurcating = R.bifurcating ? 1 : 0;
+    if (R.bifurcating && (!qpic || !eqpic)) return fail(c, QS_ERR_ARG, "qs_score: qpic/eqpic required for a bifurcating reference");
+    QS_HIP(c, hipSetDevice(c->device));
+    const size_t np = (size_t)R.n_inner * R.n_inner;
+    ScoreBuffers B;
+    QS_HIP(c, hipMalloc(&B.lca, R.lca.size() * 4));
+    QS_HIP(c, hipMalloc(&B.sums, np * 3 * 8));
+    QS_HIP(c, hipMalloc(&B.mn, np * 8));
+    QS_HIP(c, hipMalloc(&B.cand, np * kCand * 8));
+    QS_HIP(c, hipMemcpyAsync(B.lca, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    QS_HIP(c, hipMemsetAsync(B.sums, 0, np * 3 * 8, c->stream));
+    QS_HIP(c, hipMemsetAsync(B.mn, 0xFF, np * 8, c->stream));
+    QS_HIP(c, hipMemsetAsync(B.cand, 0xFF, np * kCand * 8, c->stream));
+    QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
+    ScoreDevice sd;
+    fill_score_device(c, R, B, sd);
+    QS_HIP(c, launch_score_pass1(c->stream, sd));
+    QS_HIP(c, launch_score_pass2(c->stream, sd, 1e-12));
+    std::vector<unsigned long long> sums(np * 3), cand(np * kCand);
+    uint32_t fl = 0;
+    QS_HIP(c, hipMemcpyAsync(sums.data(), B.sums, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipMemcpyAsync(cand.data(), B.cand, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipMemcpyAsync(&fl, c->dev_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipStreamSynchronize(c->stream));
+    if (fl & 1u) return fail(c, QS_ERR_OVERFLOW, "qs_score: more than 8 distinct near-minimal count triples for one node pair");
+    if (fl & 2u) return fail(c, QS_ERR_UNSUPPORTED, "qs_score: reduced count triple does not fit 21 bits per component");
+
+    const double inf = std::numeric_limits<double>::infinity();
+    const uint32_t N = R.n_nodes;
+    for (uint32_t v = 0; v < N; ++v) {
+        lqic[v] = inf;
+        if (R.bifurcating) { qpic[v] = inf; eqpic[v] = inf; }
+    }
+    // host finalisation: O(#node pairs * path length)
+    for (uint32_t iu = 0; iu < R.n_inner; ++iu)
+        for (uint32_t iv = iu + 1; iv < R.n_inner; ++iv) {
+            const size_t key = (size_t)iu * R.n_inner + iv;
+            const unsigned long long *cs = &cand[key * kCand];
+            if (cs[0] == kCandEmpty) continue; // pair owns no resolved quartet
+            double lqmin = inf;
+            for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
+                const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
+                const double v = host_log_score(q1, q2, q3);
+                lqmin = std::min(lqmin, v);
+            }
+            uint64_t p1 = sums[key * 3], p2 = sums[key * 3 + 1], p3 = sums[key * 3 + 2];
+            if (!(flags & QS_SCORE_QP_EXACT64)) { p1 &= 0xFFFFFFFFull; p2 &= 0xFFFFFFFFull; p3 &= 0xFFFFFFFFull; } // QSC:382
+            const double qp = host_log_score(p1, p2, p3);
+            // walk the path u..v (edges are indexed by their child node)
+            uint32_t x = R.inner_node[iu], y = R.inner_node[iv];
+            uint32_t path_edges = 0, last_edge_a = 0, last_edge_b = 0;
+            bool through_deg2_root = false;
+            while (x != y) {
+                uint32_t e;
+                if (R.depth[x] >= R.depth[y]) { e = x; x = (uint32_t)R.parent[x]; }
+                else { e = y; y = (uint32_t)R.parent[y]; }
+                lqic[e] = std::min(lqic[e], lqmin);
+                if (R.bifurcating) eqpic[e] = std::min(eqpic[e], qp);
+                if (path_edges == 0) last_edge_a = e; else last_edge_b = e;
+                ++path_edges;
+            }
+            if (R.bifurcating) {
+                if (path_edges == 2 && x == R.root && R.nchild[R.root] == 2) through_deg2_root = true;
+                if (path_edges == 1) qpic[last_edge_a] = qp;
+                else if (through_deg2_root) { qpic[last_edge_a] = qp; qpic[last_edge_b] = qp; }
+            }
+        }
+    return QS_OK;
+}
+
+extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q) {
+    if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_raw_qic: no table");
+    if (r0 + nq > c->n_tuples) return fail(c, QS_ERR_ARG, "qs_raw_qic: rank range outside this context's table");
+    if (nq == 0) return QS_OK;
+    RefHost R;
+    int rc = build_ref(c, ref, R);
+    if (rc != QS_OK) return rc;
+    QS_HIP(c, hipSetDevice(c->device));
+    ScoreBuffers B;
+    QS_HIP(c, hipMalloc(&B.lca, R.lca.size() * 4));
+    QS_HIP(c, hipMemcpyAsync(B.lca, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    uint8_t *dt = nullptr; unsigned long long *dq = nullptr;
+    QS_HIP(c, hipMalloc(&dt, nq));
+    hipError_t e = hipMalloc(&dq, nq * 24);
+    if (e != hipSuccess) { (void)hipFree(dt); return fail(c, QS_ERR_OOM, "qs_raw_qic: hipMalloc"); }
+    ScoreDevice sd;
+    fill_score_device(c, R, B, sd);
+    sd.frame = 1; // printRawQICScores uses the multifurcating loop's argument order
+    e = launch_raw_qic(c->stream, sd, r0, nq, dt, dq);
+    if (e == hipSuccess) e = hipMemcpyAsync(topo, dt, nq, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(q, dq, nq * 24, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dt); (void)hipFree(dq);
+    if (e != hipSuccess) return fail(c, QS_ERR_HIP, std::string("qs_raw_qic: ") + hipGetErrorString(e));
+    return QS_OK;
+}

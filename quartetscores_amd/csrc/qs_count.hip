@@ -1,0 +1,437 @@
+// qs_count.hip -- quartet-topology counting on gfx950 (MI355X).
+//
+// Replaces QuartetCounterLookup::countQuartets / updateQuartets / updateQuartetsThreeLinks /
+// updateQuartetsThreeClades (QuartetCounterLookup.hpp:65-238) and the per-increment index
+// arithmetic of QuartetLookupTable (quartet_lookup_table.hpp:87-111,141-212).
+//
+// Two formulations of the same count:
+//
+//  GATHER (default).  The reference walks every tree and does one random read-modify-write
+//  per (tree, displayed quartet). Here the loop nest is turned inside out: every lane OWNS
+//  table cells (a run of consecutive ranks) and the trees are streamed past it. A tree is
+//  reduced once to its "pair-depth panel": for every taxon pair {x,y} the depth of their
+//  lowest common ancestor (build_panel kernel, O(n^2) per tree). By the four-point
+//  condition a tree displays ab|cd  iff  M[ab]+M[cd] > M[ac]+M[bd] (= M[ad]+M[bc]); all
+//  three sums equal means the tree does not resolve the quartet. Panels are stored 16 trees
+//  per 16-byte element ([tree-chunk][pair] of uint4), so one lane compares 4 (u8) or 2 (u16)
+//  trees per 32-bit integer instruction (SWAR: the sums are kept below 128 / 32768 so that
+//  "(S1 | H) - S2" never borrows across fields) and v_bcnt accumulates the hits. Counters
+//  live in registers for the whole launch and each table cell is written exactly once, with
+//  plain coalesced stores: no atomics, and HBM traffic is one pass over the table instead of
+//  m passes.
+//
+//  SCATTER.  The tree-major formulation of BASELINE.json's north_star: one wavefront per
+//  (tree, inner node), the tree's tour staged in LDS, lanes enumerating the third clade while
+//  the wave walks pairs of the first and members of the second, atomicAdd into the table.
+//  Each displayed quartet is counted once (only when the pair side holds the 4-set's minimum
+//  id; the reference counts it at both ends of its middle path, SURVEY.md 3.2 iii). Kept as
+//  the literal restatement and as an independent cross-check of the gather path.
+//
+// Integer/byte work only: no MFMA.
+#include "qs_common.hpp"
+#include "qs_internal.hpp"
+
+namespace qs {
+
+// ======================================================================================
+// pair-depth panel
+// ======================================================================================
+
+constexpr int kPanelThreads = 256;
+constexpr int kPanelPPT = 8; // pairs per thread
+constexpr int kPanelPB = kPanelThreads * kPanelPPT;
+
+// Panel layout: uint4 P[n_chunks][npairs]; element = TPC consecutive trees of one taxon pair
+// (TPC = 16 for u8 depths, 8 for u16). pair index of x<y is C(y,2)+x.
+template <typename DT, bool PARTIAL>
+__global__ __launch_bounds__(kPanelThreads) void build_panel_kernel(const uint32_t *__restrict__ leaf_off,
+                                                                    const uint16_t *__restrict__ leaf_ids,
+                                                                    const uint16_t *__restrict__ adj_depth,
+                                                                    uint32_t n_trees, uint32_t n, uint32_t npairs,
+                                                                    uint32_t levels, uint4 *__restrict__ P) {
+    constexpr int TPC = 16 / (int)sizeof(DT);
+    constexpr uint32_t FLAG = sizeof(DT) == 1 ? 0x20u : 0x2000u;
+    extern __shared__ __align__(16) unsigned char smem[];
+    DT *out = reinterpret_cast<DT *>(smem);                                  // [kPanelPB][TPC]
+    uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)kPanelPB * 16); // [n]
+    uint16_t *st = pos + n;                                                  // [levels][n]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tc = blockIdx.y;
+    const uint32_t p0 = blockIdx.x * kPanelPB;
+
+    uint32_t px[kPanelPPT], py[kPanelPPT];
+#pragma unroll
+    for (int q = 0; q < kPanelPPT; ++q) {
+        uint32_t p = p0 + q * kPanelThreads + tid;
+        if (p < npairs) unrank2(p, px[q], py[q]);
+        else { px[q] = 0; py[q] = 1; }
+    }
+
+    for (int j = 0; j < TPC; ++j) {
+        const uint32_t t = tc * TPC + j;
+        if (t >= n_trees) { // uniform: padding trees resolve nothing (all sums equal)
+#pragma unroll
+            for (int q = 0; q < kPanelPPT; ++q) out[(q * kPanelThreads + tid) * TPC + j] = 0;
+            continue;
+        }
+        const uint32_t base = leaf_off[t];
+        const uint32_t L = leaf_off[t + 1] - base;
+        __syncthreads(); // previous tree's queries done
+        for (uint32_t x = tid; x < n; x += kPanelThreads) pos[x] = 0xFFFFu;
+        __syncthreads();
+        for (uint32_t i = tid; i < L; i += kPanelThreads) {
+            pos[leaf_ids[base + i]] = (uint16_t)i;
+            st[i] = adj_depth[base + i];
+        }
+        __syncthreads();
+        // sparse table over D[0 .. L-2]
+        for (uint32_t k = 1; k < levels; ++k) {
+            const uint32_t half = 1u << (k - 1), span = 1u << k;
+            if (span + 1 <= L) {
+                for (uint32_t i = tid; i + span <= L - 1; i += kPanelThreads)
+                    st[k * n + i] = min(st[(k - 1) * n + i], st[(k - 1) * n + i + half]);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < kPanelPPT; ++q) {
+            uint32_t a = pos[px[q]], b = pos[py[q]];
+            uint32_t val;
+            if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) {
+                val = FLAG;
+            } else {
+                uint32_t lo = min(a, b), hi = max(a, b);
+                uint32_t len = hi - lo; // >= 1: D[lo .. hi-1]
+                uint32_t k = 31u - (uint32_t)__clz((int)len);
+                val = min(st[k * n + lo], st[k * n + hi - (1u << k)]);
+            }
+            out[(q * kPanelThreads + tid) * TPC + j] = (DT)val;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPanelPPT; ++q) {
+        uint32_t p = p0 + q * kPanelThreads + tid;
+        if (p < npairs) P[(size_t)tc * npairs + p] = reinterpret_cast<const uint4 *>(out)[q * kPanelThreads + tid];
+    }
+}
+
+static uint32_t panel_levels(uint32_t n) {
+    uint32_t lv = 1;
+    while ((1u << lv) < n) ++lv;
+    return lv + 1;
+}
+
+hipError_t launch_build_panel(hipStream_t s, const DeviceBatch &b, uint32_t n, int panel_bits, bool partial, void *panel,
+                              uint32_t n_chunks) {
+    const uint32_t npairs = (uint32_t)binom2(n);
+    const uint32_t levels = panel_levels(n);
+    const size_t lds = (size_t)kPanelPB * 16 + (size_t)n * 2 + (size_t)levels * n * 2;
+    dim3 grid((npairs + kPanelPB - 1) / kPanelPB, n_chunks), block(kPanelThreads);
+#define QS_PANEL(DT, PART)                                                                                      \
+    do {                                                                                                        \
+        auto k = build_panel_kernel<DT, PART>;                                                                  \
+        if (lds > 48 * 1024) {                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                      \
+        }                                                                                                       \
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
+                           (uint4 *)panel);                                                                     \
+    } while (0)
+    if (panel_bits == 8) { if (partial) QS_PANEL(uint8_t, true); else QS_PANEL(uint8_t, false); }
+    else { if (partial) QS_PANEL(uint16_t, true); else QS_PANEL(uint16_t, false); }
+#undef QS_PANEL
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// gather count kernel
+// ======================================================================================
+
+template <int BITS> struct Swar;
+template <> struct Swar<8> {
+    static constexpr uint32_t H = 0x80808080u, ONES = 0x01010101u;
+};
+template <> struct Swar<16> {
+    static constexpr uint32_t H = 0x80008000u, ONES = 0x00010001u;
+};
+
+// One 32-bit word = 4 (or 2) trees of one quartet. ab,cd / ac,bd / ad,bc are the LCA depths
+// of the three pairings. Adds the number of trees displaying each topology to c0,c1,c2.
+template <int BITS, int MODE>
+__device__ __forceinline__ void swar_step(uint32_t ab, uint32_t cd, uint32_t ac, uint32_t bd, uint32_t ad, uint32_t bc,
+                                          uint32_t &c0, uint32_t &c1, uint32_t &c2) {
+    constexpr uint32_t H = Swar<BITS>::H, ONES = Swar<BITS>::ONES;
+    const uint32_t s1h = ab + cd + H; // every field: 128 + S1  (S1 < 128)
+    const uint32_t s2 = ac + bd;
+    const uint32_t x = s1h - s2;      // field top bit: S1 >= S2 ; field value never 0
+    const uint32_t t = x - ONES;      // field top bit: S1 >  S2
+    if (MODE == MODE_BINARY_FULL) {
+        c0 += __popc(t & H);
+        c1 += __popc(~x & H);
+    } else {
+        const uint32_t s3 = ad + bc;
+        const uint32_t w = s1h - s3;  // field top bit: S1 >= S3
+        const uint32_t v = x & ~(t | w); // S1 == S2 and S3 > S1
+        uint32_t hv = H;
+        if (MODE == MODE_PARTIAL) hv = ~((ab | cd) << 2) & H; // flag bit (0x20 / 0x2000) -> top bit
+        c0 += __popc(t & hv);
+        c1 += __popc(~x & hv);
+        c2 += __popc(v & hv);
+    }
+}
+
+__device__ __forceinline__ uint32_t upper_bound_le(const uint32_t *__restrict__ arr, uint32_t lo, uint32_t hi, uint32_t key) {
+    // largest i in [lo, hi) with arr[i] <= key (arr non-decreasing, arr[lo] <= key)
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (arr[mid] <= key) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Workgroup = (d-block of kDB largest ids, third id c, chunk of 256 pairs (a,b) with a<b<c).
+// Lane = one (a,b): it owns the kDB quartets {a,b,c,d0..d0+7}, i.e. ranks C(d,4)+C(c,3)+pairidx.
+template <int BITS, int MODE, typename CT>
+__global__ __launch_bounds__(kCountThreads) void count_gather_kernel(const uint4 *__restrict__ P, uint32_t npairs,
+                                                                     uint32_t n_chunks, uint32_t m_trees, uint32_t n,
+                                                                     uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
+                                                                     uint32_t n_dblk, const uint32_t *__restrict__ dprefix,
+                                                                     const uint32_t *__restrict__ cprefix,
+                                                                     uint32_t row_stride, CT *__restrict__ table,
+                                                                     uint32_t *__restrict__ overflow_flag) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4 *rows = reinterpret_cast<uint4 *>(smem); // [(1+kDB)][row_stride]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bid = blockIdx.x;
+    // ---- tile decode (uniform) ----
+    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, bid);
+    const uint32_t local = bid - dprefix[k];
+    const uint32_t d0 = d_lo + k * kDB;
+    const uint32_t d1 = min(d0 + (uint32_t)kDB, d_hi);
+    const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
+    const uint32_t pair0 = (local - cprefix[c]) * kCountThreads;
+    const uint32_t npair_c = (uint32_t)binom2(c);
+
+    const uint32_t pi = pair0 + tid;
+    const bool lane_valid = pi < npair_c;
+    uint32_t a = 0, b = 1;
+    if (lane_valid) unrank2(pi, a, b);
+
+    const uint32_t rowC = (uint32_t)binom2(c);
+    uint32_t c0[kDB], c1[kDB], c2[kDB];
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) c0[j] = c1[j] = c2[j] = 0;
+
+    for (uint32_t tc = 0; tc < n_chunks; ++tc) {
+        const uint4 *Pc = P + (size_t)tc * npairs;
+        __syncthreads();
+        // rows (x,c), x < c
+        for (uint32_t x = tid; x < c; x += kCountThreads) rows[x] = Pc[rowC + x];
+        // rows (x,d), x <= c   (x == c is the pair (c,d))
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            const uint32_t d = d0 + j;
+            if (d < d1 && d > c) {
+                const uint32_t rowD = (uint32_t)binom2(d);
+                for (uint32_t x = tid; x <= c; x += kCountThreads) rows[(1 + j) * row_stride + x] = Pc[rowD + x];
+            }
+        }
+        uint4 ab = make_uint4(0, 0, 0, 0);
+        if (lane_valid) ab = Pc[pi];
+        __syncthreads();
+        const uint4 ac = rows[a], bc = rows[b];
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            const uint32_t d = d0 + j;
+            if (d < d1 && d > c) {
+                const uint4 ad = rows[(1 + j) * row_stride + a];
+                const uint4 bd = rows[(1 + j) * row_stride + b];
+                const uint4 cd = rows[(1 + j) * row_stride + c];
+                swar_step<BITS, MODE>(ab.x, cd.x, ac.x, bd.x, ad.x, bc.x, c0[j], c1[j], c2[j]);
+                swar_step<BITS, MODE>(ab.y, cd.y, ac.y, bd.y, ad.y, bc.y, c0[j], c1[j], c2[j]);
+                swar_step<BITS, MODE>(ab.z, cd.z, ac.z, bd.z, ad.z, bc.z, c0[j], c1[j], c2[j]);
+                swar_step<BITS, MODE>(ab.w, cd.w, ac.w, bd.w, ad.w, bc.w, c0[j], c1[j], c2[j]);
+            }
+        }
+    }
+
+    if (!lane_valid) return;
+    const uint64_t rc = binom3(c) + pi;
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) {
+        const uint32_t d = d0 + j;
+        if (d < d1 && d > c) {
+            const uint64_t idx = (binom4(d) + rc - rank_lo) * 3;
+            uint32_t n0 = c0[j], n1 = c1[j], n2 = (MODE == MODE_BINARY_FULL) ? (m_trees - c0[j] - c1[j]) : c2[j];
+            uint32_t v0 = (uint32_t)table[idx] + n0, v1 = (uint32_t)table[idx + 1] + n1, v2 = (uint32_t)table[idx + 2] + n2;
+            if (sizeof(CT) == 2 && ((v0 | v1 | v2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+            table[idx] = (CT)v0;
+            table[idx + 1] = (CT)v1;
+            table[idx + 2] = (CT)v2;
+        }
+    }
+}
+
+size_t gather_lds_bytes(uint32_t d_hi) { return (size_t)(1 + kDB) * d_hi * sizeof(uint4); }
+
+hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void *panel, int panel_bits, int mode,
+                               uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag) {
+    if (g.total_tiles == 0) return hipSuccess;
+    const uint32_t npairs = (uint32_t)binom2(g.n);
+    const uint32_t row_stride = g.d_hi;
+    const size_t lds = gather_lds_bytes(g.d_hi);
+    dim3 grid(g.total_tiles), block(kCountThreads);
+#define QS_GATHER(B, M, CT)                                                                                         \
+    do {                                                                                                            \
+        auto k = count_gather_kernel<B, M, CT>;                                                                     \
+        if (lds > 48 * 1024) {                                                                                      \
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL(k, grid, block, lds, s, (const uint4 *)panel, npairs, n_chunks, m_trees, g.n, g.d_lo, g.d_hi, \
+                           g.rank_lo, g.n_dblk, g.dprefix, g.cprefix, row_stride, (CT *)table, overflow_flag);      \
+    } while (0)
+#define QS_GATHER_M(B, CT)                                                                                          \
+    do {                                                                                                            \
+        if (mode == MODE_BINARY_FULL) QS_GATHER(B, MODE_BINARY_FULL, CT);                                           \
+        else if (mode == MODE_GENERAL_FULL) QS_GATHER(B, MODE_GENERAL_FULL, CT);                                    \
+        else QS_GATHER(B, MODE_PARTIAL, CT);                                                                        \
+    } while (0)
+    if (panel_bits == 8) {
+        if (count_bits == 32) QS_GATHER_M(8, uint32_t); else QS_GATHER_M(8, uint16_t);
+    } else {
+        if (count_bits == 32) QS_GATHER_M(16, uint32_t); else QS_GATHER_M(16, uint16_t);
+    }
+#undef QS_GATHER_M
+#undef QS_GATHER
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// scatter count kernel (tree-major, atomics)
+// ======================================================================================
+
+template <typename CT> __device__ __forceinline__ void table_atomic_inc(CT *table, uint64_t cell);
+template <> __device__ __forceinline__ void table_atomic_inc<uint32_t>(uint32_t *table, uint64_t cell) {
+    atomicAdd(&table[cell], 1u);
+}
+template <> __device__ __forceinline__ void table_atomic_inc<uint16_t>(uint16_t *table, uint64_t cell) {
+    // packed half-word increment: cell totals stay < 2^16, so no carry crosses the half-word
+    uint32_t *w = reinterpret_cast<uint32_t *>(table) + (cell >> 1);
+    atomicAdd(w, (cell & 1) ? 0x10000u : 1u);
+}
+
+constexpr int kScatterMaxLeaves = 4096;
+
+// One wavefront (= one workgroup) per inner node of one evaluation tree. The tree's tour is
+// staged in LDS. For every oriented triple (pair side P; single sides Q, R) of the node's
+// links the wave walks pairs (a,a') of P and members b of Q (wave-uniform), lanes enumerate
+// c in R; a hit is counted only when min(a,a') < min(b,c).
+template <typename CT>
+__global__ __launch_bounds__(kWave) void count_scatter_kernel(const uint32_t *__restrict__ leaf_off,
+                                                              const uint16_t *__restrict__ leaf_ids,
+                                                              const uint32_t *__restrict__ node_tree,
+                                                              const uint32_t *__restrict__ rng_off,
+                                                              const uint16_t *__restrict__ ranges, uint32_t d_lo,
+                                                              uint32_t d_hi, uint64_t rank_lo, CT *__restrict__ table) {
+    __shared__ uint16_t ids[kScatterMaxLeaves];
+    const uint32_t v = blockIdx.x, lane = threadIdx.x;
+    const uint32_t t = node_tree[v];
+    const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
+    for (uint32_t i = lane; i < L; i += kWave) ids[i] = leaf_ids[base + i];
+    __syncthreads();
+    const uint32_t k0 = rng_off[v], k = rng_off[v + 1] - k0;
+    for (uint32_t i1 = 0; i1 < k; ++i1)
+        for (uint32_t i2 = i1 + 1; i2 < k; ++i2)
+            for (uint32_t i3 = i2 + 1; i3 < k; ++i3) {
+                const uint32_t li[3] = {i1, i2, i3};
+                for (int o = 0; o < 3; ++o) { // which link is the pair side
+                    const uint32_t lp = li[o], lq = li[(o + 1) % 3], lr = li[(o + 2) % 3];
+                    const uint32_t ps = ranges[2 * (k0 + lp)], pe = ranges[2 * (k0 + lp) + 1];
+                    const uint32_t qs_ = ranges[2 * (k0 + lq)], qe = ranges[2 * (k0 + lq) + 1];
+                    const uint32_t rs = ranges[2 * (k0 + lr)], re = ranges[2 * (k0 + lr) + 1];
+                    const uint32_t np = (pe + L - ps) % L, nq = (qe + L - qs_) % L, nr = (re + L - rs) % L;
+                    for (uint32_t x = 0; x < np; ++x) {
+                        const uint32_t a = ids[(ps + x) % L];
+                        for (uint32_t y = x + 1; y < np; ++y) {
+                            const uint32_t a2 = ids[(ps + y) % L];
+                            const uint32_t amin = min(a, a2);
+                            for (uint32_t z = 0; z < nq; ++z) {
+                                const uint32_t bq = ids[(qs_ + z) % L];
+                                if (bq < amin) continue; // uniform
+                                for (uint32_t w = lane; w < nr; w += kWave) {
+                                    const uint32_t cr = ids[(rs + w) % L];
+                                    if (cr < amin) continue;
+                                    // sort the four ids
+                                    uint32_t s0 = min(a, a2), s1 = max(a, a2), s2 = min(bq, cr), s3 = max(bq, cr);
+                                    // s0 is the global minimum by construction
+                                    uint32_t lo = min(s1, s2), hi = max(s1, s2);
+                                    uint32_t m1 = lo, m2 = min(hi, s3), m3 = max(hi, s3);
+                                    if (m3 < d_lo || m3 >= d_hi) continue;
+                                    const int slot = slot_of_pairing(a, a2, bq, cr);
+                                    const uint64_t cell = (rank4(s0, m1, m2, m3) - rank_lo) * 3 + (uint64_t)slot;
+                                    table_atomic_inc<CT>(table, cell);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+}
+
+hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
+                                uint64_t rank_lo, void *table, int count_bits) {
+    (void)n;
+    if (b.n_nodes == 0) return hipSuccess;
+    dim3 grid(b.n_nodes), block(kWave);
+    if (count_bits == 32)
+        hipLaunchKernelGGL(count_scatter_kernel<uint32_t>, grid, block, 0, s, b.leaf_off, b.leaf_ids, b.node_tree, b.rng_off,
+                           b.ranges, d_lo, d_hi, rank_lo, (uint32_t *)table);
+    else
+        hipLaunchKernelGGL(count_scatter_kernel<uint16_t>, grid, block, 0, s, b.leaf_off, b.leaf_ids, b.node_tree, b.rng_off,
+                           b.ranges, d_lo, d_hi, rank_lo, (uint16_t *)table);
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// lookup (countQuartetOccurrences, QuartetCounterLookup.hpp:299-318)
+// ======================================================================================
+
+template <typename CT>
+__global__ void lookup_kernel(uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const CT *__restrict__ table, uint64_t nq,
+                              const uint16_t *__restrict__ abcd, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const uint32_t a = abcd[4 * i], b = abcd[4 * i + 1], c = abcd[4 * i + 2], d = abcd[4 * i + 3];
+    uint32_t lo1 = min(a, b), hi1 = max(a, b), lo2 = min(c, d), hi2 = max(c, d);
+    uint32_t s0 = min(lo1, lo2), s3 = max(hi1, hi2);
+    uint32_t m1 = max(lo1, lo2), m2 = min(hi1, hi2);
+    uint32_t s1 = min(m1, m2), s2 = max(m1, m2);
+    uint64_t o0 = 0, o1 = 0, o2 = 0;
+    if (s3 >= d_lo && s3 < d_hi && s0 != s1 && s1 != s2 && s2 != s3) {
+        const uint64_t cell = (rank4(s0, s1, s2, s3) - rank_lo) * 3;
+        o0 = table[cell + slot_of_pairing(a, b, c, d)];
+        o1 = table[cell + slot_of_pairing(a, c, b, d)];
+        o2 = table[cell + slot_of_pairing(a, d, b, c)];
+    }
+    out[3 * i] = o0; out[3 * i + 1] = o1; out[3 * i + 2] = o2;
+}
+
+hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,
+                         int count_bits, uint64_t nq, const uint16_t *abcd_dev, uint64_t *out_dev) {
+    (void)n;
+    if (nq == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((nq + 255) / 256));
+    if (count_bits == 32)
+        hipLaunchKernelGGL(lookup_kernel<uint32_t>, grid, block, 0, s, d_lo, d_hi, rank_lo, (const uint32_t *)table, nq,
+                           abcd_dev, out_dev);
+    else
+        hipLaunchKernelGGL(lookup_kernel<uint16_t>, grid, block, 0, s, d_lo, d_hi, rank_lo, (const uint16_t *)table, nq,
+                           abcd_dev, out_dev);
+    return hipGetLastError();
+}
+
+} // namespace qs

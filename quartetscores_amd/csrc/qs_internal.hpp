@@ -1,0 +1,81 @@
+// qs_internal.hpp -- launcher interface between the C-ABI layer (qs_abi.hip) and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qs {
+
+// Panel element type / kernel mode of one batch
+enum PanelBits { PANEL_U8 = 8, PANEL_U16 = 16 };
+enum CountMode {
+    MODE_BINARY_FULL = 0,  // every tree fully resolved and holding all n taxa: n2 = m - n0 - n1
+    MODE_GENERAL_FULL = 1, // multifurcations possible, all taxa present
+    MODE_PARTIAL = 2       // taxa may be missing (flag bit in the panel)
+};
+
+// depth limits of the SWAR comparison (see qs_count.hip)
+constexpr uint32_t kMaxDepthU8Full = 63;
+constexpr uint32_t kMaxDepthU8Partial = 31;
+constexpr uint32_t kMaxDepthU16Full = 16383;
+constexpr uint32_t kMaxDepthU16Partial = 8191;
+
+struct DeviceBatch {
+    uint32_t n_trees = 0;
+    uint32_t total_leaves = 0;
+    uint32_t max_depth = 0;
+    bool all_full = false;
+    bool all_binary = false;
+    uint32_t *leaf_off = nullptr;  // device
+    uint16_t *leaf_ids = nullptr;  // device
+    uint16_t *adj_depth = nullptr; // device
+    // scatter-only
+    uint32_t n_nodes = 0, n_links = 0;
+    uint32_t *node_off = nullptr, *rng_off = nullptr, *node_tree = nullptr;
+    uint16_t *ranges = nullptr;
+};
+
+struct CountGeometry {
+    uint32_t n;          // taxa
+    uint32_t d_lo, d_hi; // shard of the largest id
+    uint64_t rank_lo;    // C(d_lo,4)
+    uint32_t n_dblk;     // d-blocks
+    uint32_t total_tiles;
+    const uint32_t *dprefix; // device, n_dblk+1
+    const uint32_t *cprefix; // device, n+1
+};
+
+// qs_count.hip
+hipError_t launch_build_panel(hipStream_t s, const DeviceBatch &b, uint32_t n, int panel_bits, bool partial, void *panel,
+                              uint32_t n_chunks);
+hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void *panel, int panel_bits, int mode,
+                               uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag);
+hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
+                                uint64_t rank_lo, void *table, int count_bits);
+hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,
+                         int count_bits, uint64_t nq, const uint16_t *abcd_dev, uint64_t *out_dev);
+size_t gather_lds_bytes(uint32_t d_hi);
+
+// qs_score.hip
+struct ScoreDevice {
+    const uint32_t *ref_lca; // n*n: (depth << 16) | inner-node compact id, for leaf pairs (lookup ids)
+    uint32_t n, n_inner;
+    uint32_t d_lo, d_hi;
+    uint64_t rank_lo, n_tuples;
+    const void *table;
+    int count_bits;
+    unsigned long long *pair_sums; // n_inner*n_inner*3
+    unsigned long long *pair_min;  // n_inner*n_inner (ordered f64 bits)
+    unsigned long long *pair_cand; // n_inner*n_inner*kCand
+    uint32_t *flags;               // [0] candidate overflow
+    int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
+                                   //    order of the multifurcating / raw-QIC loops (QSC:551-558, 661-668)
+};
+constexpr int kCand = 8;
+constexpr unsigned long long kCandEmpty = ~0ull;
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd);
+hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol);
+hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
+                          unsigned long long *q_dev);
+
+} // namespace qs

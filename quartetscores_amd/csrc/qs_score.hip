@@ -1,0 +1,203 @@
+// qs_score.hip -- LQ-/QP-/EQP-IC reductions over the count table on gfx950.
+//
+// Replaces the C(n,4)-sized part of QuartetScoreComputer (QuartetScoreComputer.hpp):
+//   processNodePair / computeQuartetScoresBifurcating   :379-508
+//   computeQuartetScoresMultifurcating                  :513-593
+//   the topology test of printRawQICScores              :636-672
+//
+// The reference walks node pairs (u,v) and enumerates S1xS2xS3xS4; every 4-set is visited
+// exactly once overall. Here the walk is quartet-major: lane = table rank, so the table is
+// read once with fully coalesced 12-byte tuples. Lookup ids are the reference tree's own
+// depth-first leaf order (QuartetCounterLookup.hpp:252-258), therefore for sorted ids
+// a<b<c<d only the two non-crossing pairings ab|cd and ad|bc can be the reference topology,
+// decided from the LCA depths of the three adjacent pairs (equivalent to the reference's
+// "strictly largest LCA-to-LCA distance" test, :535-562, because
+// dist(lca_xy, lca_zw) = depth(lca_xy) + depth(lca_zw) - 2*depth(lca of all four)).
+// The same three LCAs give the two junction nodes (u,v) of the quartet = the node pair that
+// owns it (:436-447). In the reference's frame (a in S1, b in S2, c in S3, d in S4 with
+// S1,S2,S3,S4 consecutive in the cyclic leaf order) p2 always receives the crossing pairing.
+//
+// Pass 1: per node pair, 64-bit sums of (q1,q2,q3) and the minimum device-evaluated QIC.
+// Pass 2: every distinct count triple whose device QIC is within `tol` of the pair's minimum
+//         is recorded (scaled by its gcd, which leaves log_score bit-identical), so that the
+//         host can evaluate log_score with the same libm as the reference's CPU path and take
+//         the exact minimum. The host work is O(#node pairs), the device work O(C(n,4)).
+#include "qs_common.hpp"
+#include "qs_internal.hpp"
+
+namespace qs {
+
+// QuartetScoreComputer.hpp:135-159 (device evaluation; only used to ORDER candidates)
+__device__ __forceinline__ double dev_log_score(uint32_t q1, uint32_t q2, uint32_t q3) {
+    if ((q1 | q2 | q3) == 0) return 0.0;
+    const double sum = (double)((uint64_t)q1 + q2 + q3);
+    const double inv_log3 = 0.91023922662683739361;
+    double qic = 1.0;
+    if (q1) { double p = (double)q1 / sum; qic += p * log(p) * inv_log3; }
+    if (q2) { double p = (double)q2 / sum; qic += p * log(p) * inv_log3; }
+    if (q3) { double p = (double)q3 / sum; qic += p * log(p) * inv_log3; }
+    return (q1 < q2 || q1 < q3) ? -qic : qic;
+}
+
+struct QuartetRef {
+    bool resolved;
+    uint32_t key;        // lo_inner * n_inner + hi_inner
+    uint32_t q1, q2, q3; // counts in the reference's log_score argument order
+    uint8_t topo;        // 0: s0s1|s2s3, 2: s0s3|s1s2, 255: unresolved
+};
+
+template <typename CT>
+__device__ __forceinline__ QuartetRef classify(const ScoreDevice &sd, uint64_t local_rank) {
+    QuartetRef r;
+    uint32_t a, b, c, d;
+    unrank4(local_rank + sd.rank_lo, a, b, c, d);
+    const uint32_t e01 = sd.ref_lca[(size_t)b * sd.n + a];
+    const uint32_t e12 = sd.ref_lca[(size_t)c * sd.n + b];
+    const uint32_t e23 = sd.ref_lca[(size_t)d * sd.n + c];
+    const uint32_t d01 = e01 >> 16, d12 = e12 >> 16, d23 = e23 >> 16;
+    const CT *tup = reinterpret_cast<const CT *>(sd.table) + local_rank * 3;
+    const uint32_t n0 = tup[0], n1 = tup[1], n2 = tup[2];
+    const uint32_t mx = max(d01, d23);
+    uint32_t j1, j2;
+    if (d12 < mx) { // ab|cd
+        r.resolved = true; r.topo = 0;
+        r.q1 = n0; r.q2 = n1; r.q3 = n2;
+        j1 = (d01 > d12) ? (e01 & 0xFFFFu) : (e12 & 0xFFFFu);
+        j2 = (d23 > d12) ? (e23 & 0xFFFFu) : (e12 & 0xFFFFu);
+    } else if (d12 > mx) { // ad|bc
+        r.resolved = true; r.topo = 2;
+        r.q1 = n2;
+        if (sd.frame == 0) { r.q2 = n1; r.q3 = n0; } // S1S3|S2S4 is the crossing pairing
+        else { r.q2 = n0; r.q3 = n1; }               // occ(u,z,v,w) = (uz|vw, uv|zw, uw|zv)
+        j1 = e12 & 0xFFFFu;
+        j2 = (d01 >= d23) ? (e01 & 0xFFFFu) : (e23 & 0xFFFFu);
+    } else {
+        r.resolved = false; r.topo = 255; r.q1 = r.q2 = r.q3 = 0; j1 = j2 = 0;
+    }
+    const uint32_t lo = min(j1, j2), hi = max(j1, j2);
+    r.key = lo * sd.n_inner + hi;
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = r < sd.n_tuples;
+    QuartetRef q;
+    q.resolved = false; q.key = 0; q.q1 = q.q2 = q.q3 = 0;
+    if (in_range) q = classify<CT>(sd, r);
+    const unsigned long long valid = __ballot(q.resolved);
+    if (valid == 0) return;
+    const int leader = __ffsll((long long)valid) - 1;
+    const uint32_t lkey = __shfl(q.key, leader, 64);
+    const bool uniform = __ballot(q.resolved && q.key != lkey) == 0;
+    const unsigned long long ord = q.resolved ? f64_to_ordered(dev_log_score(q.q1, q.q2, q.q3)) : ~0ull;
+    if (uniform) {
+        const unsigned long long s1 = wave_sum_u64(q.resolved ? q.q1 : 0);
+        const unsigned long long s2 = wave_sum_u64(q.resolved ? q.q2 : 0);
+        const unsigned long long s3 = wave_sum_u64(q.resolved ? q.q3 : 0);
+        const unsigned long long mn = wave_min_u64(ord);
+        if ((int)(threadIdx.x & 63) == leader) {
+            atomicAdd(&sd.pair_sums[(size_t)lkey * 3 + 0], s1);
+            atomicAdd(&sd.pair_sums[(size_t)lkey * 3 + 1], s2);
+            atomicAdd(&sd.pair_sums[(size_t)lkey * 3 + 2], s3);
+            atomicMin(&sd.pair_min[lkey], mn);
+        }
+    } else if (q.resolved) {
+        atomicAdd(&sd.pair_sums[(size_t)q.key * 3 + 0], (unsigned long long)q.q1);
+        atomicAdd(&sd.pair_sums[(size_t)q.key * 3 + 1], (unsigned long long)q.q2);
+        atomicAdd(&sd.pair_sums[(size_t)q.key * 3 + 2], (unsigned long long)q.q3);
+        atomicMin(&sd.pair_min[q.key], ord);
+    }
+}
+
+__device__ __forceinline__ uint32_t gcd_u32(uint32_t x, uint32_t y) {
+    if (x == 0) return y;
+    if (y == 0) return x;
+    const int sh = __ffs((int)(x | y)) - 1;
+    x >>= (__ffs((int)x) - 1);
+    while (y) {
+        y >>= (__ffs((int)y) - 1);
+        if (x > y) { uint32_t t = x; x = y; y = t; }
+        y -= x;
+    }
+    return x << sh;
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void score_pass2_kernel(ScoreDevice sd, double tol) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= sd.n_tuples) return;
+    const QuartetRef q = classify<CT>(sd, r);
+    if (!q.resolved) return;
+    const double sc = dev_log_score(q.q1, q.q2, q.q3);
+    const double mn = ordered_to_f64(sd.pair_min[q.key]);
+    if (!(sc <= mn + tol)) return;
+    uint32_t g = gcd_u32(gcd_u32(q.q1, q.q2), q.q3);
+    if (g == 0) g = 1;
+    const uint32_t a = q.q1 / g, b = q.q2 / g, c = q.q3 / g;
+    if ((a | b | c) >> 21) { atomicOr(&sd.flags[0], 2u); return; }
+    const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
+    unsigned long long *slots = sd.pair_cand + (size_t)q.key * kCand;
+    // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
+    for (int s = 0; s < kCand; ++s) {
+        unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == packed) return;
+        if (cur == kCandEmpty) {
+            unsigned long long old = atomicCAS(&slots[s], kCandEmpty, packed);
+            if (old == kCandEmpty || old == packed) return;
+        }
+    }
+    atomicOr(&sd.flags[0], 1u);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void raw_qic_kernel(ScoreDevice sd, uint64_t r0, uint64_t nq, uint8_t *__restrict__ topo,
+                                                      unsigned long long *__restrict__ qout) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const QuartetRef q = classify<CT>(sd, r0 + i);
+    topo[i] = q.topo;
+    qout[3 * i] = q.q1; qout[3 * i + 1] = q.q2; qout[3 * i + 2] = q.q3;
+}
+
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
+    if (sd.n_tuples == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((sd.n_tuples + 255) / 256));
+    if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass1_kernel<uint32_t>, grid, block, 0, s, sd);
+    else hipLaunchKernelGGL(score_pass1_kernel<uint16_t>, grid, block, 0, s, sd);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) {
+    if (sd.n_tuples == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((sd.n_tuples + 255) / 256));
+    if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass2_kernel<uint32_t>, grid, block, 0, s, sd, tol);
+    else hipLaunchKernelGGL(score_pass2_kernel<uint16_t>, grid, block, 0, s, sd, tol);
+    return hipGetLastError();
+}
+
+hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
+                          unsigned long long *q_dev) {
+    if (nq == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((nq + 255) / 256));
+    if (sd.count_bits == 32) hipLaunchKernelGGL(raw_qic_kernel<uint32_t>, grid, block, 0, s, sd, r0, nq, topo_dev, q_dev);
+    else hipLaunchKernelGGL(raw_qic_kernel<uint16_t>, grid, block, 0, s, sd, r0, nq, topo_dev, q_dev);
+    return hipGetLastError();
+}
+
+} // namespace qs

@@ -1,0 +1,312 @@
+"""Python host above the C-ABI, mirroring the reference's interface for the hot path.
+
+    QuartetCounterLookup  <->  QuartetCounterLookup<CINT>   (QuartetCounterLookup.hpp:24-53)
+    QuartetScoreComputer  <->  QuartetScoreComputer<CINT>   (QuartetScoreComputer.hpp:43-80)
+
+Same names, argument meaning and error behaviour, so that the parity tests read like tests
+of the reference. All computation happens in libquartetscores_hip.so (HIP, gfx950); this
+file only marshals arrays. torch is optional here: it is used when the caller wants the
+count table inside a torch tensor (multi-GPU all-reduce over RCCL, see distributed.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib, flatten, newick
+from ._lib import QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_SCORE_QP_EXACT64, QS_SCORE_QP_WRAP32  # noqa: F401
+
+
+class QSError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[qs {code}] {msg}")
+        self.code = code
+
+
+def count_bits_for(m: int) -> int:
+    """Counter width for m evaluation trees. The reference picks u8/u16/u32/u64 by m
+    (QuartetScores.cpp:115-147); the GPU table has 16- and 32-bit cells."""
+    return 16 if m < (1 << 16) else 32
+
+
+class Context:
+    """Thin RAII wrapper of qs_ctx."""
+
+    def __init__(self, n_taxa: int, count_bits: int = 32, device: int = 0, stream: int = 0, d_lo: int = 0, d_hi: int = 0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.qs_create(C.byref(h), n_taxa, count_bits, 0, device, C.c_void_p(stream or None), d_lo, d_hi or n_taxa)
+        if rc != 0:
+            raise QSError(rc, self.L.qs_last_error(None).decode())
+        self.h = h
+        self.n = n_taxa
+        self.count_bits = count_bits
+        self.d_lo, self.d_hi = d_lo, d_hi or n_taxa
+        self._attached = None  # keeps an attached torch tensor alive
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise QSError(rc, self.L.qs_last_error(self.h).decode())
+
+    # table
+    @property
+    def table_tuples(self) -> int:
+        return int(self.L.qs_table_tuples(self.h))
+
+    @property
+    def table_bytes(self) -> int:
+        return int(self.L.qs_table_bytes(self.h))
+
+    def table_alloc(self):
+        self._chk(self.L.qs_table_alloc(self.h))
+
+    def table_attach(self, tensor):
+        """tensor: a torch CUDA tensor with >= table_bytes bytes (kept alive by this object)."""
+        nbytes = tensor.numel() * tensor.element_size()
+        self._chk(self.L.qs_table_attach(self.h, C.c_void_p(tensor.data_ptr()), nbytes))
+        self._attached = tensor
+
+    def table_clear(self):
+        self._chk(self.L.qs_table_clear(self.h))
+
+    def table_download(self) -> np.ndarray:
+        dt = np.uint32 if self.count_bits == 32 else np.uint16
+        out = np.zeros((max(self.table_tuples, 1), 3), dtype=dt)
+        self._chk(self.L.qs_table_download(self.h, out.ctypes.data_as(C.c_void_p), self.table_bytes))
+        return out[: self.table_tuples]
+
+    def table_upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.qs_table_upload(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    # batches
+    @staticmethod
+    def _batch_struct(b: flatten.TreeBatch, with_nodes=True):
+        s = _lib.TreeBatchC()
+        s.n_trees = b.n_trees
+        keep = [np.ascontiguousarray(x) for x in (b.leaf_off, b.leaf_ids, b.adj_depth, b.node_off, b.rng_off, b.ranges)]
+        s.leaf_off, s.leaf_ids, s.adj_depth = (k.ctypes.data for k in keep[:3])
+        if with_nodes:
+            s.node_off, s.rng_off, s.ranges = (k.ctypes.data for k in keep[3:])
+        return s, keep
+
+    def batch_upload(self, b: flatten.TreeBatch, with_nodes=True):
+        s, keep = self._batch_struct(b, with_nodes)
+        h = C.c_void_p()
+        self._chk(self.L.qs_batch_upload(self.h, C.byref(s), C.byref(h)))
+        del keep
+        return h
+
+    def batch_free(self, hb):
+        self.L.qs_batch_free(self.h, hb)
+
+    def count_batch(self, hb, algo=QS_ALGO_AUTO):
+        self._chk(self.L.qs_count_batch(self.h, hb, algo))
+
+    def count_trees(self, b: flatten.TreeBatch, algo=QS_ALGO_AUTO):
+        s, keep = self._batch_struct(b, True)
+        self._chk(self.L.qs_count_trees(self.h, C.byref(s), algo))
+        del keep
+
+    def sync(self):
+        self._chk(self.L.qs_sync(self.h))
+
+    @property
+    def trees_counted(self) -> int:
+        return int(self.L.qs_trees_counted(self.h))
+
+    def last_count_ms(self) -> Tuple[float, float, float]:
+        out = (C.c_float * 3)()
+        self._chk(self.L.qs_last_count_ms(self.h, C.byref(out)))
+        return tuple(float(x) for x in out)
+
+    def last_count_variant(self) -> str:
+        return self.L.qs_last_count_variant(self.h).decode()
+
+    def lookup(self, abcd: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(abcd, dtype=np.uint16).reshape(-1, 4)
+        out = np.zeros((len(q), 3), dtype=np.uint64)
+        self._chk(self.L.qs_lookup(self.h, len(q), q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # scoring
+    @staticmethod
+    def _ref_struct(ref: flatten.RefTree):
+        s = _lib.RefTreeC()
+        par = np.ascontiguousarray(ref.parent, dtype=np.int32)
+        ln = np.ascontiguousarray(ref.leaf_node, dtype=np.uint32)
+        s.n_nodes, s.n_taxa, s.parent, s.leaf_node = ref.n_nodes, ref.n_taxa, par.ctypes.data, ln.ctypes.data
+        return s, (par, ln)
+
+    def score(self, ref: flatten.RefTree, flags=QS_SCORE_QP_WRAP32):
+        s, keep = self._ref_struct(ref)
+        lq = np.zeros(ref.n_nodes); qp = np.zeros(ref.n_nodes); eqp = np.zeros(ref.n_nodes)
+        bif = C.c_int(0)
+        self._chk(self.L.qs_score(self.h, C.byref(s), flags, lq.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p),
+                                  eqp.ctypes.data_as(C.c_void_p), C.byref(bif)))
+        del keep
+        return lq, qp, eqp, bool(bif.value)
+
+    def raw_qic(self, ref: flatten.RefTree, r0: int, nq: int):
+        s, keep = self._ref_struct(ref)
+        topo = np.zeros(nq, dtype=np.uint8)
+        q = np.zeros((nq, 3), dtype=np.uint64)
+        self._chk(self.L.qs_raw_qic(self.h, C.byref(s), r0, nq, topo.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)))
+        del keep
+        return topo, q
+
+
+def _read_eval(eval_trees) -> List[str]:
+    """evalTreesPath of the reference: a file of ';'-terminated Newick trees. A list of
+    Newick strings is accepted as well (tests)."""
+    if isinstance(eval_trees, (str, os.PathLike)) and os.path.exists(str(eval_trees)):
+        with open(eval_trees) as f:
+            return [f.read()]
+    if isinstance(eval_trees, str):
+        return [eval_trees]
+    return list(eval_trees)
+
+
+class QuartetCounterLookup:
+    """QuartetCounterLookup<CINT>(refTree, evalTreesPath, m, savemem) -- counting happens in the
+    constructor (QuartetCounterLookup.hpp:245-273). `savemem` is accepted and ignored: the GPU
+    table is always the compact C(n,4)x3 layout and holds semantic (1x) counts."""
+
+    def __init__(self, refTree: Union[str, flatten.RefTree], evalTreesPath, m: Optional[int] = None, savemem: bool = False,
+                 *, count_bits: Optional[int] = None, device: int = 0, stream: int = 0, algo: int = QS_ALGO_AUTO,
+                 batch_trees: int = 4096, table_tensor=None):
+        self.ref = refTree if isinstance(refTree, flatten.RefTree) else flatten.flatten_reference(refTree)
+        texts = _read_eval(evalTreesPath)
+        batch = flatten.flatten_eval_trees(texts, self.ref.name_to_id)  # raises UnknownTaxonError like QCL:218
+        self.m = batch.n_trees if m is None else m
+        self.savemem = savemem
+        bits = count_bits or count_bits_for(self.m)
+        self.ctx = Context(self.ref.n_taxa, bits, device, stream)
+        if table_tensor is not None:
+            self.ctx.table_attach(table_tensor)
+            self.ctx.table_clear()
+        else:
+            self.ctx.table_alloc()
+        for lo in range(0, batch.n_trees, batch_trees):
+            hi = min(batch.n_trees, lo + batch_trees)
+            self.ctx.count_trees(batch.slice(lo, hi) if (lo, hi) != (0, batch.n_trees) else batch, algo)
+        # "lookup table size in bytes: ..." (QuartetCounterLookup.hpp:268-272)
+        self.lookup_table_bytes = self.ctx.table_bytes
+        self._node_to_lookup = {int(v): i for i, v in enumerate(self.ref.leaf_node)}
+
+    def countQuartetOccurrences(self, aIdx: int, bIdx: int, cIdx: int, dIdx: int) -> Tuple[int, int, int]:
+        """Arguments are reference-tree NODE indices (QuartetCounterLookup.hpp:299-318)."""
+        ids = [self._node_to_lookup[x] for x in (aIdx, bIdx, cIdx, dIdx)]
+        r = self.ctx.lookup(np.array(ids, dtype=np.uint16))[0]
+        return int(r[0]), int(r[1]), int(r[2])
+
+    def table(self) -> np.ndarray:
+        return self.ctx.table_download()
+
+
+class QuartetScoreComputer:
+    """QuartetScoreComputer<CINT>(refTree, evalTreesPath, m, verboseOutput, enforceSmallMem): does
+    all the work in its constructor (QuartetScoreComputer.hpp:698-785). Scores are indexed by
+    edge; edge e is the edge above node e+1 of the reference tree in preorder."""
+
+    def __init__(self, refTree: Union[str, flatten.RefTree], evalTreesPath, m: Optional[int] = None, verboseOutput: bool = False,
+                 enforceSmallMem: bool = False, *, qp_exact64: bool = False, log=None, **kw):
+        self.ref = refTree if isinstance(refTree, flatten.RefTree) else flatten.flatten_reference(refTree)
+        say = log or (lambda s: None)
+        n = self.ref.n_taxa
+        self.quartetCounterLookup = QuartetCounterLookup(self.ref, evalTreesPath, m, enforceSmallMem, **kw)
+        say(f"There are {self.quartetCounterLookup.m} evaluation trees.")
+        say(f"The reference tree has {n} taxa.")
+        say(f"lookup table size in bytes: {self.quartetCounterLookup.lookup_table_bytes}")
+        say("Finished counting quartets.")
+        ctx = self.quartetCounterLookup.ctx
+        lq, qp, eqp, bif = ctx.score(self.ref, QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32)
+        self.bifurcating = bif
+        say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
+        self._lq, self._qp, self._eqp = lq[1:], (qp[1:] if bif else None), (eqp[1:] if bif else None)
+        say("Finished computing scores.")
+
+    def getLQICScores(self) -> List[float]:
+        return list(self._lq)
+
+    def getQPICScores(self) -> List[float]:
+        return [] if self._qp is None else list(self._qp)
+
+    def getEQPICScores(self) -> List[float]:
+        return [] if self._eqp is None else list(self._eqp)
+
+    def edge_leafset(self, e: int) -> frozenset:
+        """Taxon names below edge e (the child side)."""
+        node = self.ref.nodes[e + 1]
+        return frozenset(x.name for x in newick.preorder(node) if x.is_leaf)
+
+    def scores_by_bipartition(self):
+        """{canonical side: (lq, qp, eqp)} for internal edges, keyed like tests/oracle_api.py."""
+        names = self.ref.names
+        out = {}
+        for e in range(self.ref.n_nodes - 1):
+            below = self.edge_leafset(e)
+            if len(below) <= 1 or len(below) >= len(names) - 1:
+                continue
+            other = frozenset(names) - below
+            key = below if (len(below) < len(other) or (len(below) == len(other) and min(names) not in below)) else other
+            val = (self._lq[e], None if self._qp is None else self._qp[e], None if self._eqp is None else self._eqp[e])
+            while key in out:
+                key = frozenset(list(key) + ["#dup"])
+            out[key] = val
+        return out
+
+    def printRawQICScores(self, rawPath: str, chunk: int = 1 << 20):
+        """-q file: "(a,b|c,d): qic" per quartet resolved in the reference, in rank order.
+        (The reference prints in its Euler-tour loop order, QuartetScoreComputer.hpp:627-630; the set of
+        lines is the same.) QIC via the host libm; %g like operator<<(double)."""
+        ctx = self.quartetCounterLookup.ctx
+        names = self.ref.names
+        total = ctx.table_tuples
+        from .ranks import unrank4_np
+        with open(rawPath, "w") as f:
+            for r0 in range(0, total, chunk):
+                nq = min(chunk, total - r0)
+                topo, q = ctx.raw_qic(self.ref, r0, nq)
+                ids = unrank4_np(np.arange(r0, r0 + nq, dtype=np.int64))
+                for i in range(nq):
+                    t = topo[i]
+                    if t == 255:
+                        continue
+                    a, b, c, d = (int(x) for x in ids[i])
+                    if t == 0:
+                        lab = (names[a], names[b], names[c], names[d])
+                    else:
+                        lab = (names[a], names[d], names[b], names[c])
+                    f.write("(%s,%s|%s,%s): %g\n" % (lab + (log_score(int(q[i, 0]), int(q[i, 1]), int(q[i, 2])),)))
+
+
+def log_score(q1: int, q2: int, q3: int) -> float:
+    """QuartetScoreComputer.hpp:135-159 with the host libm (C doubles via math.log)."""
+    if q1 == 0 and q2 == 0 and q3 == 0:
+        return 0.0
+    s = q1 + q2 + q3
+    p1, p2, p3 = q1 / s, q2 / s, q3 / s
+    qic = 1.0
+    if p1 != 0:
+        qic += p1 * math.log(p1) / math.log(3)
+    if p2 != 0:
+        qic += p2 * math.log(p2) / math.log(3)
+    if p3 != 0:
+        qic += p3 * math.log(p3) / math.log(3)
+    return qic * -1 if (q1 < q2 or q1 < q3) else qic

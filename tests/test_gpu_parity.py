@@ -1,0 +1,330 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full size --
+through size-independent properties. Bit-exact for counts; scores must be identical to the
+oracle's (same libm on the host), tolerance stated as <= 1 ulp.
+Run on the GPU box: python -m pytest tests -m gpu
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import d5_trees, key_of, ulp_diff
+from oracle_api import Oracle
+from quartetscores_amd import flatten, ranks, synth
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ULP_TOL = 1  # north_star: IC scores within 1 ulp (we expect 0)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from quartetscores_amd import engine
+    return engine
+
+
+def make_case(n, m, seed, **kw):
+    ref_nw = synth.reference_tree(n, seed)
+    trees = synth.tree_set(n, m, 1000 + seed, **kw)
+    return ref_nw, trees
+
+
+def oracle_counts(ref_nw, trees, **kw):
+    o = Oracle(ref_nw)
+    o.count("\n".join(trees), nthreads=4, **kw)
+    return o
+
+
+def gpu_table(eng, ref, batch, count_bits=32, algo=None, split=None):
+    ctx = eng.Context(ref.n_taxa, count_bits)
+    ctx.table_alloc()
+    algo = eng.QS_ALGO_GATHER if algo is None else algo
+    if split:
+        for lo in range(0, batch.n_trees, split):
+            ctx.count_trees(batch.slice(lo, min(batch.n_trees, lo + split)), algo)
+    else:
+        ctx.count_trees(batch, algo)
+    return ctx, ctx.table_download()
+
+
+CASES = [
+    # n, m, dropout, collapse, rooted, seed, expected variant substring
+    (8, 20, 0.0, 0.0, False, 1, "binary_full"),
+    (32, 200, 0.0, 0.0, False, 2, "binary_full"),     # BASELINE configs[0]
+    (33, 37, 0.0, 0.0, True, 3, "binary_full"),       # rooted evaluation trees, ragged sizes
+    (24, 50, 0.0, 0.4, False, 4, "general_full"),     # multifurcating evaluation trees
+    (20, 60, 0.3, 0.3, False, 5, "partial"),          # taxon dropout + collapsed edges (fixture F2)
+    (12, 17, 0.5, 0.0, True, 6, "partial"),
+    (64, 40, 0.0, 0.0, False, 7, "binary_full"),
+]
+
+
+@pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES)
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_gather_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, variant, count_bits):
+    ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx, T = gpu_table(eng, ref, batch, count_bits)
+    assert variant in ctx.last_count_variant(), ctx.last_count_variant()
+    o = oracle_counts(ref_nw, trees)
+    assert o.names == ref.names
+    assert (T.astype(np.uint64) == o.counts()).all()
+    assert ctx.trees_counted == m
+
+
+@pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES[:6])
+def test_scatter_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, variant):
+    ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    for bits in (32, 16):
+        ctx, T = gpu_table(eng, ref, batch, bits, algo=eng.QS_ALGO_SCATTER)
+        assert "scatter" in ctx.last_count_variant()
+        o = oracle_counts(ref_nw, trees)
+        assert (T.astype(np.uint64) == o.counts()).all()
+
+
+def test_deep_trees_take_the_u16_panel(eng):
+    n = 96
+    ref_nw = synth.reference_tree(n, 9)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    trees = [cat + ";"] * 3 + synth.tree_set(n, 5, 10)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)  # depth up to n-2 > 63
+    assert int(batch.adj_depth.max()) > 63
+    ctx, T = gpu_table(eng, ref, batch)
+    assert "depth_u16" in ctx.last_count_variant()
+    o = oracle_counts(ref_nw, trees)
+    assert (T.astype(np.uint64) == o.counts()).all()
+    # partial + deep
+    trees2 = [cat + ";"] * 2 + synth.tree_set(n, 6, 11, dropout=0.2)
+    batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id, recentre=False)
+    ctx2, T2 = gpu_table(eng, ref, batch2)
+    assert "partial/depth_u16" in ctx2.last_count_variant()
+    assert (T2.astype(np.uint64) == oracle_counts(ref_nw, trees2).counts()).all()
+
+
+def test_batches_accumulate_and_are_deterministic(eng):
+    ref_nw, trees = make_case(28, 90, 12)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    _, T1 = gpu_table(eng, ref, batch)
+    _, T2 = gpu_table(eng, ref, batch, split=16)  # ragged last batch
+    _, T3 = gpu_table(eng, ref, batch, algo=eng.QS_ALGO_SCATTER, split=32)
+    assert (T1 == T2).all() and (T1 == T3).all()
+    assert (T1.sum(axis=1) == 90).all()  # every tree resolves every quartet
+
+
+def test_lookup_matches_oracle(eng):
+    ref_nw, trees = make_case(16, 30, 13, collapse=0.3)
+    ref = flatten.flatten_reference(ref_nw)
+    q = eng.QuartetCounterLookup(ref, trees)
+    o = oracle_counts(ref_nw, trees)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        ids = rng.choice(16, size=4, replace=False)
+        nodes = [int(ref.leaf_node[i]) for i in ids]
+        assert q.countQuartetOccurrences(*nodes) == o.lookup(*[int(i) for i in ids])
+
+
+def test_unknown_taxon_is_an_error(eng, golden):
+    with pytest.raises(flatten.UnknownTaxonError):
+        eng.QuartetCounterLookup(golden["D1"]["ref"], [golden["D6"]["bad_tree"]])
+
+
+def test_u16_table_overflow_is_reported(eng):
+    ref_nw, trees = make_case(8, 4, 14)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = eng.Context(8, 16)
+    ctx.table_alloc()
+    ctx.table_upload(np.full((70, 3), 65534, dtype=np.uint16))
+    with pytest.raises(eng.QSError) as ei:
+        ctx.count_trees(batch)
+    assert ei.value.code == -5
+
+
+# ---- scores ---------------------------------------------------------------------------------
+
+def assert_scores_equal(gpu_sc, ora_sc):
+    assert set(gpu_sc) == set(ora_sc)
+    worst = 0
+    for k, ov in ora_sc.items():
+        gv = gpu_sc[k]
+        for g, o in zip(gv, ov):
+            if o is None:
+                assert g is None
+                continue
+            d = int(ulp_diff(g, o))
+            worst = max(worst, d)
+            assert d <= SCORE_ULP_TOL, (sorted(k), g, o)
+    return worst
+
+
+@pytest.mark.parametrize("n,m,dropout,collapse,seed", [(8, 20, 0, 0, 21), (32, 200, 0, 0, 22), (20, 60, 0.3, 0.3, 23),
+                                                       (48, 30, 0, 0.2, 24)])
+def test_scores_bifurcating_reference(eng, n, m, dropout, collapse, seed):
+    ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse)
+    qsc = eng.QuartetScoreComputer(ref_nw, trees)
+    assert qsc.bifurcating
+    o = oracle_counts(ref_nw, trees)
+    o.score(nthreads=4)
+    worst = assert_scores_equal(qsc.scores_by_bipartition(), o.scores_by_bipartition())
+    assert worst == 0  # same libm, same triples -> identical doubles
+
+
+def test_scores_golden_D1_D2_D3(eng, golden):
+    g = golden["D1"]
+    qsc = eng.QuartetScoreComputer(g["ref"], g["eval"])
+    sc = qsc.scores_by_bipartition()
+    for k, v in g["scores"].items():
+        kk = key_of(k)
+        got = sc.get(kk) or sc[frozenset(set(qsc.ref.names) - kk)]
+        assert list(got) == v
+    # D2: multifurcating reference -> LQ-IC only
+    qsc2 = eng.QuartetScoreComputer(golden["D2"]["ref"], g["eval"])
+    assert not qsc2.bifurcating and qsc2.getQPICScores() == [] and qsc2.getEQPICScores() == []
+    sc2 = qsc2.scores_by_bipartition()
+    assert len(sc2) == len(golden["D2"]["lq"])
+    for k, v in golden["D2"]["lq"].items():
+        kk = key_of(k)
+        got = sc2.get(kk) or sc2[frozenset(set(qsc2.ref.names) - kk)]
+        assert got[0] == v
+    # D3: 150/50 mix; semantic counts, so no savemem-u8 overflow (reference defect Q1 not reproduced)
+    d3 = golden["D3"]
+    trees = [d3["eval"][0]] * 150 + [d3["eval"][1]] * 50
+    qsc3 = eng.QuartetScoreComputer(d3["ref"], trees, enforceSmallMem=True)
+    ids = [qsc3.ref.leaf_node[qsc3.ref.name_to_id[x]] for x in "abcd"]
+    assert qsc3.quartetCounterLookup.countQuartetOccurrences(*[int(i) for i in ids]) == tuple(d3["occ_abcd"])
+    sc3 = qsc3.scores_by_bipartition()
+    for k, v in d3["scores"].items():
+        assert list(sc3[key_of(k)]) == v
+
+
+def test_scores_multifurcating_reference_random(eng):
+    n = 18
+    ref_nw = synth.random_tree(n, np.random.default_rng(31), collapse=0.4)
+    trees = synth.tree_set(n, 40, 32, collapse=0.2)
+    qsc = eng.QuartetScoreComputer(ref_nw, trees)
+    o = oracle_counts(ref_nw, trees)
+    o.score()
+    assert qsc.bifurcating == o.bifurcating
+    assert_scores_equal(qsc.scores_by_bipartition(), o.scores_by_bipartition())
+
+
+def test_D5_u32_wrap_of_qp_sums(eng, golden):
+    """70 000 trees (two topologies) on 64 taxa: QP sums exceed 2^32."""
+    g = golden["D5"]
+    ref_nw, alt_nw = d5_trees(g["n"], g["block"])
+    ref = flatten.flatten_reference(ref_nw)
+    two = flatten.flatten_eval_trees([ref_nw, alt_nw], ref.name_to_id)
+    L = g["n"]
+
+    def tile(b, t, k):
+        s = b.slice(t, t + 1)
+        return s.leaf_ids, s.adj_depth, k
+    ids = np.concatenate([np.tile(two.slice(t, t + 1).leaf_ids, k) for t, k in ((0, g["mult"][0]), (1, g["mult"][1]))])
+    dep = np.concatenate([np.tile(two.slice(t, t + 1).adj_depth, k) for t, k in ((0, g["mult"][0]), (1, g["mult"][1]))])
+    m = sum(g["mult"])
+    big = flatten.TreeBatch(m, (np.arange(m + 1, dtype=np.uint32) * L), ids, dep, np.zeros(m + 1, dtype=np.uint32),
+                            np.zeros(1, dtype=np.uint32), np.zeros(0, dtype=np.uint16))
+    del tile
+    ctx = eng.Context(g["n"], 32)
+    ctx.table_alloc()
+    ctx.count_trees(big)
+    T = ctx.table_download()
+    assert (T.sum(axis=1) == m).all()
+    central = frozenset(f"t{i}" for i in range(32, 64))
+    for flag, want in ((eng.QS_SCORE_QP_WRAP32, g["qp_wrap32"]), (eng.QS_SCORE_QP_EXACT64, g["qp_exact64"])):
+        lq, qp, eqp, bif = ctx.score(ref, flag)
+        assert bif
+        hit = 0
+        for v in range(1, ref.n_nodes):
+            below = frozenset(x.name for x in __import__("quartetscores_amd").newick.preorder(ref.nodes[v]) if x.is_leaf)
+            if below == central or frozenset(ref.names) - below == central:
+                assert lq[v] == g["lq"] and qp[v] == want and eqp[v] == want
+                hit += 1
+            elif 1 < len(below) < g["n"] - 1:
+                assert lq[v] == 1.0 and qp[v] == 1.0 and eqp[v] == 1.0
+        assert hit == 1
+
+
+def test_rooted_reference_is_unrooted_for_scoring(eng, golden):
+    """Documented divergence from reference quirk Q5: a degree-2 root is an edge subdivision;
+    both root edges carry the scores the unrooted tree gives that internode."""
+    g4, g1 = golden["D4"], golden["D1"]
+    qsc = eng.QuartetScoreComputer(g4["ref"], g1["eval"])
+    found = {qsc.edge_leafset(e): (qsc.getLQICScores()[e], qsc.getQPICScores()[e], qsc.getEQPICScores()[e])
+             for e in range(qsc.ref.n_nodes - 1)}
+    want = g1["scores"]["t1,t3,t4,t5,t6"]
+    assert list(found[key_of("t1,t3,t4,t5,t6")]) == want
+    assert list(found[key_of("t0,t2,t7")]) == want
+    for k, v in g1["scores"].items():
+        if k != "t1,t3,t4,t5,t6":
+            assert list(found[key_of(k)]) == v
+
+
+def test_raw_qic_lines_match_oracle(eng, tmp_path):
+    n = 10
+    ref_nw = synth.random_tree(n, np.random.default_rng(41), collapse=0.2)
+    trees = synth.tree_set(n, 25, 42, dropout=0.1)
+    qsc = eng.QuartetScoreComputer(ref_nw, trees)
+    p1, p2 = str(tmp_path / "gpu.txt"), str(tmp_path / "ora.txt")
+    qsc.printRawQICScores(p1)
+    o = oracle_counts(ref_nw, trees)
+    o.raw_qic(p2)
+
+    def canon(path):
+        out = {}
+        for line in open(path):
+            lab, val = line.strip().split("): ")
+            l, r = lab[1:].split("|")
+            key = frozenset([frozenset(l.split(",")), frozenset(r.split(","))])
+            out[key] = val
+        return out
+    a, b = canon(p1), canon(p2)
+    assert set(a) == set(b)
+    # same quartet, same topology; the printed QIC may differ only in the p2/p3 argument order
+    same = sum(a[k] == b[k] for k in a)
+    assert same == len(a)
+
+
+# ---- BASELINE configs[1] at full size: size-independent properties -----------------------------
+
+def test_config2_full_size_properties(eng):
+    n, m = 128, 1000
+    ref_nw = synth.reference_tree(n, 2000)
+    trees = synth.tree_set(n, m, 2001)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx, T = gpu_table(eng, ref, batch, 32)
+    assert "binary_full/depth_u8" in ctx.last_count_variant()
+    assert T.shape == (ranks.n_quartets(n), 3)
+    assert (T.sum(axis=1, dtype=np.uint64) == m).all()                 # every tree resolves every quartet once
+    # linearity: counting two halves separately and together gives the same table
+    _, Th = gpu_table(eng, ref, batch, 32, split=500)
+    assert (T == Th).all()
+    # independent formulation (tree-major atomics) agrees on a 100-tree prefix, and so does the oracle
+    sub = batch.slice(0, 100)
+    _, Tg = gpu_table(eng, ref, sub, 32)
+    _, Ts = gpu_table(eng, ref, sub, 32, algo=eng.QS_ALGO_SCATTER)
+    assert (Tg == Ts).all()
+    o = oracle_counts(ref_nw, trees[:100])
+    assert (Tg.astype(np.uint64) == o.counts()).all()
+    # ... and the scores of that 100-tree table are identical to the oracle's at n = 128
+    qsc = eng.QuartetScoreComputer(ref, trees[:100])
+    o.score(nthreads=8)
+    assert assert_scores_equal(qsc.scores_by_bipartition(), o.scores_by_bipartition()) == 0
+    # scores on the full table are finite on every internal edge and idempotent
+    lq, qp, eqp, bif = ctx.score(ref)
+    lq2, qp2, eqp2, _ = ctx.score(ref)
+    assert bif and (lq == lq2).all() and (qp == qp2).all() and (eqp == eqp2).all()
+    internal = [v for v in range(1, ref.n_nodes) if ref.nodes[v].children]
+    assert np.isfinite(lq[internal]).all() and np.isfinite(qp[internal]).all() and np.isfinite(eqp[internal]).all()
+    assert (eqp[internal] <= qp[internal]).all()                       # EQP-IC is a min that includes the edge's own pair
