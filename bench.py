@@ -191,10 +191,20 @@ def main():
     if not args.no_cpu_baseline:
         try:
             from oracle_api import Oracle
-            cores = os.cpu_count() or 1
-            mp = args.cpu_baseline_trees or max(8, min(m, int(2.0e8 * cores * 15 / nq)))  # ~15 s at ~2e8 pairs/s/core-ish
-            mp = min(mp, m)
+            ncpu = os.cpu_count() or 1
             o = Oracle(ref_nw)
+            # The reference's OpenMP loop runs INSIDE one tree over very unequal items
+            # (QuartetCounterLookup.hpp:223-228) and stops scaling early; calibrate the thread
+            # count on a few trees, then time a bounded sample (~10-20 s) at the best setting.
+            calib = max(2, min(8, m))
+            best_t, best_rate = 1, 0.0
+            for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
+                tcal = o.count("\n".join(trees[:calib]), savemem=False, cint_bits=16, nthreads=th)
+                if calib * nq / tcal > best_rate:
+                    best_t, best_rate = th, calib * nq / tcal
+            cores = best_t
+            mp = args.cpu_baseline_trees or max(8, int(best_rate * 12.0 / nq))
+            mp = min(mp, m)
             tc = o.count("\n".join(trees[:mp]), savemem=False, nthreads=cores)
             cpu_val = mp * nq / tc
             # the same prefix counted on the GPU must give the same table (bit-exact gate)

@@ -47,6 +47,13 @@ def load():
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `make -C quartetscores_amd/csrc` (or __graft_entry__.build()). "
             "quartetscores_amd has no CPU fallback.")
+    # One HIP runtime per process: torch ships its own libamdhip64. If our library were loaded
+    # first it would bind /opt/rocm's copy and a later `import torch` would bring a second
+    # runtime that owns the devices (qs_create then sees none). Import torch first when present.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.qs_create.restype = i32
