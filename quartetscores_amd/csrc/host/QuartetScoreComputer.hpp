@@ -1,0 +1,229 @@
+// QuartetScoreComputer.hpp -- C++ host mirror of the reference's two hot-path classes, above the C-ABI.
+//
+//   QuartetCounterLookup<CINT>   <->  reference QuartetCounterLookup.hpp:24-53
+//   QuartetScoreComputer<CINT>   <->  reference QuartetScoreComputer.hpp:43-80
+//
+// Same constructor arguments, getters and stdout protocol, so main() reads like
+// the reference's (QuartetScores.cpp:115-147). Everything that is O(m*C(n,4)) or O(C(n,4)) happens in
+// libquartetscores_hip.so on the GPU; this header flattens trees and forwards.
+#pragma once
+
+#include "../../../include/quartetscores_hip.h"
+#include "flatten.hpp"
+#include "newick.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <tuple>
+#include <type_traits>
+
+namespace qsh {
+
+inline std::string slurp(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// Count the number of evaluation trees (QuartetScores.cpp:23-32). The reference parses the file once
+// just to count; here it is a scan for top-level ';'.
+inline size_t countEvalTrees(const std::string &evalTreesPath) {
+    std::string text = slurp(evalTreesPath);
+    NewickReader rd(text);
+    Tree t;
+    size_t m = 0;
+    while (rd.next(t)) ++m;
+    return m;
+}
+
+struct DeviceOptions {
+    int device = 0;
+    uint32_t algo = QS_ALGO_AUTO;
+    size_t batch_trees = 8192; // trees per qs_count_trees call
+    bool qp_exact64 = false;
+};
+
+template <typename CINT> class QuartetCounterLookup {
+public:
+    QuartetCounterLookup(Tree const &refTree, const std::string &evalTreesPath, size_t m, bool savemem,
+                         DeviceOptions opt = DeviceOptions())
+        : ref_(flatten_reference(refTree)), savemem_(savemem) {
+        static_assert(sizeof(CINT) <= 4, "m >= 2^32 evaluation trees are not supported by the GPU table");
+        const uint32_t bits = sizeof(CINT) <= 2 ? 16 : 32;
+        (void)m;
+        if (qs_create(&ctx_, (uint32_t)ref_.names.size(), bits, QS_FLAG_NONE, opt.device, nullptr, 0, 0) != QS_OK)
+            throw std::runtime_error(qs_last_error(nullptr));
+        if (qs_table_alloc(ctx_) != QS_OK) fail();
+        countQuartets(evalTreesPath, m, opt);
+        std::cout << "lookup table size in bytes: " << qs_table_bytes(ctx_) << "\n"; // QCL:268-272
+    }
+    ~QuartetCounterLookup() { qs_destroy(ctx_); }
+    QuartetCounterLookup(const QuartetCounterLookup &) = delete;
+    QuartetCounterLookup &operator=(const QuartetCounterLookup &) = delete;
+
+    // arguments are reference-tree NODE indices (QuartetCounterLookup.hpp:299-318)
+    std::tuple<CINT, CINT, CINT> countQuartetOccurrences(size_t aIdx, size_t bIdx, size_t cIdx, size_t dIdx) const {
+        uint16_t ids[4] = {lookup_of(aIdx), lookup_of(bIdx), lookup_of(cIdx), lookup_of(dIdx)};
+        uint64_t out[3];
+        if (qs_lookup(ctx_, 1, ids, out) != QS_OK) throw std::runtime_error(qs_last_error(ctx_));
+        return std::tuple<CINT, CINT, CINT>((CINT)out[0], (CINT)out[1], (CINT)out[2]);
+    }
+    qs_ctx *context() const { return ctx_; }
+    const RefFlat &reference() const { return ref_; }
+
+private:
+    RefFlat ref_;
+    qs_ctx *ctx_ = nullptr;
+    bool savemem_;
+
+    [[noreturn]] void fail() const { throw std::runtime_error(qs_last_error(ctx_)); }
+    uint16_t lookup_of(size_t node) const {
+        for (size_t i = 0; i < ref_.leaf_node.size(); ++i) if (ref_.leaf_node[i] == node) return (uint16_t)i;
+        throw std::out_of_range("not a leaf node");
+    }
+    // QuartetCounterLookup.hpp:196-238: stream the evaluation trees, one batch resident at a time
+    void countQuartets(const std::string &evalTreesPath, size_t m, const DeviceOptions &opt) {
+        std::string text = slurp(evalTreesPath);
+        NewickReader rd(text);
+        Tree t;
+        BatchFlat b;
+        unsigned progress = 1;
+        const float onePercent = (float)m / 100;
+        size_t i = 0;
+        auto flush = [&]() {
+            if (b.n_trees == 0) return;
+            qs_tree_batch hb;
+            hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data();
+            hb.adj_depth = b.adj_depth.data(); hb.node_off = b.node_off.data(); hb.rng_off = b.rng_off.data();
+            hb.ranges = b.ranges.data();
+            if (qs_count_trees(ctx_, &hb, opt.algo) != QS_OK) fail();
+            b.clear();
+        };
+        while (rd.next(t)) {
+            flatten_append(t, ref_.name_to_id, b);
+            if (b.n_trees >= opt.batch_trees) flush();
+            if (i > progress * onePercent) { // QCL:230-233
+                std::cout << "Counting quartets... " << progress << "%" << std::endl;
+                progress++;
+            }
+            ++i;
+        }
+        flush();
+    }
+};
+
+template <typename CINT> class QuartetScoreComputer {
+public:
+    QuartetScoreComputer(Tree const &refTree, const std::string &evalTreesPath, size_t m, bool verboseOutput,
+                         bool enforceSmallMem, DeviceOptions opt = DeviceOptions())
+        : referenceTree(refTree), verbose(verboseOutput) {
+        std::cout << "There are " << m << " evaluation trees.\n";
+        std::cout << "Building subtree informations for reference tree..." << std::endl;
+        const size_t n = refTree.leaf_count();
+        std::cout << "Finished precomputing subtree informations in reference tree.\n";
+        std::cout << "The reference tree has " << n << " taxa.\n";
+        // memory estimate (QuartetScoreComputer.hpp:724-731); the GPU always uses the compact table
+        const size_t memoryLookupFast = n * n * n * n * sizeof(CINT);
+        const size_t memoryLookup = (n * (n - 1) * (n - 2) * (n - 3) / 24) * 3 * sizeof(CINT) + sizeof(size_t);
+        std::cout << "Estimated memory usages (in bytes):" << std::endl;
+        std::cout << "  Runtime-efficient Lookup table: " << memoryLookupFast << std::endl;
+        std::cout << "  Memory-efficient Lookup table: " << memoryLookup << std::endl;
+        auto begin = std::chrono::steady_clock::now();
+        std::cout << "Using memory-efficient Lookup table\n"; // C(n,4)x3 in HBM
+        quartetCounterLookup.reset(new QuartetCounterLookup<CINT>(refTree, evalTreesPath, m, enforceSmallMem, opt));
+        auto end = std::chrono::steady_clock::now();
+        std::cout << "Finished counting quartets.\n";
+        std::cout << "It took: " << std::chrono::duration_cast<std::chrono::microseconds>(end - begin).count()
+                  << " microseconds." << std::endl;
+        begin = std::chrono::steady_clock::now();
+        const RefFlat &rf = quartetCounterLookup->reference();
+        qs_ref_tree rt;
+        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)n;
+        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
+        std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
+        int bif = 0;
+        if (qs_score(quartetCounterLookup->context(), &rt, opt.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32,
+                     lq.data(), qp.data(), eqp.data(), &bif) != QS_OK)
+            throw std::runtime_error(qs_last_error(quartetCounterLookup->context()));
+        // edge e = edge above node e+1 (preorder)
+        LQICScores.assign(lq.begin() + 1, lq.end());
+        if (bif) {
+            std::cout << "The reference tree is bifurcating.\n";
+            QPICScores.assign(qp.begin() + 1, qp.end());
+            EQPICScores.assign(eqp.begin() + 1, eqp.end());
+        } else {
+            std::cout << "The reference tree is multifurcating.\n";
+        }
+        end = std::chrono::steady_clock::now();
+        std::cout << "Finished computing scores.\n";
+        std::cout << "It took: " << std::chrono::duration_cast<std::chrono::microseconds>(end - begin).count()
+                  << " microseconds." << std::endl;
+    }
+
+    std::vector<double> getLQICScores() { return LQICScores; }
+    std::vector<double> getQPICScores() { return QPICScores; }
+    std::vector<double> getEQPICScores() { return EQPICScores; }
+
+    // QuartetScoreComputer.hpp:623-690: "(a,b|c,d): qic" per quartet resolved in the reference tree.
+    void printRawQICScores(Tree const &refTree, const std::string &rawPath) {
+        std::ofstream outfile(rawPath);
+        const RefFlat &rf = quartetCounterLookup->reference();
+        qs_ctx *ctx = quartetCounterLookup->context();
+        qs_ref_tree rt;
+        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
+        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
+        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 20;
+        std::vector<uint8_t> topo(chunk);
+        std::vector<uint64_t> q(chunk * 3);
+        // ranks in order: d outermost ... a innermost
+        uint64_t r = 0;
+        uint32_t a = 0, b = 1, c = 2, d = 3;
+        const uint32_t n = rt.n_taxa;
+        while (r < total) {
+            const uint64_t nq = std::min(chunk, total - r);
+            if (qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+            for (uint64_t i = 0; i < nq; ++i) {
+                if (topo[i] != 255) {
+                    const std::string &A = rf.names[a], &B = rf.names[b], &C = rf.names[c], &D = rf.names[d];
+                    double qic = log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+                    if (topo[i] == 0) outfile << "(" << A << "," << B << "|" << C << "," << D << "): " << qic << "\n";
+                    else outfile << "(" << A << "," << D << "|" << B << "," << C << "): " << qic << "\n";
+                }
+                // next 4-set in rank order
+                if (++a == b) { a = 0; if (++b == c) { b = 1; if (++c == d) { c = 2; ++d; } } }
+            }
+            r += nq;
+        }
+        (void)n;
+        outfile.close();
+    }
+
+    // QuartetScoreComputer.hpp:135-159 with the host libm
+    static double log_score(size_t q1, size_t q2, size_t q3) {
+        if (q1 == 0 && q2 == 0 && q3 == 0) return 0;
+        size_t sum = q1 + q2 + q3;
+        double p1 = (double)q1 / sum, p2 = (double)q2 / sum, p3 = (double)q3 / sum;
+        double qic = 1;
+        if (p1 != 0) qic += p1 * std::log(p1) / std::log(3);
+        if (p2 != 0) qic += p2 * std::log(p2) / std::log(3);
+        if (p3 != 0) qic += p3 * std::log(p3) / std::log(3);
+        return (q1 < q2 || q1 < q3) ? qic * -1 : qic;
+    }
+
+private:
+    Tree referenceTree;
+    bool verbose;
+    std::vector<double> LQICScores, QPICScores, EQPICScores;
+    std::unique_ptr<QuartetCounterLookup<CINT>> quartetCounterLookup;
+};
+
+} // namespace qsh

@@ -1,0 +1,148 @@
+// QuartetScores.cpp -- command-line driver of the MI355X engine; keeps the reference's CLI surface
+// (QuartetScores.cpp:48-79: -r -e -o required, -q -t -v -s optional) and stdout protocol.
+//
+//   QuartetScores -r ref.nwk -e eval.nwk -o out.nwk [-q raw.txt] [-t N] [-v] [-s]
+//                 [--device N] [--algo gather|scatter] [--exact-qp]
+//
+// -t is accepted for compatibility (the GPU path has no host thread pool); -s/--savemem is accepted and
+// has no effect: the GPU table is always the compact C(n,4)x3 layout with semantic (1x) counts.
+#include "QuartetScoreComputer.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+using namespace qsh;
+
+namespace {
+
+struct Args {
+    std::string ref, eval, out, raw;
+    size_t threads = 0;
+    bool verbose = false, savemem = false;
+    DeviceOptions dev;
+};
+
+void usage(std::ostream &os) {
+    os << "USAGE:\n   QuartetScores  [-s] [-v] [-t <uint>] [-q <string>] -o <string> -e <string> -r <string> [--version] [-h]\n"
+          "   -r, --ref      Path to the reference tree\n"
+          "   -e, --eval     Path to the evaluation trees\n"
+          "   -o, --output   Path to the annotated newick output file (for lqic/qpic/eqpic scores)\n"
+          "   -q, --qic      Path to the file where to write the raw QIC scores for each quartet\n"
+          "   -t, --threads  Maximum number of threads to use (accepted; the GPU path ignores it)\n"
+          "   -v, --verbose  Verbose mode\n"
+          "   -s, --savemem  Consume less memory (accepted; the GPU table is always the compact one)\n"
+          "   --device N     HIP device ordinal (default 0)\n"
+          "   --algo A       gather (default) | scatter\n"
+          "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n";
+}
+
+// returns 0 ok, 1 error (message printed like the reference prints TCLAP::ArgException), 2 exit quietly
+int parse(int argc, char **argv, Args &a) {
+    auto need = [&](int &i, const char *flag) -> const char * {
+        if (i + 1 >= argc) {
+            std::cerr << "ERROR: Missing a value for this argument! for arg " << flag << std::endl;
+            return nullptr;
+        }
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; ++i) {
+        std::string f = argv[i];
+        const char *v = nullptr;
+        if (f == "-r" || f == "--ref") { if (!(v = need(i, "-r (--ref)"))) return 1; a.ref = v; }
+        else if (f == "-e" || f == "--eval") { if (!(v = need(i, "-e (--eval)"))) return 1; a.eval = v; }
+        else if (f == "-o" || f == "--output") { if (!(v = need(i, "-o (--output)"))) return 1; a.out = v; }
+        else if (f == "-q" || f == "--qic") { if (!(v = need(i, "-q (--qic)"))) return 1; a.raw = v; }
+        else if (f == "-t" || f == "--threads") { if (!(v = need(i, "-t (--threads)"))) return 1; a.threads = std::stoul(v); }
+        else if (f == "-v" || f == "--verbose") a.verbose = true;
+        else if (f == "-s" || f == "--savemem") a.savemem = true;
+        else if (f == "--device") { if (!(v = need(i, "--device"))) return 1; a.dev.device = std::stoi(v); }
+        else if (f == "--algo") {
+            if (!(v = need(i, "--algo"))) return 1;
+            a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
+        } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
+        else if (f == "--version") { std::cout << argv[0] << "  version: 1.0.1 (" << qs_version() << ")" << std::endl; return 2; }
+        else if (f == "-h" || f == "--help") { usage(std::cout); return 2; }
+        else { std::cerr << "ERROR: Couldn't find match for argument for arg " << f << std::endl; return 1; }
+    }
+    const char *missing = a.ref.empty() ? "-r (--ref)" : a.eval.empty() ? "-e (--eval)" : a.out.empty() ? "-o (--output)" : nullptr;
+    if (missing) { std::cerr << "ERROR: Required argument missing: for arg " << missing << std::endl; return 1; }
+    return 0;
+}
+
+template <typename CINT>
+void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double> &lqic, std::vector<double> &qpic,
+         std::vector<double> &eqpic) {
+    QuartetScoreComputer<CINT> qsc(referenceTree, a.eval, m, a.verbose, a.savemem, a.dev);
+    lqic = qsc.getLQICScores();
+    qpic = qsc.getQPICScores();
+    eqpic = qsc.getEQPICScores();
+    if (!a.raw.empty()) qsc.printRawQICScores(referenceTree, a.raw);
+}
+
+} // namespace
+
+int main(int argc, char *argv[]) {
+    auto begin = std::chrono::steady_clock::now();
+    Args a;
+    int pr = parse(argc, argv, a);
+    if (pr == 1) return 1;
+    if (pr == 2) return 0;
+
+    std::ifstream infile(a.out);
+    if (infile.good()) {
+        std::cout << "ERROR: The specified output file already exists.\n";
+        return 1;
+    }
+    if (a.threads > 0)
+        std::cerr << "Note: -t has no effect, counting and scoring run on the GPU." << std::endl;
+
+    try {
+        std::string refText = slurp(a.ref);
+        NewickReader rr(refText);
+        Tree referenceTree;
+        if (!rr.next(referenceTree)) throw std::runtime_error("empty reference tree file");
+
+        if (a.verbose) {
+            for (size_t v = 0; v < referenceTree.node_count(); ++v)
+                if (referenceTree.is_leaf(v)) std::cout << referenceTree.name[v] << " " << v << "\n";
+            std::cout << std::endl;
+        }
+
+        std::vector<double> lqic, qpic, eqpic;
+        size_t m = countEvalTrees(a.eval);
+        // counter width by m as in QuartetScores.cpp:115-147 (u8 is widened to the GPU's 16-bit cells)
+        if (m < (size_t(1) << 8)) run<uint8_t>(referenceTree, a, m, lqic, qpic, eqpic);
+        else if (m < (size_t(1) << 16)) run<uint16_t>(referenceTree, a, m, lqic, qpic, eqpic);
+        else if (m < (size_t(1) << 32)) run<uint32_t>(referenceTree, a, m, lqic, qpic, eqpic);
+        else throw std::runtime_error("more than 2^32 evaluation trees are not supported");
+
+        // annotated Newick: per edge "qp-ic:X;lq-ic:Y;eqp-ic:Z" via std::to_string, parts omitted when +inf;
+        // the qp-ic guard tests the LQ value like the reference (quartet_newick_writer.hpp:164-187, quirk Q6)
+        const double inf = std::numeric_limits<double>::infinity();
+        auto comment = [&](size_t v) -> std::string {
+            if (v == 0) return std::string();
+            const size_t e = v - 1;
+            std::string s;
+            auto add = [&](const std::string &part) { if (!s.empty()) s += ";"; s += part; };
+            if (!qpic.empty() && lqic[e] != inf) add("qp-ic:" + std::to_string(qpic[e]));
+            if (lqic[e] != inf) add("lq-ic:" + std::to_string(lqic[e]));
+            if (!eqpic.empty() && eqpic[e] != inf) add("eqp-ic:" + std::to_string(eqpic[e]));
+            return s;
+        };
+        std::ofstream out(a.out);
+        if (!out) throw std::runtime_error("cannot write " + a.out);
+        out << write_newick(referenceTree, comment) << "\n";
+    } catch (const std::exception &e) {
+        std::cerr << "ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+
+    auto end = std::chrono::steady_clock::now();
+    std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::microseconds>(end - begin).count()
+              << " microseconds." << std::endl;
+    return 0;
+}

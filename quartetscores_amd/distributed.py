@@ -1,0 +1,88 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Tree-sharded mode (BASELINE.json north_star): evaluation trees are independent
+and counts add, so rank r counts trees [lo_r, hi_r) into a private full table and ONE in-place
+all-reduce (sum) of the table follows. The table lives in a torch tensor that the C-ABI context
+writes through qs_table_attach, so RCCL reduces it in place, no copy. u16 tables are reduced as
+packed int32 words: every cell total stays < 2^16 (enforced: m < 65536), so no carry crosses a
+half-word.
+
+The reference has no counterpart (single process, OpenMP only).
+"""
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+
+def shard_range(m: int, world: int, rank: int) -> Tuple[int, int]:
+    """Trees [lo, hi) of rank `rank`: contiguous, sizes differ by at most one, covers [0, m)."""
+    base, extra = divmod(m, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def table_words(n_tuples: int, count_bits: int) -> int:
+    """int32 words needed to hold the [rank][3] table (u16 tables are padded to a whole word)."""
+    return (n_tuples * 3 * (count_bits // 8) + 3) // 4
+
+
+def shard_of_largest_id(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Table-sharded mode: [d_lo, d_hi) of the largest taxon id, balanced by C(d,4) (ranks are
+    contiguous in d because rank's leading term is C(s3,4), quartet_lookup_table.hpp:161-165)."""
+    def c4(x):
+        return x * (x - 1) * (x - 2) * (x - 3) // 24
+    total = c4(n)
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r // world
+        d = bounds[-1]
+        while d < n and c4(d) < target:
+            d += 1
+        bounds.append(d)
+    bounds.append(n)
+    return bounds[rank], bounds[rank + 1]
+
+
+def all_reduce_table(table, group=None):
+    """In-place sum of the count table over all ranks (RCCL on GPU tensors, gloo on CPU tensors)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table
+
+
+def count_tree_sharded(n_trees: int, count_local: Callable[[int, int], None], table, group=None):
+    """Run `count_local(lo, hi)` on this rank's tree range, then all-reduce `table`.
+
+    count_local adds the quartet counts of trees [lo, hi) into `table` (on the GPU this is
+    Context.count_trees on a sliced batch with `table` attached)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n_trees, world, rank)
+    if hi > lo:
+        count_local(lo, hi)
+    return all_reduce_table(table, group)
+
+
+def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, device=None):
+    """Tree-sharded counting on the current torch.distributed world (one rank per GPU).
+    Returns (Context, table tensor); every rank ends with the full reduced table."""
+    import torch
+    import torch.distributed as dist
+    from . import engine
+    if count_bits == 16 and batch.n_trees >= (1 << 16):
+        raise ValueError("u16 tables need fewer than 65536 trees in total")
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream(dev)
+    ctx = engine.Context(ref.n_taxa, count_bits, device=dev.index or 0, stream=stream.cuda_stream)
+    table = torch.zeros(table_words(ctx.table_tuples, count_bits), dtype=torch.int32, device=dev)
+    ctx.table_attach(table)
+
+    def local(lo, hi):
+        ctx.count_trees(batch.slice(lo, hi), algo)
+
+    count_tree_sharded(batch.n_trees, local, table)
+    if dist.is_initialized():
+        torch.cuda.synchronize(dev)
+    return ctx, table

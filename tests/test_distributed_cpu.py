@@ -1,0 +1,85 @@
+"""world_size-2 gloo tests of the N>1 path (CPU): tree sharding + table all-reduce give the
+single-process table bit for bit, for u32 and for packed-u16 tables. The per-rank counter here
+is the numpy emulation of the device arithmetic (tests/emulate.py) because there is no GPU in
+this container; on the GPU the same host logic drives Context.count_trees."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, count_bits, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulate
+    from quartetscores_amd import distributed, flatten, ranks, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m = 9, 21
+    ref = flatten.flatten_reference(synth.reference_tree(n, 3))
+    batch = flatten.flatten_eval_trees(synth.tree_set(n, m, 4, collapse=0.2, dropout=0.1), ref.name_to_id)
+    nq = ranks.n_quartets(n)
+    table = torch.zeros(distributed.table_words(nq, count_bits), dtype=torch.int32)
+    dt = np.uint32 if count_bits == 32 else np.uint16
+    view = table.numpy().view(dt)[: nq * 3].reshape(nq, 3)
+
+    def local(lo, hi):
+        view[...] += emulate.counts_from_batch(batch.slice(lo, hi), n).astype(dt)
+
+    distributed.count_tree_sharded(m, local, table)
+    np.save(os.path.join(out_dir, f"t{rank}.npy"), view.copy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full.npy"), emulate.counts_from_batch(batch, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_tree_sharded_allreduce_equals_single_process(tmp_path, count_bits):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), count_bits, str(tmp_path)), nprocs=world, join=True)
+    full = np.load(tmp_path / "full.npy")
+    for r in range(world):
+        assert (np.load(tmp_path / f"t{r}.npy").astype(np.uint64) == full).all()
+
+
+def test_shard_ranges_cover_and_balance():
+    from quartetscores_amd import distributed
+    for m in (0, 1, 7, 1000, 100001):
+        for w in (1, 2, 3, 8):
+            spans = [distributed.shard_range(m, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    # table sharding by the largest id: contiguous, balanced by C(d,4)
+    n, w = 1024, 8
+    b = [distributed.shard_of_largest_id(n, w, r) for r in range(w)]
+    assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    c4 = lambda x: x * (x - 1) * (x - 2) * (x - 3) // 24
+    sizes = [c4(hi) - c4(lo) for lo, hi in b]
+    assert max(sizes) / (c4(n) / w) < 1.02
+
+
+def test_packed_u16_sum_has_no_cross_carry():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 30000, size=1000, dtype=np.uint16)
+    b = rng.integers(0, 30000, size=1000, dtype=np.uint16)
+    s = (a.view(np.int32) + b.view(np.int32)).view(np.uint16)
+    assert (s == a + b).all()
