@@ -44,6 +44,11 @@ def parse_args():
     ap.add_argument("--cpu-baseline-trees", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score", action="store_true")
+    ap.add_argument("--distinct-trees", type=int, default=0,
+                    help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
+    ap.add_argument("--table-shards", type=int, default=1,
+                    help="table-sharded mode (configs[4]): split the table by the largest taxon id into this many shards")
+    ap.add_argument("--shard-index", type=int, default=0, help="which shard this single-GPU run owns")
     return ap.parse_args()
 
 
@@ -63,8 +68,13 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in quartetscores_amd)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # QS_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all-reduce) even with one rank
+    use_dist = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from quartetscores_amd import engine, flatten, ranks, synth
@@ -73,27 +83,39 @@ def main():
     nq = ranks.n_quartets(n)
     # seeded inputs: seed = 1000 * config + tree set id; rank r counts tree set r
     ref_nw = synth.reference_tree(n, 2000)
-    trees = synth.tree_set(n, m, 2001 + rank)
+    distinct = min(args.distinct_trees or m, m)
+    trees = synth.tree_set(n, distinct, 2001 + rank)
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    if distinct < m:  # tile the flattened trees (every tree holds all n taxa -> fixed stride)
+        reps = -(-m // distinct)
+        ids = np.tile(batch.leaf_ids, reps)[: m * n]
+        dep = np.tile(batch.adj_depth, reps)[: m * n]
+        batch = flatten.TreeBatch(m, np.arange(m + 1, dtype=np.uint32) * n, ids, dep, np.zeros(m + 1, dtype=np.uint32),
+                                  np.zeros(1, dtype=np.uint32), np.zeros(0, dtype=np.uint16))
 
     stream = torch.cuda.current_stream(dev)
-    ctx = engine.Context(n, args.count_bits, device=local_rank, stream=stream.cuda_stream)
+    d_lo, d_hi = 0, n
+    if args.table_shards > 1:
+        from quartetscores_amd import distributed
+        d_lo, d_hi = distributed.shard_of_largest_id(n, args.table_shards, args.shard_index)
+        nq = ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo)  # quartets this GPU owns
+    ctx = engine.Context(n, args.count_bits, device=local_rank, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
     n_words = (ctx.table_bytes + 3) // 4
     table = torch.zeros(n_words, dtype=torch.int32, device=dev)  # u16 tables all-reduce as packed words
     ctx.table_attach(table)
-    hb = ctx.batch_upload(batch)  # inputs resident in HBM before the timed region
+    hb = ctx.batch_upload(batch, with_nodes=(args.algo == "scatter"))  # inputs resident in HBM before the timed region
     algo = engine.QS_ALGO_GATHER if args.algo == "gather" else engine.QS_ALGO_SCATTER
 
     def step():
         ctx.table_clear()
         ctx.count_batch(hb, algo)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(table, op=dist.ReduceOp.SUM)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -111,7 +133,7 @@ def main():
     t1 = time.perf_counter()
     ctx.sync()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -129,20 +151,21 @@ def main():
     ctx.table_clear()
     ctx.count_batch(hb, algo)
     ctx.sync()
-    T = ctx.table_download()
-    parity = bool((T.sum(axis=1, dtype=np.uint64) == m).all())
+    if args.count_bits == 32:  # every tree resolves every quartet exactly once: checked on the device
+        parity = bool((table[: nq * 3].view(nq, 3).sum(dim=1) == m).all().item())
+    else:
+        parity = bool((ctx.table_download().sum(axis=1, dtype=np.uint64) == m).all())
 
     score_ms = None
-    if not args.no_score and args.count_bits == 32:
+    if not args.no_score and args.count_bits == 32 and args.table_shards == 1:
         torch.cuda.synchronize(dev)
         s0 = time.perf_counter()
         ctx.score(ref)
         score_ms = (time.perf_counter() - s0) * 1e3
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     units_per_step = m * nq * world
@@ -165,8 +188,10 @@ def main():
         "config": {
             "workload": f"configs[1]: {n} taxa, {m} random eval trees per GPU, uint{args.count_bits} C(n,4)x3 table "
                         f"({nq} quartets), seeds 2000/2001+rank",
+            "distinct_trees": distinct,
+            "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
             "algo": variant,
-            "step": "table clear + pair-depth panel build + count kernel" + (" + RCCL all-reduce of the table" if world > 1 else ""),
+            "step": "table clear + pair-depth panel build + count kernel" + (" + RCCL all-reduce of the table" if use_dist else ""),
             "parity_tuple_sums_ok": parity,
             "panel_kernel_ms": panel_ms,
             "count_kernel_ms": count_ms,
@@ -204,7 +229,7 @@ def main():
                     best_t, best_rate = th, calib * nq / tcal
             cores = best_t
             mp = args.cpu_baseline_trees or max(8, int(best_rate * 12.0 / nq))
-            mp = min(mp, m)
+            mp = min(mp, distinct)
             tc = o.count("\n".join(trees[:mp]), savemem=False, nthreads=cores)
             cpu_val = mp * nq / tc
             # the same prefix counted on the GPU must give the same table (bit-exact gate)
@@ -221,7 +246,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -181,6 +181,27 @@ int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, 
              int *is_bifurcating);
 
 /*
+ * The same computation in steps, for table-sharded contexts (qs_create with a [d_lo,d_hi) shard) and
+ * multi-GPU runs. All buffers are CALLER-owned (e.g. torch tensors) so that the caller can reduce them
+ * over the shards between the steps; element type int64 throughout.
+ *   P = qs_score_pair_slots(ref)  (= (#inner nodes)^2; 0 on a malformed tree)
+ *   qs_score_pass1 : sums_dev[3*P] = per node pair, 64-bit sums of (q1,q2,q3) over THIS context's quartets;
+ *                    min_dev[P]   = the smallest device-evaluated QIC, order-preserving int64 encoding
+ *                    -> reduce over shards: SUM on sums_dev, MIN on min_dev (plain int64 reductions)
+ *   qs_score_pass2 : cand_dev[QS_SCORE_CAND_SLOTS*P] = distinct gcd-reduced count triples of this context
+ *                    whose QIC is within 1e-12 of min_dev (-1 = empty slot) -> all-gather over shards
+ *   qs_score_finish: pure host arithmetic on the reduced sums and the n_cand_parts gathered candidate
+ *                    arrays (each QS_SCORE_CAND_SLOTS*P long, concatenated) -> the three score vectors.
+ */
+#define QS_SCORE_CAND_SLOTS 8
+uint64_t qs_score_pair_slots(const qs_ref_tree *ref);
+int qs_score_pass1(qs_ctx *ctx, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev);
+int qs_score_pass2(qs_ctx *ctx, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev);
+int qs_score_finish(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,
+                    const int64_t *cand_host, uint32_t n_cand_parts, double *lqic, double *qpic, double *eqpic,
+                    int *is_bifurcating);
+
+/*
  * Raw per-quartet QIC (numeric part of printRawQICScores): for ranks [r0, r0+nq) of this
  * context's shard, topo[i] = 0 (s0s1|s2s3), 2 (s0s3|s1s2) or 255 (unresolved in the
  * reference tree: skipped by the reference, QuartetScoreComputer.hpp:669-672) and

@@ -12,13 +12,14 @@ QS_OK = 0
 QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEVICE, QS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER = 0, 1, 2
 QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
+QS_SCORE_CAND_SLOTS = 8
 
 # every symbol include/quartetscores_hip.h declares
 EXPORTS = [
     "qs_create", "qs_destroy", "qs_last_error", "qs_version", "qs_table_tuples", "qs_table_bytes", "qs_table_alloc",
     "qs_table_attach", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
-    "qs_score", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
+    "qs_score", "qs_score_pair_slots", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
 ]
 
 
@@ -96,6 +97,14 @@ def load():
     L.qs_lookup.argtypes = [vp, u64, vp, vp]
     L.qs_score.restype = i32
     L.qs_score.argtypes = [vp, C.POINTER(RefTreeC), u32, vp, vp, vp, C.POINTER(i32)]
+    L.qs_score_pair_slots.restype = u64
+    L.qs_score_pair_slots.argtypes = [C.POINTER(RefTreeC)]
+    L.qs_score_pass1.restype = i32
+    L.qs_score_pass1.argtypes = [vp, C.POINTER(RefTreeC), vp, vp]
+    L.qs_score_pass2.restype = i32
+    L.qs_score_pass2.argtypes = [vp, C.POINTER(RefTreeC), vp, vp]
+    L.qs_score_finish.restype = i32
+    L.qs_score_finish.argtypes = [vp, C.POINTER(RefTreeC), u32, vp, vp, u32, vp, vp, vp, C.POINTER(i32)]
     L.qs_raw_qic.restype = i32
     L.qs_raw_qic.argtypes = [vp, C.POINTER(RefTreeC), u64, u64, vp, vp]
     L.qs_last_count_ms.restype = i32

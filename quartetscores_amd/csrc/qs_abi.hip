@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -44,6 +45,12 @@ struct qs_ctx {
 };
 
 static std::string g_create_err;
+// upper bound of the pair-depth panel of one sub-batch (QS_PANEL_SLICE_BYTES overrides it: tests)
+static size_t panel_slice_bytes() {
+    const char *e = getenv("QS_PANEL_SLICE_BYTES");
+    if (e && *e) { long long v = atoll(e); if (v > 0) return (size_t)v; }
+    return 192ull << 20;
+}
 
 static int fail(qs_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_create_err = msg;
@@ -86,15 +93,18 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     // tile geometry of the gather kernel
     std::vector<uint32_t> cp(n_taxa + 2, 0);
     for (uint32_t cc = 2; cc <= n_taxa; ++cc)
-        cp[cc + 1] = cp[cc] + (uint32_t)((binom2(cc) + kCountThreads - 1) / kCountThreads);
+        cp[cc + 1] = cp[cc] + gather_tiles_for_c(cc);
     // note: cp[c] = tiles of all c' < c (c' >= 2)
     const uint32_t d_start = std::max(d_lo, 3u);
     c->n_dblk = d_hi > d_start ? (d_hi - d_start + kDB - 1) / kDB : 0;
     std::vector<uint32_t> dp(c->n_dblk + 1, 0);
+    uint64_t tiles64 = 0;
     for (uint32_t k = 0; k < c->n_dblk; ++k) {
         uint32_t d0 = d_start + k * kDB, d1 = std::min(d0 + (uint32_t)kDB, d_hi);
-        dp[k + 1] = dp[k] + cp[d1 - 1]; // c in [2, d1-1)
+        tiles64 += cp[d1 - 1]; // c in [2, d1-1)
+        dp[k + 1] = (uint32_t)tiles64;
     }
+    if (tiles64 >= (1ull << 31)) { delete c; return fail(nullptr, QS_ERR_UNSUPPORTED, "qs_create: shard too large for one launch; use a narrower [d_lo, d_hi)"); }
     c->total_tiles = dp[c->n_dblk];
     // the kernels take d_lo as the first d of block 0
     c->d_lo = d_lo; // shard boundary for ranks
@@ -291,21 +301,35 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         else if (d.max_depth <= lim16) bits = 16;
         else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(d.max_depth) + " exceeds the panel range; re-root the tree at its centre");
         const uint32_t tpc = 16 / (bits / 8);
-        const uint32_t n_chunks = (d.n_trees + tpc - 1) / tpc;
-        const size_t need = (size_t)n_chunks * (size_t)binom2(c->n) * 16;
+        // The panel of a sub-batch is kept at or below kPanelSliceBytes so that it stays resident in the
+        // 256 MiB Infinity Cache while every wave streams through it (measured at 512 taxa: 1.8e13
+        // quartets/s with a 260 MB panel, 1.35e13 with 1.3 GB). The table is read-modify-written once
+        // per sub-batch, which is cheap next to the counting itself.
+        const size_t chunk_bytes = (size_t)binom2(c->n) * 16;
+        uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes() / chunk_bytes);
+        const uint32_t n_chunks_total = (d.n_trees + tpc - 1) / tpc;
+        chunks_per_slice = std::min(chunks_per_slice, n_chunks_total);
+        const size_t need = (size_t)chunks_per_slice * chunk_bytes;
         if (need > c->panel_bytes) {
             if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
             hipError_t e = hipMalloc(&c->panel, need);
             if (e != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
             c->panel_bytes = need;
         }
-        if (gather_lds_bytes(c->d_hi) > 160 * 1024) return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: n_taxa too large for the LDS row tile");
-        QS_HIP(c, launch_build_panel(c->stream, d, c->n, bits, mode == MODE_PARTIAL, c->panel, n_chunks));
-        QS_HIP(c, hipEventRecord(c->ev[1], c->stream));
         CountGeometry g;
         g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
         g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
-        QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, n_chunks, d.n_trees, c->table, (int)c->count_bits, c->dev_flags));
+        hipEvent_t ev_panel_end = c->ev[1];
+        for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
+            const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
+            const uint32_t t0 = ch0 * tpc, nt = std::min(nch * tpc, d.n_trees - t0);
+            DeviceBatch sub = d;
+            sub.leaf_off = d.leaf_off + t0; // offsets stay absolute into leaf_ids / adj_depth
+            sub.n_trees = nt;
+            QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
+            if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
+            QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags));
+        }
         static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
         c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {
@@ -484,79 +508,115 @@ static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
     return QS_OK;
 }
 
-struct ScoreBuffers {
-    uint32_t *lca = nullptr;
-    unsigned long long *sums = nullptr, *mn = nullptr, *cand = nullptr;
-    ~ScoreBuffers() { (void)hipFree(lca); (void)hipFree(sums); (void)hipFree(mn); (void)hipFree(cand); }
+struct DevPtr { // RAII for a hipMalloc'ed pointer
+    void *p = nullptr;
+    ~DevPtr() { if (p) (void)hipFree(p); }
 };
 
-static void fill_score_device(const qs_ctx *c, const RefHost &R, const ScoreBuffers &B, ScoreDevice &sd) {
-    sd.ref_lca = B.lca; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
+static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t *lca_dev, ScoreDevice &sd) {
+    sd.ref_lca = lca_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
-    sd.pair_sums = B.sums; sd.pair_min = B.mn; sd.pair_cand = B.cand; sd.flags = c->dev_flags + 1;
+    sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
     sd.frame = R.bifurcating ? 0 : 1;
 }
 
-extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, double *lqic, double *qpic, double *eqpic,
-                        int *is_bifurcating) {
-    if (!c || !lqic) return fail(c, QS_ERR_ARG, "qs_score: NULL");
-    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score: no table");
-    if (c->d_lo != 0 || c->d_hi != c->n) return fail(c, QS_ERR_UNSUPPORTED, "qs_score: needs the whole table on this context (table-sharded scoring is not implemented yet)");
+extern "C" uint64_t qs_score_pair_slots(const qs_ref_tree *ref) {
+    if (!ref || !ref->parent || ref->n_nodes == 0) return 0;
+    std::vector<uint32_t> nchild(ref->n_nodes, 0);
+    for (uint32_t v = 0; v < ref->n_nodes; ++v)
+        if (ref->parent[v] >= 0 && (uint32_t)ref->parent[v] < ref->n_nodes) nchild[ref->parent[v]]++;
+    uint64_t ni = 0;
+    for (uint32_t v = 0; v < ref->n_nodes; ++v) ni += nchild[v] > 0;
+    return ni * ni;
+}
+
+extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev) {
+    if (!c || !sums_dev || !min_dev) return fail(c, QS_ERR_ARG, "qs_score_pass1: NULL");
+    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score_pass1: no table");
+    RefHost R;
+    int rc = build_ref(c, ref, R);
+    if (rc != QS_OK) return rc;
+    QS_HIP(c, hipSetDevice(c->device));
+    const size_t np = (size_t)R.n_inner * R.n_inner;
+    DevPtr lca;
+    QS_HIP(c, hipMalloc(&lca.p, R.lca.size() * 4));
+    QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    QS_HIP(c, hipMemsetAsync(sums_dev, 0, np * 3 * 8, c->stream));
+    QS_HIP(c, hipMemsetAsync(min_dev, 0x7F, np * 8, c->stream));
+    ScoreDevice sd;
+    fill_score_device(c, R, (const uint32_t *)lca.p, sd);
+    sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
+    QS_HIP(c, launch_score_pass1(c->stream, sd));
+    QS_HIP(c, hipStreamSynchronize(c->stream)); // lca is freed on return
+    return QS_OK;
+}
+
+extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev) {
+    if (!c || !min_dev || !cand_dev) return fail(c, QS_ERR_ARG, "qs_score_pass2: NULL");
+    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score_pass2: no table");
+    RefHost R;
+    int rc = build_ref(c, ref, R);
+    if (rc != QS_OK) return rc;
+    QS_HIP(c, hipSetDevice(c->device));
+    const size_t np = (size_t)R.n_inner * R.n_inner;
+    DevPtr lca;
+    QS_HIP(c, hipMalloc(&lca.p, R.lca.size() * 4));
+    QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    QS_HIP(c, hipMemsetAsync(cand_dev, 0xFF, np * kCand * 8, c->stream));
+    QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
+    ScoreDevice sd;
+    fill_score_device(c, R, (const uint32_t *)lca.p, sd);
+    sd.pair_min = (long long *)min_dev; sd.pair_cand = (unsigned long long *)cand_dev;
+    QS_HIP(c, launch_score_pass2(c->stream, sd, 1e-12));
+    uint32_t fl = 0;
+    QS_HIP(c, hipMemcpyAsync(&fl, c->dev_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipStreamSynchronize(c->stream));
+    if (fl & 1u) return fail(c, QS_ERR_OVERFLOW, "qs_score: more than 8 distinct near-minimal count triples for one node pair");
+    if (fl & 2u) return fail(c, QS_ERR_UNSUPPORTED, "qs_score: reduced count triple does not fit 21 bits per component");
+    return QS_OK;
+}
+
+// Pure host: log_score of the O(#node pairs) candidates and sums with the host libm
+// (QuartetScoreComputer.hpp:135-159), then the min-propagation along path(u,v) (:448-454, :472-489).
+extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,
+                               const int64_t *cand_host, uint32_t n_cand_parts, double *lqic, double *qpic, double *eqpic,
+                               int *is_bifurcating) {
+    if (!c || !sums_host || !cand_host || !lqic || n_cand_parts == 0) return fail(c, QS_ERR_ARG, "qs_score_finish: NULL");
     RefHost R;
     int rc = build_ref(c, ref, R);
     if (rc != QS_OK) return rc;
     if (is_bifurcating) *is_bifurcating = R.bifurcating ? 1 : 0;
     if (R.bifurcating && (!qpic || !eqpic)) return fail(c, QS_ERR_ARG, "qs_score: qpic/eqpic required for a bifurcating reference");
-    QS_HIP(c, hipSetDevice(c->device));
     const size_t np = (size_t)R.n_inner * R.n_inner;
-    ScoreBuffers B;
-    QS_HIP(c, hipMalloc(&B.lca, R.lca.size() * 4));
-    QS_HIP(c, hipMalloc(&B.sums, np * 3 * 8));
-    QS_HIP(c, hipMalloc(&B.mn, np * 8));
-    QS_HIP(c, hipMalloc(&B.cand, np * kCand * 8));
-    QS_HIP(c, hipMemcpyAsync(B.lca, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
-    QS_HIP(c, hipMemsetAsync(B.sums, 0, np * 3 * 8, c->stream));
-    QS_HIP(c, hipMemsetAsync(B.mn, 0xFF, np * 8, c->stream));
-    QS_HIP(c, hipMemsetAsync(B.cand, 0xFF, np * kCand * 8, c->stream));
-    QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
-    ScoreDevice sd;
-    fill_score_device(c, R, B, sd);
-    QS_HIP(c, launch_score_pass1(c->stream, sd));
-    QS_HIP(c, launch_score_pass2(c->stream, sd, 1e-12));
-    std::vector<unsigned long long> sums(np * 3), cand(np * kCand);
-    uint32_t fl = 0;
-    QS_HIP(c, hipMemcpyAsync(sums.data(), B.sums, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
-    QS_HIP(c, hipMemcpyAsync(cand.data(), B.cand, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
-    QS_HIP(c, hipMemcpyAsync(&fl, c->dev_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
-    QS_HIP(c, hipStreamSynchronize(c->stream));
-    if (fl & 1u) return fail(c, QS_ERR_OVERFLOW, "qs_score: more than 8 distinct near-minimal count triples for one node pair");
-    if (fl & 2u) return fail(c, QS_ERR_UNSUPPORTED, "qs_score: reduced count triple does not fit 21 bits per component");
-
+    const unsigned long long *sums = (const unsigned long long *)sums_host;
+    const unsigned long long *cand = (const unsigned long long *)cand_host;
     const double inf = std::numeric_limits<double>::infinity();
     const uint32_t N = R.n_nodes;
     for (uint32_t v = 0; v < N; ++v) {
         lqic[v] = inf;
         if (R.bifurcating) { qpic[v] = inf; eqpic[v] = inf; }
     }
-    // host finalisation: O(#node pairs * path length)
     for (uint32_t iu = 0; iu < R.n_inner; ++iu)
         for (uint32_t iv = iu + 1; iv < R.n_inner; ++iv) {
             const size_t key = (size_t)iu * R.n_inner + iv;
-            const unsigned long long *cs = &cand[key * kCand];
-            if (cs[0] == kCandEmpty) continue; // pair owns no resolved quartet
             double lqmin = inf;
-            for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
-                const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
-                const double v = host_log_score(q1, q2, q3);
-                lqmin = std::min(lqmin, v);
+            bool any = false;
+            for (uint32_t part = 0; part < n_cand_parts; ++part) {
+                const unsigned long long *cs = cand + ((size_t)part * np + key) * kCand;
+                for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
+                    const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
+                    const double v = host_log_score(q1, q2, q3);
+                    lqmin = std::min(lqmin, v);
+                    any = true;
+                }
             }
+            if (!any) continue; // pair owns no resolved quartet
             uint64_t p1 = sums[key * 3], p2 = sums[key * 3 + 1], p3 = sums[key * 3 + 2];
             if (!(flags & QS_SCORE_QP_EXACT64)) { p1 &= 0xFFFFFFFFull; p2 &= 0xFFFFFFFFull; p3 &= 0xFFFFFFFFull; } // QSC:382
             const double qp = host_log_score(p1, p2, p3);
             // walk the path u..v (edges are indexed by their child node)
             uint32_t x = R.inner_node[iu], y = R.inner_node[iv];
             uint32_t path_edges = 0, last_edge_a = 0, last_edge_b = 0;
-            bool through_deg2_root = false;
             while (x != y) {
                 uint32_t e;
                 if (R.depth[x] >= R.depth[y]) { e = x; x = (uint32_t)R.parent[x]; }
@@ -567,12 +627,37 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
                 ++path_edges;
             }
             if (R.bifurcating) {
-                if (path_edges == 2 && x == R.root && R.nchild[R.root] == 2) through_deg2_root = true;
+                const bool through_deg2_root = path_edges == 2 && x == R.root && R.nchild[R.root] == 2;
                 if (path_edges == 1) qpic[last_edge_a] = qp;
                 else if (through_deg2_root) { qpic[last_edge_a] = qp; qpic[last_edge_b] = qp; }
             }
         }
     return QS_OK;
+}
+
+extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, double *lqic, double *qpic, double *eqpic,
+                        int *is_bifurcating) {
+    if (!c || !lqic) return fail(c, QS_ERR_ARG, "qs_score: NULL");
+    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score: no table");
+    if (c->d_lo != 0 || c->d_hi != c->n)
+        return fail(c, QS_ERR_UNSUPPORTED, "qs_score: this context owns a table shard; use qs_score_pass1 / qs_score_pass2 / "
+                                           "qs_score_finish with reductions over the shards in between");
+    const size_t np = (size_t)qs_score_pair_slots(ref);
+    if (np == 0) return fail(c, QS_ERR_ARG, "qs_score: bad reference tree");
+    QS_HIP(c, hipSetDevice(c->device));
+    DevPtr sums, mn, cand;
+    QS_HIP(c, hipMalloc(&sums.p, np * 3 * 8));
+    QS_HIP(c, hipMalloc(&mn.p, np * 8));
+    QS_HIP(c, hipMalloc(&cand.p, np * kCand * 8));
+    int rc = qs_score_pass1(c, ref, (int64_t *)sums.p, (int64_t *)mn.p);
+    if (rc != QS_OK) return rc;
+    rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);
+    if (rc != QS_OK) return rc;
+    std::vector<int64_t> hs(np * 3), hc(np * kCand);
+    QS_HIP(c, hipMemcpyAsync(hs.data(), sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipMemcpyAsync(hc.data(), cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipStreamSynchronize(c->stream));
+    return qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, lqic, qpic, eqpic, is_bifurcating);
 }
 
 extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q) {
@@ -583,15 +668,15 @@ extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64
     int rc = build_ref(c, ref, R);
     if (rc != QS_OK) return rc;
     QS_HIP(c, hipSetDevice(c->device));
-    ScoreBuffers B;
-    QS_HIP(c, hipMalloc(&B.lca, R.lca.size() * 4));
-    QS_HIP(c, hipMemcpyAsync(B.lca, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    DevPtr lca;
+    QS_HIP(c, hipMalloc(&lca.p, R.lca.size() * 4));
+    QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
     uint8_t *dt = nullptr; unsigned long long *dq = nullptr;
     QS_HIP(c, hipMalloc(&dt, nq));
     hipError_t e = hipMalloc(&dq, nq * 24);
     if (e != hipSuccess) { (void)hipFree(dt); return fail(c, QS_ERR_OOM, "qs_raw_qic: hipMalloc"); }
     ScoreDevice sd;
-    fill_score_device(c, R, B, sd);
+    fill_score_device(c, R, (const uint32_t *)lca.p, sd);
     sd.frame = 1; // printRawQICScores uses the multifurcating loop's argument order
     e = launch_raw_qic(c->stream, sd, r0, nq, dt, dq);
     if (e == hipSuccess) e = hipMemcpyAsync(topo, dt, nq, hipMemcpyDeviceToHost, c->stream);

@@ -62,15 +62,17 @@ QS_HD int slot_of_pairing(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
     return smaller_than_partner - 1; // position of partner in sorted order minus 1
 }
 
-// order-preserving map double -> uint64 (for atomicMin on doubles)
-QS_HD uint64_t f64_to_ordered(double v) {
-    union { double d; uint64_t u; } c; c.d = v;
-    return (c.u & 0x8000000000000000ull) ? ~c.u : (c.u | 0x8000000000000000ull);
+// order-preserving map double -> int64 (signed compare == double compare), so that atomicMin on the
+// device and a MIN all-reduce over int64 (RCCL / gloo) both work on scores
+QS_HD long long f64_to_sortable(double v) {
+    union { double d; long long i; } c; c.d = v;
+    return c.i < 0 ? (long long)(0x8000000000000000ull - (unsigned long long)c.i) : c.i;
 }
-QS_HD double ordered_to_f64(uint64_t o) {
-    union { double d; uint64_t u; } c;
-    c.u = (o & 0x8000000000000000ull) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o;
+QS_HD double sortable_to_f64(long long s) {
+    union { double d; long long i; } c;
+    c.i = s < 0 ? (long long)(0x8000000000000000ull - (unsigned long long)s) : s;
     return c.d;
 }
+constexpr long long kSortableMax = 0x7F7F7F7F7F7F7F7Fll; // "no score yet" (hipMemset byte 0x7F): a huge finite double
 
 } // namespace qs

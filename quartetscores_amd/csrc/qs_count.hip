@@ -157,28 +157,36 @@ template <> struct Swar<16> {
     static constexpr uint32_t H = 0x80008000u, ONES = 0x00010001u;
 };
 
-// One 32-bit word = 4 (or 2) trees of one quartet. ab,cd / ac,bd / ad,bc are the LCA depths
-// of the three pairings. Adds the number of trees displaying each topology to c0,c1,c2.
+// SWAR comparison of one 32-bit word = 4 (u8) or 2 (u16) trees of one quartet.
+// With S1 = M[ab]+M[cd], S2 = M[ac]+M[bd], S3 = M[ad]+M[bc] (all fields < 128 / 32768):
+//   x = (S1 + H) - S2   field top bit <=> S1 >= S2, field never 0
+//   t = x - ONES        field top bit <=> S1 >  S2            -> topology ab|cd
+//   ~x                  field top bit <=> S2 >  S1            -> topology ac|bd
+//   w = (S1 + H) - S3   field top bit <=> S1 >= S3; S1 == S2 and S3 > S1 -> topology ad|bc
+// The parts that do not depend on d are hoisted by the caller: k12 = ab + H - ac, k13 = ab + H - bc,
+// so x = k12 + (cd - bd) and w = k13 + (cd - ad): two integer ops each per (d, word).
+// acc += popcount(v) in ONE instruction (v_bcnt_u32_b32 has an accumulate operand; hipcc otherwise
+// emits bcnt with 0 followed by an add)
+__device__ __forceinline__ void popc_acc(uint32_t v, uint32_t &acc) {
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(v));
+}
+
 template <int BITS, int MODE>
-__device__ __forceinline__ void swar_step(uint32_t ab, uint32_t cd, uint32_t ac, uint32_t bd, uint32_t ad, uint32_t bc,
+__device__ __forceinline__ void swar_step(uint32_t k12, uint32_t k13, uint32_t ab, uint32_t cd, uint32_t bd, uint32_t ad,
                                           uint32_t &c0, uint32_t &c1, uint32_t &c2) {
     constexpr uint32_t H = Swar<BITS>::H, ONES = Swar<BITS>::ONES;
-    const uint32_t s1h = ab + cd + H; // every field: 128 + S1  (S1 < 128)
-    const uint32_t s2 = ac + bd;
-    const uint32_t x = s1h - s2;      // field top bit: S1 >= S2 ; field value never 0
-    const uint32_t t = x - ONES;      // field top bit: S1 >  S2
+    const uint32_t x = k12 + (cd - bd);
+    const uint32_t t = x - ONES;
     if (MODE == MODE_BINARY_FULL) {
-        c0 += __popc(t & H);
-        c1 += __popc(~x & H);
+        popc_acc(t & H, c0);
+        popc_acc(~x & H, c1);
     } else {
-        const uint32_t s3 = ad + bc;
-        const uint32_t w = s1h - s3;  // field top bit: S1 >= S3
-        const uint32_t v = x & ~(t | w); // S1 == S2 and S3 > S1
+        const uint32_t w = k13 + (cd - ad);
         uint32_t hv = H;
         if (MODE == MODE_PARTIAL) hv = ~((ab | cd) << 2) & H; // flag bit (0x20 / 0x2000) -> top bit
-        c0 += __popc(t & hv);
-        c1 += __popc(~x & hv);
-        c2 += __popc(v & hv);
+        popc_acc(t & hv, c0);
+        popc_acc(~x & hv, c1);
+        popc_acc(x & ~(t | w) & hv, c2);
     }
 }
 
@@ -191,69 +199,160 @@ __device__ __forceinline__ uint32_t upper_bound_le(const uint32_t *__restrict__ 
     return lo;
 }
 
-// Workgroup = (d-block of kDB largest ids, third id c, chunk of 256 pairs (a,b) with a<b<c).
-// Lane = one (a,b): it owns the kDB quartets {a,b,c,d0..d0+7}, i.e. ranks C(d,4)+C(c,3)+pairidx.
+// Work item = one WAVEFRONT = (d-block of kDB largest ids, third id c, tile of (a,b) with a<b<c).
+// Ids below c are cut into blocks of 8. An off-diagonal tile is (a-block at) x (b-block bt), at < bt:
+// lane (ia, ib) owns a = 8*at+ia, b = 8*bt+ib. A diagonal tile packs TWO diagonal blocks (2k, 2k+1):
+// lanes 0..31 / 32..63 enumerate the 28 pairs a<b inside block 2k / 2k+1. A lane owns the kDB quartets
+// {a,b,c,d0..d0+7}; ranks C(d,4)+C(c,3)+C(b,2)+a are consecutive along a (12-byte tuples).
+// Per 16-tree chunk the wave stages only the panel elements of the pairs (x,c), (x,d) for the 16 ids x
+// of its two blocks: (1+kDB)*16 = 144 elements = 2.3 KB, independent of n; (c,d) comes through scalar
+// loads. Staging is double-buffered through registers: the global loads of chunk t+1 are issued before
+// the compute of chunk t and written to the other LDS buffer after it. The four waves of a workgroup
+// are independent (own tile, own LDS region; DS operations of one wave execute in order), so there is
+// no workgroup barrier anywhere in the kernel.
+constexpr int kTA = 8, kTB = 8;                         // tile sides (kTA * kTB == 64 lanes)
+constexpr int kCols = kTA + kTB;                        // staged ids per wave
+constexpr int kRowElems = (1 + kDB) * kCols;            // 144 staged elements
+constexpr int kStagePerLane = (kRowElems + kWave - 1) / kWave; // 3
+constexpr int kWavesPerBlock = kCountThreads / kWave;   // 4
+
 template <int BITS, int MODE, typename CT>
 __global__ __launch_bounds__(kCountThreads) void count_gather_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                      uint32_t n_chunks, uint32_t m_trees, uint32_t n,
                                                                      uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
-                                                                     uint32_t n_dblk, const uint32_t *__restrict__ dprefix,
+                                                                     uint32_t n_dblk, uint32_t total_tiles,
+                                                                     const uint32_t *__restrict__ dprefix,
                                                                      const uint32_t *__restrict__ cprefix,
-                                                                     uint32_t row_stride, CT *__restrict__ table,
+                                                                     CT *__restrict__ table,
                                                                      uint32_t *__restrict__ overflow_flag) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint4 *rows = reinterpret_cast<uint4 *>(smem); // [(1+kDB)][row_stride]
+    __shared__ uint4 stage_all[kWavesPerBlock][2][kRowElems];
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t bid = blockIdx.x;
-    // ---- tile decode (uniform) ----
-    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, bid);
-    const uint32_t local = bid - dprefix[k];
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= total_tiles) return; // whole wave
+    uint4(*stage)[kRowElems] = stage_all[wave];
+
+    // ---- tile decode (wave-uniform) ----
+    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
+    const uint32_t local = tile - dprefix[k];
     const uint32_t d0 = d_lo + k * kDB;
     const uint32_t d1 = min(d0 + (uint32_t)kDB, d_hi);
     const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
-    const uint32_t pair0 = (local - cprefix[c]) * kCountThreads;
-    const uint32_t npair_c = (uint32_t)binom2(c);
+    const uint32_t T = (c + kTB - 1) / kTB, n_off = T * (T - 1) / 2;
+    const uint32_t tl = local - cprefix[c];
+    uint32_t a0, b0, a, b, colA, colB; // colA/colB: this lane's columns in the staged rows
+    if (tl < n_off) {                  // off-diagonal tile (uniform branch)
+        uint32_t at, bt;
+        unrank2(tl, at, bt);           // at < bt
+        a0 = at * kTA; b0 = bt * kTB;
+        colA = lane & (kTA - 1); colB = kTA + lane / kTA;
+        a = a0 + colA; b = b0 + (colB - kTA);
+    } else {                           // two diagonal blocks
+        const uint32_t kd = tl - n_off;
+        a0 = (2 * kd) * kTA; b0 = (2 * kd + 1) * kTB;
+        const uint32_t h = lane >> 5, q = lane & 31;
+        uint32_t ia = 0, ib = 1;
+        if (q < 28) unrank2(q, ia, ib); // ia < ib < 8
+        colA = h * kTA + ia; colB = h * kTA + ib;
+        a = (h ? b0 : a0) + ia; b = (h ? b0 : a0) + ib;
+        if (q >= 28) b = 0xFFFFFFFFu;  // no pair
+    }
+    const bool lane_valid = (a < b) && (b < c);
+    const uint32_t pi = lane_valid ? (uint32_t)binom2(b) + a : 0u; // pair index of (a,b)
 
-    const uint32_t pi = pair0 + tid;
-    const bool lane_valid = pi < npair_c;
-    uint32_t a = 0, b = 1;
-    if (lane_valid) unrank2(pi, a, b);
+    // staging map: element e = row * 16 + col <- panel pair (x, y): row 0: y = c, row 1+j: y = d0+j;
+    // col < 8: x = a0+col, else x = b0+col-8. Elements no valid lane ever reads (x >= c, d outside the
+    // block) load pair 0: the value is irrelevant and an unconditional load is cheaper than a select.
+    uint32_t src[kStagePerLane];
+#pragma unroll
+    for (int s = 0; s < kStagePerLane; ++s) {
+        const uint32_t e = lane + s * kWave;
+        uint32_t p = 0u;
+        if (e < (uint32_t)kRowElems) {
+            const uint32_t row = e / kCols, col = e % kCols;
+            const uint32_t x = col < (uint32_t)kTA ? a0 + col : b0 + (col - kTA);
+            const uint32_t y = row == 0 ? c : d0 + (row - 1);
+            if (x < c && y < d1 && (row == 0 || y > c)) p = (uint32_t)binom2(y) + x;
+        }
+        src[s] = p;
+    }
+    // (c, d0+j): the same element for every lane -> uniform index -> scalar loads, no LDS
+    uint32_t cdi[kDB];
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) {
+        const uint32_t y = d0 + j;
+        cdi[j] = (y < d1 && y > c) ? (uint32_t)binom2(y) + c : 0u;
+    }
+    // valid d slots are j in [jlo, jhi)
+    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
+    const bool all_slots = (jlo == 0) && (jhi == (uint32_t)kDB);
 
-    const uint32_t rowC = (uint32_t)binom2(c);
     uint32_t c0[kDB], c1[kDB], c2[kDB];
 #pragma unroll
     for (int j = 0; j < kDB; ++j) c0[j] = c1[j] = c2[j] = 0;
 
+    uint4 nxt[kStagePerLane];
+#pragma unroll
+    for (int s = 0; s < kStagePerLane; ++s) nxt[s] = make_uint4(0, 0, 0, 0);
+    uint4 ab_next, cd_next[kDB];
+    // prologue: chunk 0 -> buffer 0
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) cd_next[j] = P[cdi[j]];
+#pragma unroll
+    for (int s = 0; s < kStagePerLane; ++s)
+        if (lane + s * kWave < (uint32_t)kRowElems) nxt[s] = P[src[s]];
+    ab_next = P[pi];
+#pragma unroll
+    for (int s = 0; s < kStagePerLane; ++s) {
+        const uint32_t e = lane + s * kWave;
+        if (e < (uint32_t)kRowElems) stage[0][e] = nxt[s];
+    }
+
     for (uint32_t tc = 0; tc < n_chunks; ++tc) {
-        const uint4 *Pc = P + (size_t)tc * npairs;
-        __syncthreads();
-        // rows (x,c), x < c
-        for (uint32_t x = tid; x < c; x += kCountThreads) rows[x] = Pc[rowC + x];
-        // rows (x,d), x <= c   (x == c is the pair (c,d))
+        const uint4 ab = ab_next;
+        uint4 cdv[kDB];
 #pragma unroll
-        for (int j = 0; j < kDB; ++j) {
-            const uint32_t d = d0 + j;
-            if (d < d1 && d > c) {
-                const uint32_t rowD = (uint32_t)binom2(d);
-                for (uint32_t x = tid; x <= c; x += kCountThreads) rows[(1 + j) * row_stride + x] = Pc[rowD + x];
-            }
+        for (int j = 0; j < kDB; ++j) cdv[j] = cd_next[j];
+        const uint4 *buf = stage[tc & 1];
+        if (tc + 1 < n_chunks) { // issue the next chunk's loads; they complete under the compute below
+            const uint4 *Pn = P + (size_t)(tc + 1) * npairs;
+#pragma unroll
+            for (int s = 0; s < kStagePerLane; ++s)
+                if (lane + s * kWave < (uint32_t)kRowElems) nxt[s] = Pn[src[s]];
+            ab_next = Pn[pi];
+#pragma unroll
+            for (int j = 0; j < kDB; ++j) cd_next[j] = Pn[cdi[j]];
         }
-        uint4 ab = make_uint4(0, 0, 0, 0);
-        if (lane_valid) ab = Pc[pi];
-        __syncthreads();
-        const uint4 ac = rows[a], bc = rows[b];
+        const uint4 ac = buf[colA], bc = buf[colB];
+        constexpr uint32_t H = Swar<BITS>::H;
+        const uint4 k12 = make_uint4(ab.x + H - ac.x, ab.y + H - ac.y, ab.z + H - ac.z, ab.w + H - ac.w);
+        const uint4 k13 = make_uint4(ab.x + H - bc.x, ab.y + H - bc.y, ab.z + H - bc.z, ab.w + H - bc.w);
+#define QS_SLOT(j)                                                                                          \
+    do {                                                                                                    \
+        const uint4 bd = buf[(1 + (j)) * kCols + colB];                                                     \
+        uint4 ad = bd;                                                                                      \
+        if (MODE != MODE_BINARY_FULL) ad = buf[(1 + (j)) * kCols + colA];                                   \
+        const uint4 cd = cdv[j];                                                                            \
+        swar_step<BITS, MODE>(k12.x, k13.x, ab.x, cd.x, bd.x, ad.x, c0[j], c1[j], c2[j]);                   \
+        swar_step<BITS, MODE>(k12.y, k13.y, ab.y, cd.y, bd.y, ad.y, c0[j], c1[j], c2[j]);                   \
+        swar_step<BITS, MODE>(k12.z, k13.z, ab.z, cd.z, bd.z, ad.z, c0[j], c1[j], c2[j]);                   \
+        swar_step<BITS, MODE>(k12.w, k13.w, ab.w, cd.w, bd.w, ad.w, c0[j], c1[j], c2[j]);                   \
+    } while (0)
+        if (all_slots) { // straight-line code for the common case
 #pragma unroll
-        for (int j = 0; j < kDB; ++j) {
-            const uint32_t d = d0 + j;
-            if (d < d1 && d > c) {
-                const uint4 ad = rows[(1 + j) * row_stride + a];
-                const uint4 bd = rows[(1 + j) * row_stride + b];
-                const uint4 cd = rows[(1 + j) * row_stride + c];
-                swar_step<BITS, MODE>(ab.x, cd.x, ac.x, bd.x, ad.x, bc.x, c0[j], c1[j], c2[j]);
-                swar_step<BITS, MODE>(ab.y, cd.y, ac.y, bd.y, ad.y, bc.y, c0[j], c1[j], c2[j]);
-                swar_step<BITS, MODE>(ab.z, cd.z, ac.z, bd.z, ad.z, bc.z, c0[j], c1[j], c2[j]);
-                swar_step<BITS, MODE>(ab.w, cd.w, ac.w, bd.w, ad.w, bc.w, c0[j], c1[j], c2[j]);
+            for (int j = 0; j < kDB; ++j) QS_SLOT(j);
+        } else {         // c inside the d-block, or the last block of the shard: skip the empty slots
+#pragma unroll
+            for (int j = 0; j < kDB; ++j)
+                if ((uint32_t)j >= jlo && (uint32_t)j < jhi) QS_SLOT(j);
+        }
+#undef QS_SLOT
+        if (tc + 1 < n_chunks) {
+#pragma unroll
+            for (int s = 0; s < kStagePerLane; ++s) {
+                const uint32_t e = lane + s * kWave;
+                if (e < (uint32_t)kRowElems) stage[(tc + 1) & 1][e] = nxt[s];
             }
         }
     }
@@ -275,25 +374,22 @@ __global__ __launch_bounds__(kCountThreads) void count_gather_kernel(const uint4
     }
 }
 
-size_t gather_lds_bytes(uint32_t d_hi) { return (size_t)(1 + kDB) * d_hi * sizeof(uint4); }
+size_t gather_lds_bytes(uint32_t) { return sizeof(uint4) * 2 * kRowElems * kWavesPerBlock; }
+
+uint32_t gather_tiles_for_c(uint32_t c) {
+    const uint32_t T = (c + kTB - 1) / kTB;
+    return T * (T - 1) / 2 + (T + 1) / 2; // off-diagonal tiles + pairs of diagonal blocks
+}
 
 hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void *panel, int panel_bits, int mode,
                                uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag) {
     if (g.total_tiles == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
-    const uint32_t row_stride = g.d_hi;
-    const size_t lds = gather_lds_bytes(g.d_hi);
-    dim3 grid(g.total_tiles), block(kCountThreads);
+    dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
 #define QS_GATHER(B, M, CT)                                                                                         \
-    do {                                                                                                            \
-        auto k = count_gather_kernel<B, M, CT>;                                                                     \
-        if (lds > 48 * 1024) {                                                                                      \
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                                          \
-        }                                                                                                           \
-        hipLaunchKernelGGL(k, grid, block, lds, s, (const uint4 *)panel, npairs, n_chunks, m_trees, g.n, g.d_lo, g.d_hi, \
-                           g.rank_lo, g.n_dblk, g.dprefix, g.cprefix, row_stride, (CT *)table, overflow_flag);      \
-    } while (0)
+    hipLaunchKernelGGL((count_gather_kernel<B, M, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_chunks,  \
+                       m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix, (CT *)table,     \
+                       overflow_flag)
 #define QS_GATHER_M(B, CT)                                                                                          \
     do {                                                                                                            \
         if (mode == MODE_BINARY_FULL) QS_GATHER(B, MODE_BINARY_FULL, CT);                                           \

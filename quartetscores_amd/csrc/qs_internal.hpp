@@ -55,6 +55,7 @@ hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n,
 hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,
                          int count_bits, uint64_t nq, const uint16_t *abcd_dev, uint64_t *out_dev);
 size_t gather_lds_bytes(uint32_t d_hi);
+uint32_t gather_tiles_for_c(uint32_t c); // workgroups of the gather kernel per (d-block, c)
 
 // qs_score.hip
 struct ScoreDevice {
@@ -65,7 +66,7 @@ struct ScoreDevice {
     const void *table;
     int count_bits;
     unsigned long long *pair_sums; // n_inner*n_inner*3
-    unsigned long long *pair_min;  // n_inner*n_inner (ordered f64 bits)
+    long long *pair_min;           // n_inner*n_inner (f64_to_sortable of the device QIC)
     unsigned long long *pair_cand; // n_inner*n_inner*kCand
     uint32_t *flags;               // [0] candidate overflow
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument

@@ -93,36 +93,82 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
+// ---- pass 1 -----------------------------------------------------------------------------
+// A workgroup walks kP1Iters * 256 consecutive ranks. Consecutive ranks vary the smallest id a,
+// and along a the owning node pair is piecewise constant, so (1) each wave first reduces its
+// runs of equal keys with a segmented scan (shuffles), (2) the run tails add into a small
+// open-addressing hash table in LDS (ds atomics), (3) the table is flushed once with global
+// atomics. This cuts the global atomics from 4 per quartet to 4 per distinct pair per workgroup.
+constexpr int kP1Iters = 16;
+constexpr int kP1Slots = 1024; // power of two
+constexpr uint32_t kKeyEmpty = 0xFFFFFFFFu;
+
+struct P1Lds {
+    uint32_t key[kP1Slots];
+    unsigned long long sum[kP1Slots * 3];
+    long long mn[kP1Slots];
+};
+
+__device__ __forceinline__ void p1_global_add(const ScoreDevice &sd, uint32_t key, unsigned long long s1,
+                                              unsigned long long s2, unsigned long long s3, long long mn) {
+    atomicAdd(&sd.pair_sums[(size_t)key * 3 + 0], s1);
+    atomicAdd(&sd.pair_sums[(size_t)key * 3 + 1], s2);
+    atomicAdd(&sd.pair_sums[(size_t)key * 3 + 2], s3);
+    atomicMin(&sd.pair_min[key], mn);
+}
+
 template <typename CT>
 __global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = r < sd.n_tuples;
-    QuartetRef q;
-    q.resolved = false; q.key = 0; q.q1 = q.q2 = q.q3 = 0;
-    if (in_range) q = classify<CT>(sd, r);
-    const unsigned long long valid = __ballot(q.resolved);
-    if (valid == 0) return;
-    const int leader = __ffsll((long long)valid) - 1;
-    const uint32_t lkey = __shfl(q.key, leader, 64);
-    const bool uniform = __ballot(q.resolved && q.key != lkey) == 0;
-    const unsigned long long ord = q.resolved ? f64_to_ordered(dev_log_score(q.q1, q.q2, q.q3)) : ~0ull;
-    if (uniform) {
-        const unsigned long long s1 = wave_sum_u64(q.resolved ? q.q1 : 0);
-        const unsigned long long s2 = wave_sum_u64(q.resolved ? q.q2 : 0);
-        const unsigned long long s3 = wave_sum_u64(q.resolved ? q.q3 : 0);
-        const unsigned long long mn = wave_min_u64(ord);
-        if ((int)(threadIdx.x & 63) == leader) {
-            atomicAdd(&sd.pair_sums[(size_t)lkey * 3 + 0], s1);
-            atomicAdd(&sd.pair_sums[(size_t)lkey * 3 + 1], s2);
-            atomicAdd(&sd.pair_sums[(size_t)lkey * 3 + 2], s3);
-            atomicMin(&sd.pair_min[lkey], mn);
-        }
-    } else if (q.resolved) {
-        atomicAdd(&sd.pair_sums[(size_t)q.key * 3 + 0], (unsigned long long)q.q1);
-        atomicAdd(&sd.pair_sums[(size_t)q.key * 3 + 1], (unsigned long long)q.q2);
-        atomicAdd(&sd.pair_sums[(size_t)q.key * 3 + 2], (unsigned long long)q.q3);
-        atomicMin(&sd.pair_min[q.key], ord);
+    __shared__ P1Lds lds;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t i = tid; i < kP1Slots; i += 256) {
+        lds.key[i] = kKeyEmpty;
+        lds.sum[3 * i] = lds.sum[3 * i + 1] = lds.sum[3 * i + 2] = 0;
+        lds.mn[i] = kSortableMax;
     }
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
+    for (int it = 0; it < kP1Iters; ++it) {
+        const uint64_t r = base + (uint64_t)it * 256 + tid;
+        QuartetRef q;
+        q.resolved = false; q.key = kKeyEmpty; q.q1 = q.q2 = q.q3 = 0;
+        if (r < sd.n_tuples) q = classify<CT>(sd, r);
+        const uint32_t key = q.resolved ? q.key : kKeyEmpty;
+        unsigned long long s1 = q.q1, s2 = q.q2, s3 = q.q3;
+        long long mn = q.resolved ? f64_to_sortable(dev_log_score(q.q1, q.q2, q.q3)) : kSortableMax;
+        // runs of equal keys inside the wave
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const bool head = (lane == 0) || (prev != key);
+        const unsigned long long heads = __ballot(head);
+        const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t orun = __shfl_up(run, off, 64);
+            const unsigned long long o1 = __shfl_up(s1, off, 64), o2 = __shfl_up(s2, off, 64), o3 = __shfl_up(s3, off, 64);
+            const long long om = __shfl_up(mn, off, 64);
+            if ((int)lane >= off && orun == run) { s1 += o1; s2 += o2; s3 += o3; mn = om < mn ? om : mn; }
+        }
+        const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+        if (tail && key != kKeyEmpty) {
+            uint32_t slot = (key * 2654435761u) >> 22; // 10 bits
+            bool done = false;
+            for (int probe = 0; probe < 32 && !done; ++probe) {
+                const uint32_t old = atomicCAS(&lds.key[slot], kKeyEmpty, key);
+                if (old == kKeyEmpty || old == key) {
+                    atomicAdd(&lds.sum[3 * slot + 0], s1);
+                    atomicAdd(&lds.sum[3 * slot + 1], s2);
+                    atomicAdd(&lds.sum[3 * slot + 2], s3);
+                    atomicMin(&lds.mn[slot], mn);
+                    done = true;
+                }
+                slot = (slot + 1) & (kP1Slots - 1);
+            }
+            if (!done) p1_global_add(sd, key, s1, s2, s3, mn); // table crowded: go straight to memory
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < kP1Slots; i += 256)
+        if (lds.key[i] != kKeyEmpty) p1_global_add(sd, lds.key[i], lds.sum[3 * i], lds.sum[3 * i + 1], lds.sum[3 * i + 2], lds.mn[i]);
 }
 
 __device__ __forceinline__ uint32_t gcd_u32(uint32_t x, uint32_t y) {
@@ -145,7 +191,7 @@ __global__ __launch_bounds__(256) void score_pass2_kernel(ScoreDevice sd, double
     const QuartetRef q = classify<CT>(sd, r);
     if (!q.resolved) return;
     const double sc = dev_log_score(q.q1, q.q2, q.q3);
-    const double mn = ordered_to_f64(sd.pair_min[q.key]);
+    const double mn = sortable_to_f64(sd.pair_min[q.key]);
     if (!(sc <= mn + tol)) return;
     uint32_t g = gcd_u32(gcd_u32(q.q1, q.q2), q.q3);
     if (g == 0) g = 1;
@@ -177,7 +223,8 @@ __global__ __launch_bounds__(256) void raw_qic_kernel(ScoreDevice sd, uint64_t r
 
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
     if (sd.n_tuples == 0) return hipSuccess;
-    dim3 block(256), grid((unsigned)((sd.n_tuples + 255) / 256));
+    const uint64_t per_block = 256ull * kP1Iters;
+    dim3 block(256), grid((unsigned)((sd.n_tuples + per_block - 1) / per_block));
     if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass1_kernel<uint32_t>, grid, block, 0, s, sd);
     else hipLaunchKernelGGL(score_pass1_kernel<uint16_t>, grid, block, 0, s, sd);
     return hipGetLastError();

@@ -86,3 +86,33 @@ def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, devic
     if dist.is_initialized():
         torch.cuda.synchronize(dev)
     return ctx, table
+
+
+def score_sharded(ctx, ref, flags: int = 0, group=None, device=None):
+    """LQ/QP/EQP-IC when every rank holds only a SHARD of the count table (table-sharded mode,
+    SURVEY.md 8(e)): each rank reduces its own quartets to per-node-pair accumulators, which are
+    combined over the ranks (SUM of the count sums, MIN of the best device QIC, all-gather of the
+    near-minimal count triples) before the O(#node pairs) host finalisation. Also correct on a
+    single rank. Returns (lq, qp, eqp, is_bifurcating) indexed by child node like Context.score."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    P = ctx.score_pair_slots(ref)
+    sums = torch.empty(3 * P, dtype=torch.int64, device=dev)
+    mins = torch.empty(P, dtype=torch.int64, device=dev)
+    cand = torch.empty(_lib.QS_SCORE_CAND_SLOTS * P, dtype=torch.int64, device=dev)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    ctx.score_pass1(ref, sums, mins)
+    if multi:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
+    ctx.score_pass2(ref, mins, cand)
+    if multi:
+        parts = [torch.empty_like(cand) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, cand, group=group)
+        cand_host = np.stack([p.cpu().numpy() for p in parts])
+    else:
+        cand_host = cand.cpu().numpy()[None, :]
+    return ctx.score_finish(ref, sums.cpu().numpy(), cand_host, flags)

@@ -162,6 +162,32 @@ class Context:
         del keep
         return lq, qp, eqp, bool(bif.value)
 
+    # scoring in steps (table shards / multi-GPU); buffers are torch int64 CUDA tensors owned by the caller
+    def score_pair_slots(self, ref: flatten.RefTree) -> int:
+        s, keep = self._ref_struct(ref)
+        return int(self.L.qs_score_pair_slots(C.byref(s)))
+
+    def score_pass1(self, ref: flatten.RefTree, sums, mins):
+        s, keep = self._ref_struct(ref)
+        self._chk(self.L.qs_score_pass1(self.h, C.byref(s), C.c_void_p(sums.data_ptr()), C.c_void_p(mins.data_ptr())))
+
+    def score_pass2(self, ref: flatten.RefTree, mins, cand):
+        s, keep = self._ref_struct(ref)
+        self._chk(self.L.qs_score_pass2(self.h, C.byref(s), C.c_void_p(mins.data_ptr()), C.c_void_p(cand.data_ptr())))
+
+    def score_finish(self, ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32):
+        """sums_host: int64[3P]; cand_host: int64[parts, 8P] (gathered over the shards)."""
+        s, keep = self._ref_struct(ref)
+        sums_host = np.ascontiguousarray(sums_host, dtype=np.int64)
+        cand_host = np.ascontiguousarray(cand_host, dtype=np.int64)
+        parts = cand_host.size // (_lib.QS_SCORE_CAND_SLOTS * (sums_host.size // 3))
+        lq = np.zeros(ref.n_nodes); qp = np.zeros(ref.n_nodes); eqp = np.zeros(ref.n_nodes)
+        bif = C.c_int(0)
+        self._chk(self.L.qs_score_finish(self.h, C.byref(s), flags, sums_host.ctypes.data_as(C.c_void_p),
+                                         cand_host.ctypes.data_as(C.c_void_p), parts, lq.ctypes.data_as(C.c_void_p),
+                                         qp.ctypes.data_as(C.c_void_p), eqp.ctypes.data_as(C.c_void_p), C.byref(bif)))
+        return lq, qp, eqp, bool(bif.value)
+
     def raw_qic(self, ref: flatten.RefTree, r0: int, nq: int):
         s, keep = self._ref_struct(ref)
         topo = np.zeros(nq, dtype=np.uint8)

@@ -121,6 +121,18 @@ def test_batches_accumulate_and_are_deterministic(eng):
     assert (T1.sum(axis=1) == 90).all()  # every tree resolves every quartet
 
 
+def test_panel_slicing_gives_the_same_table(eng, monkeypatch):
+    """Large batches are counted in sub-batches whose panel fits the Infinity Cache; force tiny slices."""
+    ref_nw, trees = make_case(20, 150, 15, collapse=0.2, dropout=0.1)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    _, T1 = gpu_table(eng, ref, batch)
+    monkeypatch.setenv("QS_PANEL_SLICE_BYTES", str(190 * 16 * 2))  # two 16-tree chunks per slice
+    _, T2 = gpu_table(eng, ref, batch)
+    assert (T1 == T2).all()
+    assert (T1.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all()
+
+
 def test_lookup_matches_oracle(eng):
     ref_nw, trees = make_case(16, 30, 13, collapse=0.3)
     ref = flatten.flatten_reference(ref_nw)
@@ -253,6 +265,62 @@ def test_D5_u32_wrap_of_qp_sums(eng, golden):
             elif 1 < len(below) < g["n"] - 1:
                 assert lq[v] == 1.0 and qp[v] == 1.0 and eqp[v] == 1.0
         assert hit == 1
+
+
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_table_sharded_counting_and_scoring(eng, count_bits):
+    """BASELINE configs[4] in miniature: the table is split by the largest taxon id into shards
+    (here 3 contexts on one GPU stand in for 3 GPUs); every shard sees all trees; the per-node-pair
+    accumulators are combined exactly as distributed.score_sharded does with collectives."""
+    import torch
+    from quartetscores_amd import distributed
+    n, m, G = 40, 50, 3
+    ref_nw, trees = make_case(n, m, 51, collapse=0.15, dropout=0.1)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    o = oracle_counts(ref_nw, trees)
+    full = o.counts()
+    ctxs, sums, mins = [], None, None
+    for g in range(G):
+        d_lo, d_hi = distributed.shard_of_largest_id(n, G, g)
+        ctx = eng.Context(n, count_bits, d_lo=d_lo, d_hi=d_hi)
+        ctx.table_alloc()
+        ctx.count_trees(batch)
+        T = ctx.table_download()
+        r0, r1 = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
+        assert T.shape[0] == r1 - r0 and (T.astype(np.uint64) == full[r0:r1]).all()
+        # lookups outside the shard read as zero, inside as the oracle
+        P = ctx.score_pair_slots(ref)
+        s_ = torch.empty(3 * P, dtype=torch.int64, device="cuda"); m_ = torch.empty(P, dtype=torch.int64, device="cuda")
+        ctx.score_pass1(ref, s_, m_)
+        sums = s_ if sums is None else sums + s_            # all_reduce(SUM)
+        mins = m_ if mins is None else torch.minimum(mins, m_)  # all_reduce(MIN)
+        ctxs.append(ctx)
+    cands = []
+    for ctx in ctxs:
+        c_ = torch.empty(8 * ctx.score_pair_slots(ref), dtype=torch.int64, device="cuda")
+        ctx.score_pass2(ref, mins, c_)
+        cands.append(c_.cpu().numpy())                      # all_gather
+    lq, qp, eqp, bif = ctxs[0].score_finish(ref, sums.cpu().numpy(), np.stack(cands))
+    # the same numbers as the unsharded path and as the oracle
+    whole = eng.Context(n, 32)
+    whole.table_alloc()
+    whole.count_trees(batch)
+    lq2, qp2, eqp2, bif2 = whole.score(ref)
+    assert bif == bif2 and (lq == lq2).all() and (qp == qp2).all() and (eqp == eqp2).all()
+    lq3, qp3, eqp3, _ = distributed.score_sharded(whole, ref)  # single-rank path of the same helper
+    assert (lq == lq3).all() and (qp == qp3).all() and (eqp == eqp3).all()
+    o.score()
+    osc = o.scores_by_bipartition()
+    from quartetscores_amd import newick
+    got = {}
+    for v in range(1, ref.n_nodes):
+        below = frozenset(x.name for x in newick.preorder(ref.nodes[v]) if x.is_leaf)
+        if 1 < len(below) < n - 1:
+            other = frozenset(ref.names) - below
+            key = below if (len(below) < len(other) or (len(below) == len(other) and min(ref.names) not in below)) else other
+            got[key] = (lq[v], qp[v], eqp[v])
+    assert assert_scores_equal(got, osc) == 0
 
 
 def test_rooted_reference_is_unrooted_for_scoring(eng, golden):
