@@ -294,18 +294,37 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     QS_HIP(c, hipEventRecord(c->ev[0], c->stream));
     if (algo == QS_ALGO_GATHER) {
         int mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
-        const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
-        const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
-        int bits;
-        if (d.max_depth <= lim8) bits = 8;
-        else if (d.max_depth <= lim16) bits = 16;
-        else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(d.max_depth) + " exceeds the panel range; re-root the tree at its centre");
-        const uint32_t tpc = 16 / (bits / 8);
-        // The panel of a sub-batch is kept at or below kPanelSliceBytes so that it stays resident in the
+        static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
+        CountGeometry g;
+        g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
+        g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
+        hipEvent_t ev_panel_end = c->ev[1];
+        // bits needed for the largest LCA depth
+        uint32_t depth_bits = 1;
+        while ((1u << depth_bits) <= d.max_depth) ++depth_bits;
+        const char *impl_env = getenv("QS_GATHER_IMPL"); // "swar" | "bitslice" (tests / A-B runs)
+        const bool bits_ok = depth_bits <= (mode == MODE_PARTIAL ? 6u : 7u);
+        bool use_bitslice = bits_ok;
+        if (impl_env && std::string(impl_env) == "swar") use_bitslice = false;
+        if (impl_env && std::string(impl_env) == "bitslice" && !bits_ok)
+            return fail(c, QS_ERR_UNSUPPORTED, "QS_GATHER_IMPL=bitslice: tree depth needs more than 7 (6 with missing taxa) bits");
+        // The panel of a sub-batch is kept at or below the slice size so that it stays resident in the
         // 256 MiB Infinity Cache while every wave streams through it (measured at 512 taxa: 1.8e13
         // quartets/s with a 260 MB panel, 1.35e13 with 1.3 GB). The table is read-modify-written once
         // per sub-batch, which is cheap next to the counting itself.
-        const size_t chunk_bytes = (size_t)binom2(c->n) * 16;
+        int bits = 8;
+        uint32_t tpc;            // trees per panel element
+        size_t elem_bytes;       // bytes per (pair, element)
+        if (use_bitslice) { tpc = 32; elem_bytes = 32; }
+        else {
+            const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
+            const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
+            if (d.max_depth <= lim8) bits = 8;
+            else if (d.max_depth <= lim16) bits = 16;
+            else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(d.max_depth) + " exceeds the panel range; re-root the tree at its centre");
+            tpc = 16 / (bits / 8); elem_bytes = 16;
+        }
+        const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
         uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes() / chunk_bytes);
         const uint32_t n_chunks_total = (d.n_trees + tpc - 1) / tpc;
         chunks_per_slice = std::min(chunks_per_slice, n_chunks_total);
@@ -316,22 +335,22 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (e != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
             c->panel_bytes = need;
         }
-        CountGeometry g;
-        g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
-        g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
-        hipEvent_t ev_panel_end = c->ev[1];
         for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
             const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
             const uint32_t t0 = ch0 * tpc, nt = std::min(nch * tpc, d.n_trees - t0);
             DeviceBatch sub = d;
             sub.leaf_off = d.leaf_off + t0; // offsets stay absolute into leaf_ids / adj_depth
             sub.n_trees = nt;
-            QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
+            if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch));
+            else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
             if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
-            QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags));
+            if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags));
+            else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags));
         }
-        static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
-        c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
+        if (use_bitslice)
+            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + "/count_u" + std::to_string(c->count_bits);
+        else
+            c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");

@@ -407,6 +407,400 @@ hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void
 }
 
 // ======================================================================================
+// bit-sliced gather path (default when LCA depths fit 7 bits)
+// ======================================================================================
+//
+// The SWAR kernel above is bound by VALU issue: 7 integer ops per (quartet, 4 trees), two of them
+// half-rate popcounts (tools/valu_rates.hip). Bit-slicing removes most of that work. The panel is
+// transposed into bit planes: one element = 8 words = the planes of one taxon pair for 32 trees
+// (word k, bit t = bit k of the LCA depth in tree t; word 7 = "pair present in tree t" for partial
+// batches). With
+//     L = M[ab] - M[ac] + 2^B   (per lane and c, once per 32 trees)
+//     R = M[bd] - M[cd] + 2^B   (per staged row element, computed by the staging lanes once per wave)
+// the topology test  ab|cd <=> M[ab]+M[cd] > M[ac]+M[bd] <=> L > R  is a (B+1)-bit magnitude
+// comparison done for 32 trees at once with two 3-input boolean ops per bit (v_bitop3_b32, full rate):
+//     gt = (l & ~r) | (~(l ^ r) & gt)      lt = (~l & r) | (~(l ^ r) & lt)        LSB -> MSB
+// so one (quartet, 32 trees) step costs 2(B+1) boolean ops + 2 popcounts instead of 8 x 7 ops.
+// The third topology of the general modes is the same comparison on  M[ad]-M[cd]  vs  M[ab]-M[bc].
+
+constexpr int kBitWords = 8;   // words per bit-plane element (32 bytes)
+constexpr int kBitTrees = 32;  // trees per element
+
+constexpr int kBPThreads = 256;
+constexpr int kBPPPT = 4;      // pairs per thread
+constexpr int kBPPB = kBPThreads * kBPPPT;
+
+// Bit-plane panel: uint4 Pb[n_groups][npairs][2]; built like build_panel_kernel (sparse table per tree
+// in LDS, one range-minimum per pair), 32 trees per workgroup pass, then transposed to planes.
+template <bool PARTIAL>
+__global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32_t *__restrict__ leaf_off,
+                                                                    const uint16_t *__restrict__ leaf_ids,
+                                                                    const uint16_t *__restrict__ adj_depth,
+                                                                    uint32_t n_trees, uint32_t n, uint32_t npairs,
+                                                                    uint32_t levels, uint4 *__restrict__ Pb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint8_t *out = smem;                                                           // [kBPPB][32] depth bytes (0xFF = absent)
+    uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)kBPPB * kBitTrees); // [n]
+    uint16_t *st = pos + n;                                                        // [levels][n]
+    const uint32_t tid = threadIdx.x, g = blockIdx.y, p0 = blockIdx.x * kBPPB;
+    uint32_t px[kBPPPT], py[kBPPPT];
+#pragma unroll
+    for (int q = 0; q < kBPPPT; ++q) {
+        uint32_t p = p0 + q * kBPThreads + tid;
+        if (p < npairs) unrank2(p, px[q], py[q]);
+        else { px[q] = 0; py[q] = 1; }
+    }
+    for (int j = 0; j < kBitTrees; ++j) {
+        const uint32_t t = g * kBitTrees + j;
+        if (t >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
+#pragma unroll
+            for (int q = 0; q < kBPPPT; ++q) out[(q * kBPThreads + tid) * kBitTrees + j] = PARTIAL ? 0xFF : 0;
+            continue;
+        }
+        const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
+        __syncthreads();
+        for (uint32_t x = tid; x < n; x += kBPThreads) pos[x] = 0xFFFFu;
+        __syncthreads();
+        for (uint32_t i = tid; i < L; i += kBPThreads) {
+            pos[leaf_ids[base + i]] = (uint16_t)i;
+            st[i] = adj_depth[base + i];
+        }
+        __syncthreads();
+        for (uint32_t k = 1; k < levels; ++k) {
+            const uint32_t half = 1u << (k - 1), span = 1u << k;
+            if (span + 1 <= L)
+                for (uint32_t i = tid; i + span <= L - 1; i += kBPThreads)
+                    st[k * n + i] = min(st[(k - 1) * n + i], st[(k - 1) * n + i + half]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < kBPPPT; ++q) {
+            const uint32_t a = pos[px[q]], b = pos[py[q]];
+            uint32_t val;
+            if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) val = 0xFF;
+            else {
+                const uint32_t lo = min(a, b), hi = max(a, b), len = hi - lo;
+                const uint32_t k = 31u - (uint32_t)__clz((int)len);
+                val = min(st[k * n + lo], st[k * n + hi - (1u << k)]);
+            }
+            out[(q * kBPThreads + tid) * kBitTrees + j] = (uint8_t)val;
+        }
+    }
+    __syncthreads();
+    // transpose 32 depth bytes -> 7 planes + presence plane
+#pragma unroll
+    for (int q = 0; q < kBPPPT; ++q) {
+        const uint32_t p = p0 + q * kBPThreads + tid;
+        if (p >= npairs) continue;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(out + (size_t)(q * kBPThreads + tid) * kBitTrees);
+        uint32_t w[kBitWords];
+#pragma unroll
+        for (int k = 0; k < kBitWords; ++k) w[k] = 0;
+#pragma unroll
+        for (int wd = 0; wd < 8; ++wd) {
+            const uint32_t v = src[wd]; // 4 trees
+#pragma unroll
+            for (int bt = 0; bt < 4; ++bt) {
+                const uint32_t byte = (v >> (8 * bt)) & 0xFFu;
+                const uint32_t tbit = wd * 4 + bt;
+                const bool absent = PARTIAL && byte == 0xFFu;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) w[k] |= (absent ? 0u : ((byte >> k) & 1u)) << tbit;
+                w[7] |= (absent ? 0u : 1u) << tbit;
+            }
+        }
+        uint4 *dst = Pb + ((size_t)g * npairs + p) * 2;
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel,
+                                 uint32_t n_groups) {
+    const uint32_t npairs = (uint32_t)binom2(n);
+    const uint32_t levels = panel_levels(n);
+    const size_t lds = (size_t)kBPPB * kBitTrees + (size_t)n * 2 + (size_t)levels * n * 2;
+    dim3 grid((npairs + kBPPB - 1) / kBPPB, n_groups), block(kBPThreads);
+    if (partial) {
+        auto k = build_bitpanel_kernel<true>;
+        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel);
+    } else {
+        auto k = build_bitpanel_kernel<false>;
+        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel);
+    }
+    return hipGetLastError();
+}
+
+struct Planes { uint32_t w[kBitWords]; };
+
+// One v_bitop3_b32: any boolean function of three words, given by its truth table
+// TT = f(0xF0, 0xCC, 0xAA) (bit i of TT = f at (a,b,c) = (i>>2&1, i>>1&1, i&1)). hipcc only fuses some
+// expression shapes into bitop3 (it fell back to xnor/and_or pairs here), so the hot chains use it
+// explicitly. Full rate on gfx950 (tools/valu_rates.hip).
+template <int TT> __device__ __forceinline__ uint32_t lut3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(d) : "v"(a), "v"(b), "v"(c), "n"(TT));
+    return d;
+}
+constexpr int kTT_XOR3 = 0xF0 ^ 0xCC ^ 0xAA;                                  // a ^ b ^ c
+constexpr int kTT_LT = ((0x0F & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (~a & b) | (~(a ^ b) & c): borrow / less-than step
+constexpr int kTT_GT = ((0xF0 & 0x33) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (a & ~b) | (~(a ^ b) & c): greater-than step
+constexpr int kTT_NOR_AND = (0xF0 & ~(0xCC | 0xAA)) & 0xFF;                   // a & ~(b | c)
+
+// global panel element -> registers; HI = false skips words 4..7 (depth bits < 5 and no presence plane needed)
+template <bool HI> __device__ __forceinline__ Planes load_planes(const uint4 *p) {
+    Planes r;
+    const uint4 lo = p[0];
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    if (HI) { const uint4 hi = p[1]; r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w; }
+    else { r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0; }
+    return r;
+}
+// LDS image: words 0..3 of element e at buf[e], words 4..7 at buf[kBsElems + e] (consecutive lanes ->
+// consecutive 16-byte slots: no bank conflicts)
+__device__ __forceinline__ Planes lds_load(const uint4 *buf, uint32_t e, int stride) {
+    const uint4 lo = buf[e], hi = buf[stride + e];
+    Planes r;
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store(uint4 *buf, uint32_t e, int stride, const Planes &r) {
+    buf[e] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+    buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+}
+
+// x - y + 2^B over B planes -> B+1 planes (unsigned, bias 2^B); word 7 = presence(x) & presence(y)
+template <int B>
+__device__ __forceinline__ Planes sub_biased(const Planes &x, const Planes &y) {
+    Planes r;
+    uint32_t br = 0;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const uint32_t a = x.w[k], b = y.w[k];
+        r.w[k] = lut3<kTT_XOR3>(a, b, br);
+        br = lut3<kTT_LT>(a, b, br);
+    }
+    r.w[B] = ~br;
+#pragma unroll
+    for (int k = B + 1; k < 7; ++k) r.w[k] = 0;
+    if (B < 7) r.w[7] = x.w[7] & y.w[7];
+    return r;
+}
+
+// [l > r] and [l < r] for NB-bit unsigned numbers in planes, 32 trees at once
+template <int NB>
+__device__ __forceinline__ void cmp_planes(const Planes &l, const Planes &r, uint32_t &gt, uint32_t &lt) {
+    gt = 0; lt = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t a = l.w[k], b = r.w[k];
+        gt = lut3<kTT_GT>(a, b, gt);
+        lt = lut3<kTT_LT>(a, b, lt);
+    }
+}
+template <int NB>
+__device__ __forceinline__ uint32_t gt_planes(const Planes &l, const Planes &r) {
+    uint32_t gt = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t a = l.w[k], b = r.w[k];
+        gt = lut3<kTT_GT>(a, b, gt);
+    }
+    return gt;
+}
+
+constexpr int kBsElems = (1 + kDB) * kCols;                 // 144 staged elements per wave and buffer
+constexpr int kBsPerLane = (kBsElems + kWave - 1) / kWave;  // 3
+
+// Same work decomposition as count_gather_kernel (wave = tile, lane = (a,b), kDB d slots).
+// B = depth bits; MODE as above.
+template <int B, int MODE, typename CT>
+__global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uint4 *__restrict__ P, uint32_t npairs,
+                                                                       uint32_t n_groups, uint32_t m_trees, uint32_t n,
+                                                                       uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
+                                                                       uint32_t n_dblk, uint32_t total_tiles,
+                                                                       const uint32_t *__restrict__ dprefix,
+                                                                       const uint32_t *__restrict__ cprefix,
+                                                                       CT *__restrict__ table,
+                                                                       uint32_t *__restrict__ overflow_flag) {
+    constexpr int NB = B + 1;
+    __shared__ uint4 stage_all[kWavesPerBlock][2][kBsElems * 2];
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= total_tiles) return;
+    uint4(*stage)[kBsElems * 2] = stage_all[wave];
+
+    // ---- tile decode (wave-uniform), identical to count_gather_kernel ----
+    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
+    const uint32_t local = tile - dprefix[k];
+    const uint32_t d0 = d_lo + k * kDB;
+    const uint32_t d1 = min(d0 + (uint32_t)kDB, d_hi);
+    const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
+    const uint32_t T = (c + kTB - 1) / kTB, n_off = T * (T - 1) / 2;
+    const uint32_t tl = local - cprefix[c];
+    uint32_t a0, b0, a, b, colA, colB;
+    if (tl < n_off) {
+        uint32_t at, bt;
+        unrank2(tl, at, bt);
+        a0 = at * kTA; b0 = bt * kTB;
+        colA = lane & (kTA - 1); colB = kTA + lane / kTA;
+        a = a0 + colA; b = b0 + (colB - kTA);
+    } else {
+        const uint32_t kd = tl - n_off;
+        a0 = (2 * kd) * kTA; b0 = (2 * kd + 1) * kTB;
+        const uint32_t h = lane >> 5, q = lane & 31;
+        uint32_t ia = 0, ib = 1;
+        if (q < 28) unrank2(q, ia, ib);
+        colA = h * kTA + ia; colB = h * kTA + ib;
+        a = (h ? b0 : a0) + ia; b = (h ? b0 : a0) + ib;
+        if (q >= 28) b = 0xFFFFFFFFu;
+    }
+    const bool lane_valid = (a < b) && (b < c);
+    const uint32_t pi = lane_valid ? (uint32_t)binom2(b) + a : 0u;
+
+    // staging map: element e = row * 16 + col; row 0: pair (x, c); row 1+j: pair (x, d0+j) MINUS pair (c, d0+j)
+    uint32_t src[kBsPerLane], sub[kBsPerLane];
+#pragma unroll
+    for (int s = 0; s < kBsPerLane; ++s) {
+        const uint32_t e = lane + s * kWave;
+        uint32_t p = 0u, q = 0xFFFFFFFFu;
+        if (e < (uint32_t)kBsElems) {
+            const uint32_t row = e / kCols, col = e % kCols;
+            const uint32_t x = col < (uint32_t)kTA ? a0 + col : b0 + (col - kTA);
+            const uint32_t y = row == 0 ? c : d0 + (row - 1);
+            const bool ok = x < c && y < d1 && (row == 0 || y > c);
+            if (ok) p = (uint32_t)binom2(y) + x;
+            if (row != 0) q = ok ? (uint32_t)binom2(y) + c : 0u;
+        }
+        src[s] = p; sub[s] = q;
+    }
+    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
+
+    uint32_t c0[kDB], c1[kDB], c2[kDB];
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) c0[j] = c1[j] = c2[j] = 0;
+
+    // Software pipeline: the raw panel elements of group g+1 are loaded into registers BEFORE the compute
+    // of group g; the subtraction R = M[x,d] - M[c,d] + 2^B and the LDS write happen AFTER it, so the
+    // load latency is covered by the compute of the current group.
+    constexpr bool HI = (B > 4) || (MODE == MODE_PARTIAL); // words 4..7 of a panel element are needed
+    Planes xr[kBsPerLane], yr[kBsPerLane], ab_next;
+    auto issue = [&](const uint4 *Pg) {
+#pragma unroll
+        for (int s = 0; s < kBsPerLane; ++s) {
+            if (lane + s * kWave < (uint32_t)kBsElems) {
+                xr[s] = load_planes<HI>(Pg + (size_t)src[s] * 2);
+                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes<HI>(Pg + (size_t)sub[s] * 2);
+            }
+        }
+        ab_next = load_planes<HI>(Pg + (size_t)pi * 2);
+    };
+    auto commit = [&](int bufi) {
+#pragma unroll
+        for (int s = 0; s < kBsPerLane; ++s) {
+            const uint32_t e = lane + s * kWave;
+            if (e < (uint32_t)kBsElems) {
+                Planes x = xr[s];
+                if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]); // rows 1..kDB
+                lds_store(stage[bufi], e, kBsElems, x);
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < kBsPerLane; ++s)
+#pragma unroll
+        for (int k2 = 0; k2 < kBitWords; ++k2) { xr[s].w[k2] = 0; yr[s].w[k2] = 0; }
+    issue(P);
+    commit(0);
+
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const Planes ab = ab_next;
+        const uint4 *buf = stage[g & 1];
+        if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
+        const Planes ac = lds_load(buf, colA, kBsElems);
+        const Planes L1 = sub_biased<B>(ab, ac); // M[ab] - M[ac] + 2^B ; w[7] = present(a,b) & present(a,c)
+        Planes L2;
+        if (MODE != MODE_BINARY_FULL) {
+            const Planes bc = lds_load(buf, colB, kBsElems);
+            L2 = sub_biased<B>(ab, bc);          // M[ab] - M[bc] + 2^B
+        }
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
+                const Planes Rb = lds_load(buf, (1 + j) * kCols + colB, kBsElems); // M[bd] - M[cd] + 2^B
+                uint32_t gt, lt;
+                cmp_planes<NB>(L1, Rb, gt, lt);
+                if (MODE == MODE_BINARY_FULL) {
+                    popc_acc(gt, c0[j]);
+                    popc_acc(lt, c1[j]);
+                } else {
+                    const Planes Ra = lds_load(buf, (1 + j) * kCols + colA, kBsElems); // M[ad] - M[cd] + 2^B
+                    uint32_t g2 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, L2), gt, lt);    // S1 == S2 and S3 > S1
+                    if (MODE == MODE_PARTIAL) {
+                        const uint32_t v = L1.w[7] & Rb.w[7]; // a,b,c,d all present
+                        gt &= v; lt &= v; g2 &= v;
+                    }
+                    popc_acc(gt, c0[j]);
+                    popc_acc(lt, c1[j]);
+                    popc_acc(g2, c2[j]);
+                }
+            }
+        }
+        if (g + 1 < n_groups) commit((g + 1) & 1);
+    }
+
+    if (!lane_valid) return;
+    const uint64_t rc = binom3(c) + pi;
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) {
+        const uint32_t d = d0 + j;
+        if (d < d1 && d > c) {
+            const uint64_t idx = (binom4(d) + rc - rank_lo) * 3;
+            uint32_t n0 = c0[j], n1 = c1[j], n2 = (MODE == MODE_BINARY_FULL) ? (m_trees - c0[j] - c1[j]) : c2[j];
+            uint32_t v0 = (uint32_t)table[idx] + n0, v1 = (uint32_t)table[idx + 1] + n1, v2 = (uint32_t)table[idx + 2] + n2;
+            if (sizeof(CT) == 2 && ((v0 | v1 | v2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+            table[idx] = (CT)v0;
+            table[idx + 1] = (CT)v1;
+            table[idx + 2] = (CT)v2;
+        }
+    }
+}
+
+hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
+                                 uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag) {
+    if (g.total_tiles == 0) return hipSuccess;
+    const uint32_t npairs = (uint32_t)binom2(g.n);
+    dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
+#define QS_BS(BB, M, CT)                                                                                            \
+    hipLaunchKernelGGL((count_bitslice_kernel<BB, M, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
+                       m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
+                       (CT *)table, overflow_flag)
+#define QS_BS_M(BB, CT)                                                                                             \
+    do {                                                                                                            \
+        if (mode == MODE_BINARY_FULL) QS_BS(BB, MODE_BINARY_FULL, CT);                                              \
+        else if (mode == MODE_GENERAL_FULL) QS_BS(BB, MODE_GENERAL_FULL, CT);                                       \
+        else QS_BS(BB, MODE_PARTIAL, CT);                                                                           \
+    } while (0)
+#define QS_BS_B(CT)                                                                                                 \
+    do {                                                                                                            \
+        if (depth_bits <= 4) QS_BS_M(4, CT);                                                                        \
+        else if (depth_bits == 5) QS_BS_M(5, CT);                                                                   \
+        else if (depth_bits == 6) QS_BS_M(6, CT);                                                                   \
+        else QS_BS_M(7, CT);                                                                                        \
+    } while (0)
+    if (count_bits == 32) QS_BS_B(uint32_t); else QS_BS_B(uint16_t);
+#undef QS_BS_B
+#undef QS_BS_M
+#undef QS_BS
+    return hipGetLastError();
+}
+
+// ======================================================================================
 // scatter count kernel (tree-major, atomics)
 // ======================================================================================
 

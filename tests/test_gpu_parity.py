@@ -64,12 +64,16 @@ CASES = [
 
 @pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES)
 @pytest.mark.parametrize("count_bits", [32, 16])
-def test_gather_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, variant, count_bits):
+@pytest.mark.parametrize("impl", ["bitslice", "swar"])
+def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, rooted, seed, variant, count_bits, impl):
+    """Both gather implementations: bit-sliced (default) and the byte-SWAR one (fallback for deep trees)."""
+    monkeypatch.setenv("QS_GATHER_IMPL", impl)
     ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     ctx, T = gpu_table(eng, ref, batch, count_bits)
     assert variant in ctx.last_count_variant(), ctx.last_count_variant()
+    assert ("bitslice" in ctx.last_count_variant()) == (impl == "bitslice")
     o = oracle_counts(ref_nw, trees)
     assert o.names == ref.names
     assert (T.astype(np.uint64) == o.counts()).all()
@@ -88,7 +92,7 @@ def test_scatter_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, va
         assert (T.astype(np.uint64) == o.counts()).all()
 
 
-def test_deep_trees_take_the_u16_panel(eng):
+def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     n = 96
     ref_nw = synth.reference_tree(n, 9)
     ref = flatten.flatten_reference(ref_nw)
@@ -98,16 +102,38 @@ def test_deep_trees_take_the_u16_panel(eng):
     trees = [cat + ";"] * 3 + synth.tree_set(n, 5, 10)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)  # depth up to n-2 > 63
     assert int(batch.adj_depth.max()) > 63
+    o = oracle_counts(ref_nw, trees)
+    ctx, T = gpu_table(eng, ref, batch)
+    assert "bitslice_b7" in ctx.last_count_variant()  # 7 depth bits still fit the bit-sliced kernel
+    assert (T.astype(np.uint64) == o.counts()).all()
+    monkeypatch.setenv("QS_GATHER_IMPL", "swar")
     ctx, T = gpu_table(eng, ref, batch)
     assert "depth_u16" in ctx.last_count_variant()
-    o = oracle_counts(ref_nw, trees)
     assert (T.astype(np.uint64) == o.counts()).all()
+    monkeypatch.delenv("QS_GATHER_IMPL")
     # partial + deep
     trees2 = [cat + ";"] * 2 + synth.tree_set(n, 6, 11, dropout=0.2)
     batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id, recentre=False)
     ctx2, T2 = gpu_table(eng, ref, batch2)
     assert "partial/depth_u16" in ctx2.last_count_variant()
     assert (T2.astype(np.uint64) == oracle_counts(ref_nw, trees2).counts()).all()
+
+
+def test_very_deep_trees_fall_back_to_swar_u16(eng):
+    n = 150
+    ref_nw = synth.reference_tree(n, 19)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    trees = [cat + ";"] * 2 + synth.tree_set(n, 3, 20)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
+    assert int(batch.adj_depth.max()) > 127
+    ctx, T = gpu_table(eng, ref, batch)
+    assert "depth_u16" in ctx.last_count_variant()
+    assert (T.sum(axis=1) == 5).all()
+    _, T2 = gpu_table(eng, ref, flatten.flatten_eval_trees(trees, ref.name_to_id))  # re-centred: shallow again
+    assert (T == T2).all()
 
 
 def test_batches_accumulate_and_are_deterministic(eng):
@@ -372,7 +398,7 @@ def test_config2_full_size_properties(eng):
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     ctx, T = gpu_table(eng, ref, batch, 32)
-    assert "binary_full/depth_u8" in ctx.last_count_variant()
+    assert "binary_full/bitslice" in ctx.last_count_variant()
     assert T.shape == (ranks.n_quartets(n), 3)
     assert (T.sum(axis=1, dtype=np.uint64) == m).all()                 # every tree resolves every quartet once
     # linearity: counting two halves separately and together gives the same table
