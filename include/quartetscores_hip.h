@@ -70,6 +70,10 @@ enum {
 #define QS_ALGO_GATHER 1u   /* quartet-major: each lane owns table cells, trees streamed as pair-depth panels */
 #define QS_ALGO_SCATTER 2u  /* tree-major: one wavefront per (tree, inner node, orientation), atomicAdd */
 
+/* OR-ed into `algo`: the table's previous contents are discarded -- same result as qs_table_clear
+ * followed by the count, without the extra clear and read passes over the table (gather only) */
+#define QS_COUNT_OVERWRITE 0x100u
+
 /* qs_score flags */
 #define QS_SCORE_QP_WRAP32 0u   /* reference-compatible: QP sums kept mod 2^32 (QuartetScoreComputer.hpp:382) */
 #define QS_SCORE_QP_EXACT64 1u  /* 64-bit sums */

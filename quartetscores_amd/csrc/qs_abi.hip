@@ -288,9 +288,13 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     const DeviceBatch &d = b->d;
     if (d.n_trees == 0) return QS_OK;
     QS_HIP(c, hipSetDevice(c->device));
-    if (c->count_bits == 16 && c->trees_counted + d.n_trees > 0xFFFFull)
+    if (c->count_bits == 16 && ((algo & QS_COUNT_OVERWRITE) ? 0 : c->trees_counted) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "qs_count_batch: more than 65535 trees need count_bits = 32");
+    const bool overwrite = (algo & QS_COUNT_OVERWRITE) != 0;
+    algo &= ~QS_COUNT_OVERWRITE;
     if (algo == QS_ALGO_AUTO) algo = QS_ALGO_GATHER;
+    if (overwrite && algo != QS_ALGO_GATHER) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_COUNT_OVERWRITE needs the gather algorithm");
+    if (overwrite) c->trees_counted = 0;
     QS_HIP(c, hipEventRecord(c->ev[0], c->stream));
     if (algo == QS_ALGO_GATHER) {
         int mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
@@ -344,8 +348,8 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
             if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
-            if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags));
-            else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags));
+            if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+            else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }
         if (use_bitslice)
             c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + "/count_u" + std::to_string(c->count_bits);

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kCountThreads) void count_gather_kernel(const uint4
                                                                      const uint32_t *__restrict__ dprefix,
                                                                      const uint32_t *__restrict__ cprefix,
                                                                      CT *__restrict__ table,
-                                                                     uint32_t *__restrict__ overflow_flag) {
+                                                                     uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
     __shared__ uint4 stage_all[kWavesPerBlock][2][kRowElems];
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -365,7 +365,8 @@ __global__ __launch_bounds__(kCountThreads) void count_gather_kernel(const uint4
         if (d < d1 && d > c) {
             const uint64_t idx = (binom4(d) + rc - rank_lo) * 3;
             uint32_t n0 = c0[j], n1 = c1[j], n2 = (MODE == MODE_BINARY_FULL) ? (m_trees - c0[j] - c1[j]) : c2[j];
-            uint32_t v0 = (uint32_t)table[idx] + n0, v1 = (uint32_t)table[idx + 1] + n1, v2 = (uint32_t)table[idx + 2] + n2;
+            uint32_t v0 = n0, v1 = n1, v2 = n2;
+            if (!overwrite) { v0 += (uint32_t)table[idx]; v1 += (uint32_t)table[idx + 1]; v2 += (uint32_t)table[idx + 2]; }
             if (sizeof(CT) == 2 && ((v0 | v1 | v2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
             table[idx] = (CT)v0;
             table[idx + 1] = (CT)v1;
@@ -382,14 +383,15 @@ uint32_t gather_tiles_for_c(uint32_t c) {
 }
 
 hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void *panel, int panel_bits, int mode,
-                               uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag) {
+                               uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
+                               bool overwrite) {
     if (g.total_tiles == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
 #define QS_GATHER(B, M, CT)                                                                                         \
     hipLaunchKernelGGL((count_gather_kernel<B, M, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_chunks,  \
                        m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix, (CT *)table,     \
-                       overflow_flag)
+                       overflow_flag, overwrite ? 1u : 0u)
 #define QS_GATHER_M(B, CT)                                                                                          \
     do {                                                                                                            \
         if (mode == MODE_BINARY_FULL) QS_GATHER(B, MODE_BINARY_FULL, CT);                                           \
@@ -427,11 +429,15 @@ constexpr int kBitWords = 8;   // words per bit-plane element (32 bytes)
 constexpr int kBitTrees = 32;  // trees per element
 
 constexpr int kBPThreads = 256;
-constexpr int kBPPPT = 4;      // pairs per thread
+constexpr int kBPPPT = 1;      // pairs per thread (small workgroups: many resident per CU hide the LDS round trips)
 constexpr int kBPPB = kBPThreads * kBPPPT;
 
-// Bit-plane panel: uint4 Pb[n_groups][npairs][2]; built like build_panel_kernel (sparse table per tree
-// in LDS, one range-minimum per pair), 32 trees per workgroup pass, then transposed to planes.
+// Bit-plane panel: uint4 Pb[n_groups][npairs][2]. Workgroup = (group of 32 trees, 1024 pairs). The
+// four waves work on different trees at the same time: a wave builds the tree's leaf positions and
+// sparse table (range minimum over adj_depth) in its own LDS region -- DS operations of one wave
+// execute in order, so no workgroup barrier is needed -- and answers the workgroup's 1024 pair queries
+// for that tree (2 LDS reads + min each). One barrier, then the 32 depth bytes of every pair are
+// transposed to 7 planes + the presence plane and stored as two coalesced uint4.
 template <bool PARTIAL>
 __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32_t *__restrict__ leaf_off,
                                                                     const uint16_t *__restrict__ leaf_ids,
@@ -439,60 +445,58 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
                                                                     uint32_t n_trees, uint32_t n, uint32_t npairs,
                                                                     uint32_t levels, uint4 *__restrict__ Pb) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint8_t *out = smem;                                                           // [kBPPB][32] depth bytes (0xFF = absent)
-    uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)kBPPB * kBitTrees); // [n]
-    uint16_t *st = pos + n;                                                        // [levels][n]
-    const uint32_t tid = threadIdx.x, g = blockIdx.y, p0 = blockIdx.x * kBPPB;
-    uint32_t px[kBPPPT], py[kBPPPT];
-#pragma unroll
-    for (int q = 0; q < kBPPPT; ++q) {
-        uint32_t p = p0 + q * kBPThreads + tid;
-        if (p < npairs) unrank2(p, px[q], py[q]);
-        else { px[q] = 0; py[q] = 1; }
-    }
-    for (int j = 0; j < kBitTrees; ++j) {
+    uint8_t *out = smem;                                     // [kBPPB][32] depth bytes (0xFF = absent)
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const size_t per_wave = (size_t)n * 2 * (1 + levels);
+    uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)kBPPB * kBitTrees + wave * per_wave); // [n]
+    uint16_t *st = pos + n;                                                                          // [levels][n]
+    const uint32_t g = blockIdx.y, p0 = blockIdx.x * kBPPB;
+    constexpr int kWavesPB = kBPThreads / kWave;
+    constexpr int kQPL = kBPPB / kWave; // queries per lane and tree (16)
+
+    for (int j = (int)wave; j < kBitTrees; j += kWavesPB) {
         const uint32_t t = g * kBitTrees + j;
         if (t >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
-#pragma unroll
-            for (int q = 0; q < kBPPPT; ++q) out[(q * kBPThreads + tid) * kBitTrees + j] = PARTIAL ? 0xFF : 0;
+            for (int q = 0; q < kQPL; ++q) out[(size_t)(q * kWave + lane) * kBitTrees + j] = PARTIAL ? 0xFF : 0;
             continue;
         }
         const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
-        __syncthreads();
-        for (uint32_t x = tid; x < n; x += kBPThreads) pos[x] = 0xFFFFu;
-        __syncthreads();
-        for (uint32_t i = tid; i < L; i += kBPThreads) {
+        for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
+        for (uint32_t i = lane; i < L; i += kWave) {
             pos[leaf_ids[base + i]] = (uint16_t)i;
             st[i] = adj_depth[base + i];
         }
-        __syncthreads();
         for (uint32_t k = 1; k < levels; ++k) {
             const uint32_t half = 1u << (k - 1), span = 1u << k;
             if (span + 1 <= L)
-                for (uint32_t i = tid; i + span <= L - 1; i += kBPThreads)
+                for (uint32_t i = lane; i + span <= L - 1; i += kWave)
                     st[k * n + i] = min(st[(k - 1) * n + i], st[(k - 1) * n + i + half]);
-            __syncthreads();
         }
-#pragma unroll
-        for (int q = 0; q < kBPPPT; ++q) {
-            const uint32_t a = pos[px[q]], b = pos[py[q]];
-            uint32_t val;
-            if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) val = 0xFF;
-            else {
-                const uint32_t lo = min(a, b), hi = max(a, b), len = hi - lo;
-                const uint32_t k = 31u - (uint32_t)__clz((int)len);
-                val = min(st[k * n + lo], st[k * n + hi - (1u << k)]);
+        for (int q = 0; q < kQPL; ++q) {
+            const uint32_t pl = q * kWave + lane, p = p0 + pl;
+            uint32_t val = 0;
+            if (p < npairs) {
+                uint32_t x, y;
+                unrank2(p, x, y);
+                const uint32_t a = pos[x], b = pos[y];
+                if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) val = 0xFF;
+                else {
+                    const uint32_t lo = min(a, b), hi = max(a, b), len = hi - lo;
+                    const uint32_t k = 31u - (uint32_t)__clz((int)len);
+                    val = min(st[k * n + lo], st[k * n + hi - (1u << k)]);
+                }
             }
-            out[(q * kBPThreads + tid) * kBitTrees + j] = (uint8_t)val;
+            out[(size_t)pl * kBitTrees + j] = (uint8_t)val;
         }
     }
     __syncthreads();
     // transpose 32 depth bytes -> 7 planes + presence plane
 #pragma unroll
     for (int q = 0; q < kBPPPT; ++q) {
-        const uint32_t p = p0 + q * kBPThreads + tid;
+        const uint32_t pl = q * kBPThreads + tid, p = p0 + pl;
         if (p >= npairs) continue;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(out + (size_t)(q * kBPThreads + tid) * kBitTrees);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(out + (size_t)pl * kBitTrees);
         uint32_t w[kBitWords];
 #pragma unroll
         for (int k = 0; k < kBitWords; ++k) w[k] = 0;
@@ -519,7 +523,7 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
                                  uint32_t n_groups) {
     const uint32_t npairs = (uint32_t)binom2(n);
     const uint32_t levels = panel_levels(n);
-    const size_t lds = (size_t)kBPPB * kBitTrees + (size_t)n * 2 + (size_t)levels * n * 2;
+    const size_t lds = (size_t)kBPPB * kBitTrees + (size_t)(kBPThreads / kWave) * n * 2 * (1 + levels);
     dim3 grid((npairs + kBPPB - 1) / kBPPB, n_groups), block(kBPThreads);
     if (partial) {
         auto k = build_bitpanel_kernel<true>;
@@ -560,16 +564,25 @@ template <bool HI> __device__ __forceinline__ Planes load_planes(const uint4 *p)
 }
 // LDS image: words 0..3 of element e at buf[e], words 4..7 at buf[kBsElems + e] (consecutive lanes ->
 // consecutive 16-byte slots: no bank conflicts)
-__device__ __forceinline__ Planes lds_load(const uint4 *buf, uint32_t e, int stride) {
-    const uint4 lo = buf[e], hi = buf[stride + e];
+// WIDE = false: only word 4 of the upper half is live (B <= 4, no presence plane): it is kept in a
+// 4-byte array behind the 16-byte one, which shrinks the image from 32 to 20 bytes per element.
+template <bool WIDE> __device__ __forceinline__ Planes lds_load(const uint4 *buf, uint32_t e, int stride) {
+    const uint4 lo = buf[e];
     Planes r;
     r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
-    r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+    if (WIDE) {
+        const uint4 hi = buf[stride + e];
+        r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+    } else {
+        r.w[4] = reinterpret_cast<const uint32_t *>(buf + stride)[e];
+        r.w[5] = r.w[6] = r.w[7] = 0;
+    }
     return r;
 }
-__device__ __forceinline__ void lds_store(uint4 *buf, uint32_t e, int stride, const Planes &r) {
+template <bool WIDE> __device__ __forceinline__ void lds_store(uint4 *buf, uint32_t e, int stride, const Planes &r) {
     buf[e] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
-    buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+    if (WIDE) buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+    else reinterpret_cast<uint32_t *>(buf + stride)[e] = r.w[4];
 }
 
 // x - y + 2^B over B planes -> B+1 planes (unsigned, bias 2^B); word 7 = presence(x) & presence(y)
@@ -625,15 +638,17 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
                                                                        const uint32_t *__restrict__ dprefix,
                                                                        const uint32_t *__restrict__ cprefix,
                                                                        CT *__restrict__ table,
-                                                                       uint32_t *__restrict__ overflow_flag) {
+                                                                       uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
     constexpr int NB = B + 1;
-    __shared__ uint4 stage_all[kWavesPerBlock][2][kBsElems * 2];
+    constexpr bool WIDE = (B > 4) || (MODE == MODE_PARTIAL);           // LDS image holds words 4..7
+    constexpr int kImg = WIDE ? kBsElems * 2 : kBsElems + kBsElems / 4; // uint4 slots per wave and buffer
+    __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
     if (tile >= total_tiles) return;
-    uint4(*stage)[kBsElems * 2] = stage_all[wave];
+    uint4(*stage)[kImg] = stage_all[wave];
 
     // ---- tile decode (wave-uniform), identical to count_gather_kernel ----
     const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
@@ -707,7 +722,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
             if (e < (uint32_t)kBsElems) {
                 Planes x = xr[s];
                 if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]); // rows 1..kDB
-                lds_store(stage[bufi], e, kBsElems, x);
+                lds_store<WIDE>(stage[bufi], e, kBsElems, x);
             }
         }
     };
@@ -722,24 +737,24 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
         const Planes ab = ab_next;
         const uint4 *buf = stage[g & 1];
         if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
-        const Planes ac = lds_load(buf, colA, kBsElems);
+        const Planes ac = lds_load<WIDE>(buf, colA, kBsElems);
         const Planes L1 = sub_biased<B>(ab, ac); // M[ab] - M[ac] + 2^B ; w[7] = present(a,b) & present(a,c)
         Planes L2;
         if (MODE != MODE_BINARY_FULL) {
-            const Planes bc = lds_load(buf, colB, kBsElems);
+            const Planes bc = lds_load<WIDE>(buf, colB, kBsElems);
             L2 = sub_biased<B>(ab, bc);          // M[ab] - M[bc] + 2^B
         }
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
             if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
-                const Planes Rb = lds_load(buf, (1 + j) * kCols + colB, kBsElems); // M[bd] - M[cd] + 2^B
+                const Planes Rb = lds_load<WIDE>(buf, (1 + j) * kCols + colB, kBsElems); // M[bd] - M[cd] + 2^B
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
                 if (MODE == MODE_BINARY_FULL) {
                     popc_acc(gt, c0[j]);
                     popc_acc(lt, c1[j]);
                 } else {
-                    const Planes Ra = lds_load(buf, (1 + j) * kCols + colA, kBsElems); // M[ad] - M[cd] + 2^B
+                    const Planes Ra = lds_load<WIDE>(buf, (1 + j) * kCols + colA, kBsElems); // M[ad] - M[cd] + 2^B
                     uint32_t g2 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, L2), gt, lt);    // S1 == S2 and S3 > S1
                     if (MODE == MODE_PARTIAL) {
                         const uint32_t v = L1.w[7] & Rb.w[7]; // a,b,c,d all present
@@ -762,7 +777,8 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
         if (d < d1 && d > c) {
             const uint64_t idx = (binom4(d) + rc - rank_lo) * 3;
             uint32_t n0 = c0[j], n1 = c1[j], n2 = (MODE == MODE_BINARY_FULL) ? (m_trees - c0[j] - c1[j]) : c2[j];
-            uint32_t v0 = (uint32_t)table[idx] + n0, v1 = (uint32_t)table[idx + 1] + n1, v2 = (uint32_t)table[idx + 2] + n2;
+            uint32_t v0 = n0, v1 = n1, v2 = n2;
+            if (!overwrite) { v0 += (uint32_t)table[idx]; v1 += (uint32_t)table[idx + 1]; v2 += (uint32_t)table[idx + 2]; }
             if (sizeof(CT) == 2 && ((v0 | v1 | v2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
             table[idx] = (CT)v0;
             table[idx + 1] = (CT)v1;
@@ -772,14 +788,15 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
 }
 
 hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
-                                 uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag) {
+                                 uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
+                                 bool overwrite) {
     if (g.total_tiles == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
 #define QS_BS(BB, M, CT)                                                                                            \
     hipLaunchKernelGGL((count_bitslice_kernel<BB, M, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
-                       (CT *)table, overflow_flag)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u)
 #define QS_BS_M(BB, CT)                                                                                             \
     do {                                                                                                            \
         if (mode == MODE_BINARY_FULL) QS_BS(BB, MODE_BINARY_FULL, CT);                                              \

@@ -49,10 +49,12 @@ struct CountGeometry {
 hipError_t launch_build_panel(hipStream_t s, const DeviceBatch &b, uint32_t n, int panel_bits, bool partial, void *panel,
                               uint32_t n_chunks);
 hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void *panel, int panel_bits, int mode,
-                               uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag);
+                               uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
+                               bool overwrite);
 hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel, uint32_t n_groups);
 hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
-                                 uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag);
+                                 uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
+                                 bool overwrite);
 hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
                                 uint64_t rank_lo, void *table, int count_bits);
 hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,

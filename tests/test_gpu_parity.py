@@ -147,6 +147,27 @@ def test_batches_accumulate_and_are_deterministic(eng):
     assert (T1.sum(axis=1) == 90).all()  # every tree resolves every quartet
 
 
+def test_overwrite_mode_equals_clear_plus_count(eng, monkeypatch):
+    ref_nw, trees = make_case(26, 70, 16, collapse=0.1)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    for impl in ("bitslice", "swar"):
+        monkeypatch.setenv("QS_GATHER_IMPL", impl)
+        ctx = eng.Context(26, 32)
+        ctx.table_alloc()
+        ctx.table_upload(np.full((ranks.n_quartets(26), 3), 12345, dtype=np.uint32))  # stale contents
+        hb = ctx.batch_upload(batch)
+        ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+        ctx.sync()
+        T = ctx.table_download()
+        assert ctx.trees_counted == 70
+        assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all()
+        ctx.count_batch(hb, eng.QS_ALGO_GATHER)  # accumulates on top
+        ctx.sync()
+        assert (ctx.table_download() == 2 * T).all() and ctx.trees_counted == 140
+        ctx.batch_free(hb)
+
+
 def test_panel_slicing_gives_the_same_table(eng, monkeypatch):
     """Large batches are counted in sub-batches whose panel fits the Infinity Cache; force tiny slices."""
     ref_nw, trees = make_case(20, 150, 15, collapse=0.2, dropout=0.1)
