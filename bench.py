@@ -157,6 +157,21 @@ def main():
         parity = bool((table[: nq * 3].view(nq, 3).sum(dim=1) == m).all().item())
     else:
         parity = bool((ctx.table_download().sum(axis=1, dtype=np.uint64) == m).all())
+    # stronger gate (the tuple sums are trivially m in the binary_full variant): the table must equal the one
+    # the independent byte-SWAR implementation of the same count produces, bit for bit, on the device
+    impl_match = None
+    if args.algo == "gather" and "bitslice" in variant:
+        mine = table.clone()
+        os.environ["QS_GATHER_IMPL"] = "swar"
+        step()
+        ctx.sync()
+        del os.environ["QS_GATHER_IMPL"]
+        impl_match = bool(torch.equal(mine, table))
+        swar_variant = ctx.last_count_variant()
+        step()  # restore the default implementation's table (and variant string)
+        ctx.sync()
+        assert "swar" not in ctx.last_count_variant() and "depth_u" in swar_variant
+        del mine
 
     score_ms = None
     if not args.no_score and args.count_bits == 32 and args.table_shards == 1:
@@ -195,6 +210,7 @@ def main():
             "algo": variant,
             "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + (" + RCCL all-reduce of the table" if use_dist else ""),
             "parity_tuple_sums_ok": parity,
+            "parity_bitslice_equals_swar_impl": impl_match,
             "panel_kernel_ms": panel_ms,
             "count_kernel_ms": count_ms,
             "score_phase_ms": score_ms,
@@ -214,6 +230,22 @@ def main():
                     "below this and frac can exceed 1 (its own limit is VALU issue, see DESIGN.md)",
         },
     }
+
+    # HBM traffic of the dominant kernel: bench.py cannot collect PMC counters itself; when the committed
+    # rocprofv3 summary of THIS kernel variant on THIS default workload exists, report it (per launch;
+    # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is, KB -> bytes)
+    try:
+        if (n, m, args.count_bits, args.table_shards) == (128, 1000, 32, 1):
+            with open(os.path.join(ROOT, "profiles", "r01_final_bench_pmc_hbm.json")) as f:
+                pmc = json.load(f)
+            kname = out["roofline"]["kernel"]
+            fk = [v for k_, v in pmc["FETCH_SIZE"].items() if kname in k_]
+            wk = [v for k_, v in pmc["WRITE_SIZE"].items() if kname in k_]
+            if fk and wk:
+                out["roofline"]["traffic"] = (2 * fk[0]["avg_KB_per_dispatch"] + wk[0]["avg_KB_per_dispatch"]) * 1024
+                out["roofline"]["traffic_source"] = "profiles/r01_final_bench_pmc_hbm.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)"
+    except Exception:
+        pass
 
     if not args.no_cpu_baseline:
         try:

@@ -31,6 +31,8 @@
 #include "qs_common.hpp"
 #include "qs_internal.hpp"
 
+#include <cstdlib>
+
 namespace qs {
 
 // ======================================================================================
@@ -638,7 +640,10 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
                                                                        const uint32_t *__restrict__ dprefix,
                                                                        const uint32_t *__restrict__ cprefix,
                                                                        CT *__restrict__ table,
-                                                                       uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
+                                                                       uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
+                                                                       uint32_t diag) {
+    // diag (QS_DIAG, timing experiments only; results are wrong when set): 1 = no global loads after the
+    // first group, 2 = no LDS commits after the first group, 4 = skip the compare/popcount work
     constexpr int NB = B + 1;
     constexpr bool WIDE = (B > 4) || (MODE == MODE_PARTIAL);           // LDS image holds words 4..7
     constexpr int kImg = WIDE ? kBsElems * 2 : kBsElems + kBsElems / 4; // uint4 slots per wave and buffer
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
     for (uint32_t g = 0; g < n_groups; ++g) {
         const Planes ab = ab_next;
         const uint4 *buf = stage[g & 1];
-        if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
+        if (g + 1 < n_groups && !(diag & 1u)) issue(P + (size_t)(g + 1) * npairs * 2);
         const Planes ac = lds_load<WIDE>(buf, colA, kBsElems);
         const Planes L1 = sub_biased<B>(ab, ac); // M[ab] - M[ac] + 2^B ; w[7] = present(a,b) & present(a,c)
         Planes L2;
@@ -744,6 +749,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
             const Planes bc = lds_load<WIDE>(buf, colB, kBsElems);
             L2 = sub_biased<B>(ab, bc);          // M[ab] - M[bc] + 2^B
         }
+        if (diag & 4u) c0[0] += L1.w[0]; else
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
             if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
                 }
             }
         }
-        if (g + 1 < n_groups) commit((g + 1) & 1);
+        if (g + 1 < n_groups && !(diag & 2u)) commit((g + 1) & 1);
     }
 
     if (!lane_valid) return;
@@ -793,10 +799,12 @@ hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const vo
     if (g.total_tiles == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
+    const char *de = getenv("QS_DIAG");
+    const uint32_t diag = de ? (uint32_t)atoi(de) : 0u;
 #define QS_BS(BB, M, CT)                                                                                            \
     hipLaunchKernelGGL((count_bitslice_kernel<BB, M, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, diag)
 #define QS_BS_M(BB, CT)                                                                                             \
     do {                                                                                                            \
         if (mode == MODE_BINARY_FULL) QS_BS(BB, MODE_BINARY_FULL, CT);                                              \
