@@ -683,21 +683,32 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
     const bool lane_valid = (a < b) && (b < c);
     const uint32_t pi = lane_valid ? (uint32_t)binom2(b) + a : 0u;
 
-    // staging map: element e = row * 16 + col; row 0: pair (x, c); row 1+j: pair (x, d0+j) MINUS pair (c, d0+j)
-    uint32_t src[kBsPerLane], sub[kBsPerLane];
+    // staging map. LDS slot = row * 16 + col; row 0: pair (x, c); row 1+j: pair (x, d0+j) MINUS pair (c, d0+j);
+    // col < 8: x = a0+col, else x = b0+col-8. An off-diagonal tile of the binary_full variant only ever reads
+    // row 0 at its a-columns (M[ac]) and rows 1..kDB at its b-columns (R of (b,d)): 72 of the 144 slots, so
+    // only those are loaded and written. Diagonal tiles (a and b from the same block) and the general
+    // variants (which also need M[bc] and R of (a,d)) stage all 144.
+    const bool half_stage = (MODE == MODE_BINARY_FULL) && (tl < n_off);
+    const uint32_t n_stage = half_stage ? (uint32_t)(kTA + kDB * kTB) : (uint32_t)kBsElems;
+    uint32_t src[kBsPerLane], sub[kBsPerLane], slot[kBsPerLane];
 #pragma unroll
     for (int s = 0; s < kBsPerLane; ++s) {
         const uint32_t e = lane + s * kWave;
-        uint32_t p = 0u, q = 0xFFFFFFFFu;
-        if (e < (uint32_t)kBsElems) {
-            const uint32_t row = e / kCols, col = e % kCols;
+        uint32_t p = 0u, q = 0xFFFFFFFFu, sl = 0u;
+        if (e < n_stage) {
+            uint32_t row, col;
+            if (half_stage) {
+                if (e < (uint32_t)kTA) { row = 0; col = e; }
+                else { row = 1 + (e - kTA) / kTB; col = kTA + (e - kTA) % kTB; }
+            } else { row = e / kCols; col = e % kCols; }
+            sl = row * kCols + col;
             const uint32_t x = col < (uint32_t)kTA ? a0 + col : b0 + (col - kTA);
             const uint32_t y = row == 0 ? c : d0 + (row - 1);
             const bool ok = x < c && y < d1 && (row == 0 || y > c);
             if (ok) p = (uint32_t)binom2(y) + x;
             if (row != 0) q = ok ? (uint32_t)binom2(y) + c : 0u;
         }
-        src[s] = p; sub[s] = q;
+        src[s] = p; sub[s] = q; slot[s] = sl;
     }
     const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
 
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
     auto issue = [&](const uint4 *Pg) {
 #pragma unroll
         for (int s = 0; s < kBsPerLane; ++s) {
-            if (lane + s * kWave < (uint32_t)kBsElems) {
+            if (lane + s * kWave < n_stage) {
                 xr[s] = load_planes<HI>(Pg + (size_t)src[s] * 2);
                 if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes<HI>(Pg + (size_t)sub[s] * 2);
             }
@@ -723,11 +734,10 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
     auto commit = [&](int bufi) {
 #pragma unroll
         for (int s = 0; s < kBsPerLane; ++s) {
-            const uint32_t e = lane + s * kWave;
-            if (e < (uint32_t)kBsElems) {
+            if (lane + s * kWave < n_stage) {
                 Planes x = xr[s];
                 if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]); // rows 1..kDB
-                lds_store<WIDE>(stage[bufi], e, kBsElems, x);
+                lds_store<WIDE>(stage[bufi], slot[s], kBsElems, x);
             }
         }
     };
