@@ -104,6 +104,13 @@ def main():
     n_words = (ctx.table_bytes + 3) // 4
     table = torch.zeros(n_words, dtype=torch.int32, device=dev)  # u16 tables all-reduce as packed words
     ctx.table_attach(table)
+    # N > 1: two tables, so that the RCCL all-reduce of step k's table (async, on RCCL's stream) overlaps
+    # the counting of step k+1 into the other one. Needs 2x table memory: only when it comfortably fits.
+    tables = [table]
+    if use_dist and 2 * ctx.table_bytes < 64 * (1 << 30):
+        tables.append(torch.zeros(n_words, dtype=torch.int32, device=dev))
+    pending = [None] * len(tables)
+    step_no = [0]
     hb = ctx.batch_upload(batch, with_nodes=(args.algo == "scatter"))  # inputs resident in HBM before the timed region
     algo = engine.QS_ALGO_GATHER if args.algo == "gather" else engine.QS_ALGO_SCATTER
 
@@ -111,13 +118,27 @@ def main():
     step_algo = algo | engine.QS_COUNT_OVERWRITE if args.algo == "gather" else algo
 
     def step():
+        i = step_no[0] % len(tables)
+        step_no[0] += 1
+        if pending[i] is not None:       # the all-reduce that last used this table must be done
+            pending[i].wait()
+            pending[i] = None
+        if len(tables) > 1:
+            ctx.table_attach(tables[i])
         if args.algo != "gather":
             ctx.table_clear()
         ctx.count_batch(hb, step_algo)
         if use_dist:
-            dist.all_reduce(table, op=dist.ReduceOp.SUM)
+            pending[i] = dist.all_reduce(tables[i], op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for i, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[i] = None
 
     def fence():
+        drain()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -142,6 +163,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    drain()
+    if len(tables) > 1:                  # measurements below run on one table without collectives
+        ctx.table_attach(table)
+        tables[:] = [table]
+        pending[:] = [None]
+    use_dist_saved, use_dist = use_dist, False
     # per-kernel durations: an extra, untimed pass that reads the HIP events after every launch
     for _ in range(max(3, min(args.steps, 10))):
         step()
@@ -208,7 +235,7 @@ def main():
             "distinct_trees": distinct,
             "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + (" + RCCL all-reduce of the table" if use_dist else ""),
+            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + (" + RCCL all-reduce of the table (async, overlapped with the next step through a second table)" if use_dist_saved else ""),
             "parity_tuple_sums_ok": parity,
             "parity_bitslice_equals_swar_impl": impl_match,
             "panel_kernel_ms": panel_ms,
@@ -222,7 +249,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": ("count_bitslice_kernel" if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
+            "kernel": (("count_bitslice2_kernel" if "x2/" in variant else "count_bitslice_kernel") if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
             "algorithmic_bytes_per_launch": m * nq * bytes_per_unit,
             "avg_launch_ms": count_ms,
             "note": "achieved = algorithmic RMW bytes of the reference formulation (8 B per tree x quartet) / kernel time; "
@@ -279,10 +306,16 @@ def main():
         except Exception as e:  # the baseline is reported, never required for the metric
             out["cpu_baseline"] = {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
-    print(json.dumps(out))
-    if use_dist:
+    if use_dist_saved:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON line must be the LAST line on stdout: RCCL prints a version banner through C stdio, which is
+    # block-buffered on a pipe and would otherwise be flushed after Python's line at exit
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out))
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -34,6 +34,8 @@ struct qs_ctx {
     // geometry
     uint32_t *dprefix = nullptr, *cprefix = nullptr;
     uint32_t n_dblk = 0, total_tiles = 0;
+    uint32_t *dprefix2 = nullptr, *cprefix2 = nullptr; // tiling of the two-a-column kernel
+    uint32_t total_tiles2 = 0;
     // workspace
     void *panel = nullptr;
     size_t panel_bytes = 0;
@@ -113,6 +115,19 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     if (hipMalloc(&c->dprefix, dp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix");
     if (hipMemcpy(c->cprefix, cp.data(), cp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix");
     if (hipMemcpy(c->dprefix, dp.data(), dp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix");
+    {   // the same for the 16x8 tiles of count_bitslice2_kernel
+        std::vector<uint32_t> cp2(n_taxa + 2, 0), dp2(c->n_dblk + 1, 0);
+        for (uint32_t cc = 2; cc <= n_taxa; ++cc) cp2[cc + 1] = cp2[cc] + bitslice2_tiles_for_c(cc);
+        for (uint32_t k = 0; k < c->n_dblk; ++k) {
+            uint32_t d0 = d_start + k * kDB, d1 = std::min(d0 + (uint32_t)kDB, d_hi);
+            dp2[k + 1] = dp2[k] + cp2[d1 - 1];
+        }
+        c->total_tiles2 = dp2[c->n_dblk];
+        if (hipMalloc(&c->cprefix2, cp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix2");
+        if (hipMalloc(&c->dprefix2, dp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix2");
+        if (hipMemcpy(c->cprefix2, cp2.data(), cp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix2");
+        if (hipMemcpy(c->dprefix2, dp2.data(), dp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix2");
+    }
     if (hipMalloc(&c->dev_flags, 16) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc flags");
     if (hipMemset(c->dev_flags, 0, 16) != hipSuccess) return cleanup(QS_ERR_HIP, "memset flags");
     for (int i = 0; i < 3; ++i)
@@ -128,6 +143,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->panel) (void)hipFree(c->panel);
     if (c->dprefix) (void)hipFree(c->dprefix);
     if (c->cprefix) (void)hipFree(c->cprefix);
+    if (c->dprefix2) (void)hipFree(c->dprefix2);
+    if (c->cprefix2) (void)hipFree(c->cprefix2);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
     for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -316,6 +333,9 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         // 256 MiB Infinity Cache while every wave streams through it (measured at 512 taxa: 1.8e13
         // quartets/s with a 260 MB panel, 1.35e13 with 1.3 GB). The table is read-modify-written once
         // per sub-batch, which is cheap next to the counting itself.
+        // binary_full batches use the kernel with two a-columns per lane (QS_BITSLICE_TILE=1 selects the plain one)
+        const char *tile_env = getenv("QS_BITSLICE_TILE");
+        const bool two_a = use_bitslice && mode == MODE_BINARY_FULL && !(tile_env && tile_env[0] == '1');
         int bits = 8;
         uint32_t tpc;            // trees per panel element
         size_t elem_bytes;       // bytes per (pair, element)
@@ -348,11 +368,15 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
             if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
-            if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+            if (use_bitslice && two_a) {
+                CountGeometry g2 = g;
+                g2.total_tiles = c->total_tiles2; g2.dprefix = c->dprefix2; g2.cprefix = c->cprefix2;
+                QS_HIP(c, launch_count_bitslice2(c->stream, g2, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+            } else if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }
         if (use_bitslice)
-            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + "/count_u" + std::to_string(c->count_bits);
+            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (two_a ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
         else
             c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {

@@ -803,6 +803,215 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
     }
 }
 
+// ---- binary_full variant with TWO a-columns per lane ---------------------------------------------
+// Same arithmetic; the tile is 16 a x 8 b: lane (ia, ib) owns a1 = 8*A1+ia, a2 = 8*A2+ia and b = 8*Bk+ib
+// (A1 < A2 < Bk are 8-blocks of ids below c; A2 may be absent). The staged R element of (b,d) is read
+// from LDS once and compared against both L(a1,b,c) and L(a2,b,c): LDS reads, staging loads and LDS
+// writes per quartet drop by ~40 %. Diagonal tiles keep the packing of count_bitslice_kernel (two
+// diagonal blocks per wave, one a per lane). Staged slots: row * 24 + col, cols 0..7 = block A1,
+// 8..15 = block A2, 16..23 = block Bk; an off-diagonal tile fills row 0 at cols 0..15 and rows 1..kDB at
+// cols 16..23 (80 elements), a diagonal tile rows 0..kDB at cols 0..15 (144).
+constexpr int kCols2 = 3 * kTA;
+constexpr int kBs2Slots = (1 + kDB) * kCols2;          // 216
+constexpr int kBs2PerLane = 3;                         // max(80, 144) / 64 rounded up
+
+uint32_t bitslice2_tiles_for_c(uint32_t c) {
+    const uint32_t T = (c + kTB - 1) / kTB;
+    return (T * T) / 4 + (T + 1) / 2; // pairs of a-blocks below every b-block + pairs of diagonal blocks
+}
+
+template <int B, typename CT>
+__global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const uint4 *__restrict__ P, uint32_t npairs,
+                                                                        uint32_t n_groups, uint32_t m_trees, uint32_t n,
+                                                                        uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
+                                                                        uint32_t n_dblk, uint32_t total_tiles,
+                                                                        const uint32_t *__restrict__ dprefix,
+                                                                        const uint32_t *__restrict__ cprefix,
+                                                                        CT *__restrict__ table,
+                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
+    constexpr int NB = B + 1;
+    constexpr bool WIDE = (B > 4);
+    constexpr bool HI = (B > 4);
+    constexpr int kImg = WIDE ? kBs2Slots * 2 : kBs2Slots + kBs2Slots / 4;
+    __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= total_tiles) return;
+    uint4(*stage)[kImg] = stage_all[wave];
+
+    // ---- tile decode (wave-uniform) ----
+    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
+    const uint32_t local = tile - dprefix[k];
+    const uint32_t d0 = d_lo + k * kDB;
+    const uint32_t d1 = min(d0 + (uint32_t)kDB, d_hi);
+    const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
+    const uint32_t T = (c + kTB - 1) / kTB, n_off = (T * T) / 4;
+    const uint32_t tl = local - cprefix[c];
+    const bool offdiag = tl < n_off;
+    uint32_t blk[3];                 // id block of column groups 0..7, 8..15, 16..23 (0xFFFFFFFF = absent)
+    uint32_t a1, a2, b, colA1, colA2, colB;
+    if (offdiag) {
+        // b-block Bk = largest k with floor(k*k/4) <= tl
+        uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f));
+        while ((Bk * Bk) / 4 > tl) --Bk;
+        while (((Bk + 1) * (Bk + 1)) / 4 <= tl) ++Bk;
+        const uint32_t j = tl - (Bk * Bk) / 4;
+        blk[0] = 2 * j; blk[1] = (2 * j + 1 < Bk) ? 2 * j + 1 : 0xFFFFFFFFu; blk[2] = Bk;
+        const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
+        colA1 = ia; colA2 = kTA + ia; colB = 2 * kTA + ib;
+        a1 = blk[0] * kTA + ia;
+        a2 = blk[1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : blk[1] * kTA + ia;
+        b = Bk * kTB + ib;
+    } else {
+        const uint32_t kd = tl - n_off;
+        blk[0] = 2 * kd; blk[1] = 2 * kd + 1; blk[2] = 0xFFFFFFFFu;
+        const uint32_t h = lane >> 5, q = lane & 31;
+        uint32_t ia = 0, ib = 1;
+        if (q < 28) unrank2(q, ia, ib);
+        colA1 = h * kTA + ia; colA2 = colA1; colB = h * kTA + ib;
+        a1 = blk[h] * kTA + ia; a2 = 0xFFFFFFFFu;
+        b = q < 28 ? blk[h] * kTA + ib : 0xFFFFFFFFu;
+    }
+    const bool has_a2 = offdiag && blk[1] != 0xFFFFFFFFu; // wave-uniform
+    const bool v1 = (a1 < b) && (b < c);
+    const bool v2 = has_a2 && (a2 < b) && (b < c);
+    const uint32_t pi1 = v1 ? (uint32_t)binom2(b) + a1 : 0u;
+    const uint32_t pi2 = v2 ? (uint32_t)binom2(b) + a2 : 0u;
+
+    const uint32_t n_stage = offdiag ? (uint32_t)(2 * kTA + kDB * kTB) : (uint32_t)((1 + kDB) * 2 * kTA);
+    uint32_t src[kBs2PerLane], sub[kBs2PerLane], slot[kBs2PerLane];
+#pragma unroll
+    for (int s = 0; s < kBs2PerLane; ++s) {
+        const uint32_t e = lane + s * kWave;
+        uint32_t p = 0u, q = 0xFFFFFFFFu, sl = 0u;
+        if (e < n_stage) {
+            uint32_t row, col;
+            if (offdiag) {
+                if (e < (uint32_t)(2 * kTA)) { row = 0; col = e; }
+                else { row = 1 + (e - 2 * kTA) / kTB; col = 2 * kTA + (e - 2 * kTA) % kTB; }
+            } else { row = e / (2 * kTA); col = e % (2 * kTA); }
+            sl = row * kCols2 + col;
+            const uint32_t bk = blk[col / kTA];
+            const uint32_t x = bk == 0xFFFFFFFFu ? 0xFFFFFFFFu : bk * kTA + (col % kTA);
+            const uint32_t y = row == 0 ? c : d0 + (row - 1);
+            const bool ok = x < c && y < d1 && (row == 0 || y > c);
+            if (ok) p = (uint32_t)binom2(y) + x;
+            if (row != 0) q = ok ? (uint32_t)binom2(y) + c : 0u;
+        }
+        src[s] = p; sub[s] = q; slot[s] = sl;
+    }
+    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
+
+    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB]; // counters of (a1,b) and (a2,b)
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
+
+    Planes xr[kBs2PerLane], yr[kBs2PerLane], ab1_next, ab2_next;
+    auto issue = [&](const uint4 *Pg) {
+#pragma unroll
+        for (int s = 0; s < kBs2PerLane; ++s) {
+            if (lane + s * kWave < n_stage) {
+                xr[s] = load_planes<HI>(Pg + (size_t)src[s] * 2);
+                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes<HI>(Pg + (size_t)sub[s] * 2);
+            }
+        }
+        ab1_next = load_planes<HI>(Pg + (size_t)pi1 * 2);
+        if (has_a2) ab2_next = load_planes<HI>(Pg + (size_t)pi2 * 2);
+    };
+    auto commit = [&](int bufi) {
+#pragma unroll
+        for (int s = 0; s < kBs2PerLane; ++s) {
+            if (lane + s * kWave < n_stage) {
+                Planes x = xr[s];
+                if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]);
+                lds_store<WIDE>(stage[bufi], slot[s], kBs2Slots, x);
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < kBs2PerLane; ++s)
+#pragma unroll
+        for (int k2 = 0; k2 < kBitWords; ++k2) { xr[s].w[k2] = 0; yr[s].w[k2] = 0; }
+#pragma unroll
+    for (int k2 = 0; k2 < kBitWords; ++k2) ab2_next.w[k2] = 0;
+    issue(P);
+    commit(0);
+
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const Planes ab1 = ab1_next, ab2 = ab2_next;
+        const uint4 *buf = stage[g & 1];
+        if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
+        const Planes L1 = sub_biased<B>(ab1, lds_load<WIDE>(buf, colA1, kBs2Slots));
+        Planes L2 = L1;
+        if (has_a2) L2 = sub_biased<B>(ab2, lds_load<WIDE>(buf, colA2, kBs2Slots));
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
+                const Planes Rb = lds_load<WIDE>(buf, (1 + j) * kCols2 + colB, kBs2Slots);
+                uint32_t gt, lt;
+                cmp_planes<NB>(L1, Rb, gt, lt);
+                popc_acc(gt, x0[j]);
+                popc_acc(lt, x1[j]);
+                if (has_a2) {
+                    uint32_t gt2, lt2;
+                    cmp_planes<NB>(L2, Rb, gt2, lt2);
+                    popc_acc(gt2, y0[j]);
+                    popc_acc(lt2, y1[j]);
+                }
+            }
+        }
+        if (g + 1 < n_groups) commit((g + 1) & 1);
+    }
+
+    const uint64_t rcb = binom3(c);
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) {
+        const uint32_t d = d0 + j;
+        if (d < d1 && d > c) {
+            const uint64_t base = binom4(d) + rcb - rank_lo;
+            if (v1) {
+                const uint64_t idx = (base + pi1) * 3;
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = m_trees - x0[j] - x1[j];
+                if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
+                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+                table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
+            }
+            if (v2) {
+                const uint64_t idx = (base + pi2) * 3;
+                uint32_t w0 = y0[j], w1 = y1[j], w2 = m_trees - y0[j] - y1[j];
+                if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
+                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+                table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
+            }
+        }
+    }
+}
+
+hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
+                                  uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
+                                  bool overwrite) {
+    if (g.total_tiles == 0) return hipSuccess;
+    const uint32_t npairs = (uint32_t)binom2(g.n);
+    dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
+#define QS_BS2(BB, CT)                                                                                              \
+    hipLaunchKernelGGL((count_bitslice2_kernel<BB, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,  \
+                       m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u)
+#define QS_BS2_B(CT)                                                                                                \
+    do {                                                                                                            \
+        if (depth_bits <= 4) QS_BS2(4, CT);                                                                         \
+        else if (depth_bits == 5) QS_BS2(5, CT);                                                                    \
+        else if (depth_bits == 6) QS_BS2(6, CT);                                                                    \
+        else QS_BS2(7, CT);                                                                                         \
+    } while (0)
+    if (count_bits == 32) QS_BS2_B(uint32_t); else QS_BS2_B(uint16_t);
+#undef QS_BS2_B
+#undef QS_BS2
+    return hipGetLastError();
+}
+
 hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                  uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                  bool overwrite) {

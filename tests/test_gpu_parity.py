@@ -64,9 +64,13 @@ CASES = [
 
 @pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES)
 @pytest.mark.parametrize("count_bits", [32, 16])
-@pytest.mark.parametrize("impl", ["bitslice", "swar"])
+@pytest.mark.parametrize("impl", ["bitslice", "bitslice1", "swar"])
 def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, rooted, seed, variant, count_bits, impl):
-    """Both gather implementations: bit-sliced (default) and the byte-SWAR one (fallback for deep trees)."""
+    """All gather implementations: bit-sliced (default; binary_full batches take the kernel with two a-columns
+    per lane, "bitslice1" forces the one-column kernel) and the byte-SWAR one (fallback for deep trees)."""
+    if impl == "bitslice1":
+        monkeypatch.setenv("QS_BITSLICE_TILE", "1")
+        impl = "bitslice"
     monkeypatch.setenv("QS_GATHER_IMPL", impl)
     ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
     ref = flatten.flatten_reference(ref_nw)
