@@ -10,6 +10,7 @@
 
 #include "../../../include/quartetscores_hip.h"
 #include "flatten.hpp"
+#include "ingest.hpp"
 #include "newick.hpp"
 
 #include <chrono>
@@ -20,6 +21,7 @@
 #include <limits>
 #include <memory>
 #include <sstream>
+#include <thread>
 #include <stdexcept>
 #include <tuple>
 #include <type_traits>
@@ -34,22 +36,19 @@ inline std::string slurp(const std::string &path) {
     return ss.str();
 }
 
-// Count the number of evaluation trees (QuartetScores.cpp:23-32). The reference parses the file once
-// just to count; here it is a scan for top-level ';'.
+// Count the number of evaluation trees (QuartetScores.cpp:23-32). The reference parses the whole file
+// just to count; here it is one scan for top-level ';' (ingest.hpp).
 inline size_t countEvalTrees(const std::string &evalTreesPath) {
-    std::string text = slurp(evalTreesPath);
-    NewickReader rd(text);
-    Tree t;
-    size_t m = 0;
-    while (rd.next(t)) ++m;
-    return m;
+    return split_trees(slurp(evalTreesPath)).size();
 }
 
 struct DeviceOptions {
     int device = 0;
     uint32_t algo = QS_ALGO_AUTO;
-    size_t batch_trees = 8192; // trees per qs_count_trees call
+    size_t batch_trees = 8192;   // trees per device batch
+    unsigned ingest_threads = 0; // host threads that parse + flatten (0 = hardware concurrency); the CLI's -t
     bool qp_exact64 = false;
+    std::string load_table, save_table; // count-table persistence
 };
 
 template <typename CINT> class QuartetCounterLookup {
@@ -90,34 +89,52 @@ private:
         for (size_t i = 0; i < ref_.leaf_node.size(); ++i) if (ref_.leaf_node[i] == node) return (uint16_t)i;
         throw std::out_of_range("not a leaf node");
     }
-    // QuartetCounterLookup.hpp:196-238: stream the evaluation trees, one batch resident at a time
+    // QuartetCounterLookup.hpp:196-238. One pass over the file: spans of trees are parsed + flattened by a
+    // thread pool, batch by batch, while the GPU counts the previous batch (qs_count_batch is asynchronous).
     void countQuartets(const std::string &evalTreesPath, size_t m, const DeviceOptions &opt) {
-        std::string text = slurp(evalTreesPath);
-        NewickReader rd(text);
-        Tree t;
-        BatchFlat b;
+        if (!opt.load_table.empty()) { // resume from a saved table instead of counting
+            std::string bytes = slurp(opt.load_table);
+            if (bytes.size() != qs_table_bytes(ctx_)) throw std::runtime_error("--load-table: size does not match this reference tree / counter width");
+            if (qs_table_upload(ctx_, bytes.data(), bytes.size()) != QS_OK) fail();
+            return;
+        }
+        const std::string text = slurp(evalTreesPath);
+        const auto spans = split_trees(text);
+        unsigned threads = opt.ingest_threads ? opt.ingest_threads : std::max(1u, std::thread::hardware_concurrency());
+        std::vector<qs_device_batch *> in_flight;
         unsigned progress = 1;
         const float onePercent = (float)m / 100;
-        size_t i = 0;
-        auto flush = [&]() {
-            if (b.n_trees == 0) return;
-            qs_tree_batch hb;
-            hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data();
-            hb.adj_depth = b.adj_depth.data(); hb.node_off = b.node_off.data(); hb.rng_off = b.rng_off.data();
-            hb.ranges = b.ranges.data();
-            if (qs_count_trees(ctx_, &hb, opt.algo) != QS_OK) fail();
-            b.clear();
-        };
-        while (rd.next(t)) {
-            flatten_append(t, ref_.name_to_id, b);
-            if (b.n_trees >= opt.batch_trees) flush();
-            if (i > progress * onePercent) { // QCL:230-233
-                std::cout << "Counting quartets... " << progress << "%" << std::endl;
-                progress++;
+        try {
+            for (size_t i0 = 0; i0 < spans.size(); i0 += opt.batch_trees) {
+                const size_t i1 = std::min(spans.size(), i0 + opt.batch_trees);
+                BatchFlat b = flatten_parallel(text, spans, i0, i1, ref_.name_to_id, threads);
+                qs_tree_batch hb;
+                hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data();
+                hb.adj_depth = b.adj_depth.data(); hb.node_off = b.node_off.data(); hb.rng_off = b.rng_off.data();
+                hb.ranges = b.ranges.data();
+                qs_device_batch *db = nullptr;
+                if (qs_batch_upload(ctx_, &hb, &db) != QS_OK) fail();  // synchronous copy: `b` may go away
+                in_flight.push_back(db);
+                if (qs_count_batch(ctx_, db, opt.algo) != QS_OK) fail(); // asynchronous
+                while ((float)i1 > progress * onePercent && progress <= 100) { // QCL:230-233
+                    std::cout << "Counting quartets... " << progress << "%" << std::endl;
+                    progress++;
+                }
             }
-            ++i;
+            if (qs_sync(ctx_) != QS_OK) fail();
+        } catch (...) {
+            (void)qs_sync(ctx_);
+            for (auto *db : in_flight) qs_batch_free(ctx_, db);
+            throw;
         }
-        flush();
+        for (auto *db : in_flight) qs_batch_free(ctx_, db);
+        if (!opt.save_table.empty()) {
+            std::string bytes(qs_table_bytes(ctx_), '\0');
+            if (qs_table_download(ctx_, &bytes[0], bytes.size()) != QS_OK) fail();
+            std::ofstream f(opt.save_table, std::ios::binary);
+            f.write(bytes.data(), (std::streamsize)bytes.size());
+            if (!f) throw std::runtime_error("cannot write " + opt.save_table);
+        }
     }
 };
 

@@ -4,8 +4,10 @@
 //   QuartetScores -r ref.nwk -e eval.nwk -o out.nwk [-q raw.txt] [-t N] [-v] [-s]
 //                 [--device N] [--algo gather|scatter] [--exact-qp]
 //
-// -t is accepted for compatibility (the GPU path has no host thread pool); -s/--savemem is accepted and
-// has no effect: the GPU table is always the compact C(n,4)x3 layout with semantic (1x) counts.
+// -t sets the number of host threads that parse + flatten the evaluation trees (the reference's OpenMP
+// threads counted quartets; here that happens on the GPU). -s/--savemem is accepted and has no effect: the
+// GPU table is always the compact C(n,4)x3 layout with semantic (1x) counts.
+// --save-table / --load-table write / read the raw count table (resume without recounting).
 #include "QuartetScoreComputer.hpp"
 
 #include <chrono>
@@ -32,12 +34,14 @@ void usage(std::ostream &os) {
           "   -e, --eval     Path to the evaluation trees\n"
           "   -o, --output   Path to the annotated newick output file (for lqic/qpic/eqpic scores)\n"
           "   -q, --qic      Path to the file where to write the raw QIC scores for each quartet\n"
-          "   -t, --threads  Maximum number of threads to use (accepted; the GPU path ignores it)\n"
+          "   -t, --threads  Maximum number of host threads for parsing the evaluation trees (0 = all)\n"
           "   -v, --verbose  Verbose mode\n"
           "   -s, --savemem  Consume less memory (accepted; the GPU table is always the compact one)\n"
           "   --device N     HIP device ordinal (default 0)\n"
           "   --algo A       gather (default) | scatter\n"
-          "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n";
+          "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
+          "   --save-table F write the count table to F after counting\n"
+          "   --load-table F read the count table from F instead of counting (-e is still needed for m)\n";
 }
 
 // returns 0 ok, 1 error (message printed like the reference prints TCLAP::ArgException), 2 exit quietly
@@ -64,6 +68,8 @@ int parse(int argc, char **argv, Args &a) {
             if (!(v = need(i, "--algo"))) return 1;
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
+        else if (f == "--save-table") { if (!(v = need(i, "--save-table"))) return 1; a.dev.save_table = v; }
+        else if (f == "--load-table") { if (!(v = need(i, "--load-table"))) return 1; a.dev.load_table = v; }
         else if (f == "--version") { std::cout << argv[0] << "  version: 1.0.1 (" << qs_version() << ")" << std::endl; return 2; }
         else if (f == "-h" || f == "--help") { usage(std::cout); return 2; }
         else { std::cerr << "ERROR: Couldn't find match for argument for arg " << f << std::endl; return 1; }
@@ -97,8 +103,7 @@ int main(int argc, char *argv[]) {
         std::cout << "ERROR: The specified output file already exists.\n";
         return 1;
     }
-    if (a.threads > 0)
-        std::cerr << "Note: -t has no effect, counting and scoring run on the GPU." << std::endl;
+    a.dev.ingest_threads = (unsigned)a.threads;
 
     try {
         std::string refText = slurp(a.ref);

@@ -39,6 +39,43 @@ def test_cli_argument_errors(d1_files, tmp_path):
     assert p.returncode == 0 and "1.0.1" in p.stdout
 
 
+def test_cpp_host_flattening_matches_python_host(tmp_path):
+    """quartetscores_amd/csrc/host (newick.hpp, flatten.hpp, ingest.hpp) hands the C-ABI the same arrays as
+    the Python host, with 1 and with many ingest threads, for binary / multifurcating / partial / rooted trees,
+    quoted labels, branch lengths and comments."""
+    import numpy as np
+    from quartetscores_amd import flatten, synth
+    dump = os.path.join(ROOT, "quartetscores_amd", "bin", "flatten_dump")
+    assert os.path.exists(dump)
+    n = 23
+    ref_nw = synth.reference_tree(n, 5)
+    trees = (synth.tree_set(n, 150, 6) + synth.tree_set(n, 60, 7, collapse=0.3, dropout=0.2)
+             + synth.tree_set(n, 40, 8, rooted=True) + ["((t0:0.1,'t1':2e-3)x:1,[c](t2,t3)[d],t4);", "(t5,t6);", "t7;"])
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_text("\n".join(trees) + "\n\n")
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    outs = []
+    for threads in ("1", "7"):
+        p = subprocess.run([dump, str(r), str(e), threads], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        d = {ln.split(" ", 1)[0]: ln.split(" ")[1:] for ln in p.stdout.strip().split("\n")}
+        outs.append(p.stdout)
+        assert d["names"] == ref.names
+        assert [int(x) for x in d["parent"]] == list(ref.parent)
+        assert [int(x) for x in d["leaf_node"]] == list(ref.leaf_node)
+        assert int(d["n_trees"][0]) == batch.n_trees == len(trees)
+        for key, arr in (("leaf_off", batch.leaf_off), ("leaf_ids", batch.leaf_ids), ("adj_depth", batch.adj_depth),
+                         ("node_off", batch.node_off), ("rng_off", batch.rng_off), ("ranges", batch.ranges)):
+            assert [int(x) for x in d.get(key, [])] == [int(x) for x in arr], key
+    assert outs[0] == outs[1]  # the threaded ingest keeps file order
+    bad = tmp_path / "bad.nwk"
+    bad.write_text("\n".join(trees[:70]) + "\n((t0,t1),(t2,zzz),(t3,t4));\n")
+    p = subprocess.run([dump, str(r), str(bad), "4"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "unknown taxon 'zzz'" in p.stderr and "tree 70" in p.stderr
+
+
 def test_cli_fails_loudly_without_gpu(d1_files, tmp_path):
     import torch
     if torch.cuda.is_available():
@@ -80,8 +117,15 @@ def test_cli_end_to_end_matches_oracle(d1_files, tmp_path, golden):
             d[frozenset([frozenset(l.split(",")), frozenset(rr.split(","))])] = val
         return d
     assert canon(str(raw)) == canon(str(ora_raw)) and len(canon(str(raw))) == 70
+    # table persistence: save after counting, reload instead of counting -> the same annotated tree
+    tab = tmp_path / "table.bin"
+    out2, out3 = tmp_path / "o2.nwk", tmp_path / "o3.nwk"
+    p = run("-r", r, "-e", e, "-o", str(out2), "-t", "3", "--save-table", str(tab))
+    assert p.returncode == 0 and tab.stat().st_size == 70 * 3 * 2
+    p = run("-r", r, "-e", e, "-o", str(out3), "--load-table", str(tab))
+    assert p.returncode == 0 and out3.read_text() == out2.read_text() == text
     # unknown taxon -> error exit, like the reference's uncaught std::out_of_range
     bad = tmp_path / "bad.nwk"
     bad.write_text(golden["D6"]["bad_tree"] + "\n")
-    p = run("-r", r, "-e", str(bad), "-o", str(tmp_path / "o2.nwk"))
+    p = run("-r", r, "-e", str(bad), "-o", str(tmp_path / "o4.nwk"))
     assert p.returncode == 1 and "unknown taxon" in p.stderr

@@ -96,6 +96,59 @@ def test_scatter_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, va
         assert (T.astype(np.uint64) == o.counts()).all()
 
 
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 9, 15, 17])
+@pytest.mark.parametrize("impl", ["bitslice", "bitslice1", "swar", "scatter"])
+def test_tiny_and_odd_taxon_counts(eng, monkeypatch, n, impl):
+    """Edge geometry: fewer taxa than one tile, n not a multiple of the tile or d-block size, m = 1."""
+    algo = eng.QS_ALGO_GATHER
+    if impl == "scatter":
+        algo = eng.QS_ALGO_SCATTER
+    elif impl == "bitslice1":
+        monkeypatch.setenv("QS_BITSLICE_TILE", "1")
+    elif impl == "swar":
+        monkeypatch.setenv("QS_GATHER_IMPL", "swar")
+    for m, kw in ((1, {}), (33, {}), (21, dict(collapse=0.3)), (19, dict(dropout=0.3))):
+        ref_nw, trees = make_case(n, m, 60 + n, **kw)
+        ref = flatten.flatten_reference(ref_nw)
+        batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+        _, T = gpu_table(eng, ref, batch, 32, algo=algo)
+        assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all(), (n, m, kw)
+
+
+def test_degenerate_batches(eng):
+    """Empty batch, trees with fewer than four leaves, a tree that is a single leaf."""
+    ref_nw = synth.reference_tree(10, 77)
+    ref = flatten.flatten_reference(ref_nw)
+    ctx = eng.Context(10, 32)
+    ctx.table_alloc()
+    ctx.count_trees(flatten.flatten_eval_trees([], ref.name_to_id))
+    assert ctx.trees_counted == 0
+    trees = ["(t0,t1,t2);", "(t3,t4);", "t5;", "((t0,t1),(t2,t3),t4);"] + synth.tree_set(10, 3, 78)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx.count_trees(batch)
+    T = ctx.table_download()
+    o = oracle_counts(ref_nw, [t for t in trees if t.count(",") >= 1])  # the oracle's parser needs >= 2 leaves
+    assert (T.astype(np.uint64) == o.counts()).all()
+    assert ctx.trees_counted == len(trees)
+
+
+def test_binary_batches_on_table_shards(eng):
+    """The two-a-column kernel with d_lo > 0 / d_hi < n and 16-bit cells."""
+    n, m = 45, 40
+    ref_nw, trees = make_case(n, m, 71)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    full = oracle_counts(ref_nw, trees).counts()
+    for d_lo, d_hi in ((0, 17), (17, 31), (31, 45), (3, 4), (44, 45)):
+        ctx = eng.Context(n, 16, d_lo=d_lo, d_hi=d_hi)
+        ctx.table_alloc()
+        ctx.count_trees(batch)
+        assert "x2" in ctx.last_count_variant()
+        T = ctx.table_download()
+        r0, r1 = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
+        assert T.shape[0] == r1 - r0 and (T.astype(np.uint64) == full[r0:r1]).all(), (d_lo, d_hi)
+
+
 def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     n = 96
     ref_nw = synth.reference_tree(n, 9)
