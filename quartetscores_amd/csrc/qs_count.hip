@@ -31,7 +31,9 @@
 #include "qs_common.hpp"
 #include "qs_internal.hpp"
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace qs {
 
@@ -564,6 +566,11 @@ template <bool HI> __device__ __forceinline__ Planes load_planes(const uint4 *p)
     else { r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0; }
     return r;
 }
+// uniform base + 32-bit per-lane byte offset: lets hipcc use the SGPR-base addressing mode of global_load
+// instead of 64-bit per-lane pointer arithmetic
+template <bool HI> __device__ __forceinline__ Planes load_planes_off(const char *base, uint32_t byte_off) {
+    return load_planes<HI>(reinterpret_cast<const uint4 *>(base + byte_off));
+}
 // LDS image: words 0..3 of element e at buf[e], words 4..7 at buf[kBsElems + e] (consecutive lanes ->
 // consecutive 16-byte slots: no bank conflicts)
 // WIDE = false: only word 4 of the upper half is live (B <= 4, no presence plane): it is kept in a
@@ -820,7 +827,17 @@ uint32_t bitslice2_tiles_for_c(uint32_t c) {
     return (T * T) / 4 + (T + 1) / 2; // pairs of a-blocks below every b-block + pairs of diagonal blocks
 }
 
-template <int B, typename CT>
+// in-kernel stamps (diagnostic build only, QS_STAMP=<file>): shader-clock cycles per section, summed per wave
+#define QS_STAMP_T(t)                                                                                     \
+    do {                                                                                                  \
+        if (STAMP) {                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");                    \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
+    } while (0)
+
+template <int B, typename CT, bool STAMP>
 __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees, uint32_t n,
                                                                         uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
@@ -828,10 +845,14 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
                                                                         const uint32_t *__restrict__ dprefix,
                                                                         const uint32_t *__restrict__ cprefix,
                                                                         CT *__restrict__ table,
-                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
+                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
+                                                                        unsigned long long *__restrict__ stamps) {
     constexpr int NB = B + 1;
     constexpr bool WIDE = (B > 4);
     constexpr bool HI = (B > 4);
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tb = 0, te = 0;
+    unsigned long long acc_issue = 0, acc_l = 0, acc_slots = 0, acc_commit = 0;
+    QS_STAMP_T(tb);
     constexpr int kImg = WIDE ? kBs2Slots * 2 : kBs2Slots + kBs2Slots / 4;
     __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
 
@@ -909,16 +930,22 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
     for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
 
     Planes xr[kBs2PerLane], yr[kBs2PerLane], ab1_next, ab2_next;
+    // byte offsets inside one tree group of the panel (a group is npairs * 32 bytes <= 17 MB at 1024 taxa)
+    uint32_t xoff[kBs2PerLane], yoff[kBs2PerLane];
+#pragma unroll
+    for (int s = 0; s < kBs2PerLane; ++s) { xoff[s] = src[s] * 32u; yoff[s] = sub[s] == 0xFFFFFFFFu ? 0u : sub[s] * 32u; }
+    const uint32_t ab1off = pi1 * 32u, ab2off = pi2 * 32u;
     auto issue = [&](const uint4 *Pg) {
+        const char *base = reinterpret_cast<const char *>(Pg);
 #pragma unroll
         for (int s = 0; s < kBs2PerLane; ++s) {
             if (lane + s * kWave < n_stage) {
-                xr[s] = load_planes<HI>(Pg + (size_t)src[s] * 2);
-                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes<HI>(Pg + (size_t)sub[s] * 2);
+                xr[s] = load_planes_off<HI>(base, xoff[s]);
+                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes_off<HI>(base, yoff[s]);
             }
         }
-        ab1_next = load_planes<HI>(Pg + (size_t)pi1 * 2);
-        if (has_a2) ab2_next = load_planes<HI>(Pg + (size_t)pi2 * 2);
+        ab1_next = load_planes_off<HI>(base, ab1off);
+        if (has_a2) ab2_next = load_planes_off<HI>(base, ab2off);
     };
     auto commit = [&](int bufi) {
 #pragma unroll
@@ -939,17 +966,27 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
     issue(P);
     commit(0);
 
+    unsigned long long tl0 = 0;
+    QS_STAMP_T(tl0);
     for (uint32_t g = 0; g < n_groups; ++g) {
+        QS_STAMP_T(t0);
         const Planes ab1 = ab1_next, ab2 = ab2_next;
         const uint4 *buf = stage[g & 1];
         if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
+        QS_STAMP_T(t1);
         const Planes L1 = sub_biased<B>(ab1, lds_load<WIDE>(buf, colA1, kBs2Slots));
         Planes L2 = L1;
         if (has_a2) L2 = sub_biased<B>(ab2, lds_load<WIDE>(buf, colA2, kBs2Slots));
+        QS_STAMP_T(t2);
+        // the R element of slot j+1 is requested from LDS before slot j is computed (rows of slots outside
+        // [jlo, jhi) hold don't-care data, reading them is harmless). Requesting all kDB up front was slower:
+        // +35 VGPRs, 3 instead of 4 waves per SIMD.
+        Planes Rnext = lds_load<WIDE>(buf, kCols2 + colB, kBs2Slots);
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
+            const Planes Rb = Rnext;
+            if (j + 1 < kDB) Rnext = lds_load<WIDE>(buf, (2 + j) * kCols2 + colB, kBs2Slots);
             if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
-                const Planes Rb = lds_load<WIDE>(buf, (1 + j) * kCols2 + colB, kBs2Slots);
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
                 popc_acc(gt, x0[j]);
@@ -962,8 +999,13 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
                 }
             }
         }
+        QS_STAMP_T(t3);
         if (g + 1 < n_groups) commit((g + 1) & 1);
+        QS_STAMP_T(t4);
+        if (STAMP) { acc_issue += t1 - t0; acc_l += t2 - t1; acc_slots += t3 - t2; acc_commit += t4 - t3; }
     }
+    unsigned long long tl1 = 0;
+    QS_STAMP_T(tl1);
 
     const uint64_t rcb = binom3(c);
 #pragma unroll
@@ -987,6 +1029,13 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
             }
         }
     }
+    if (STAMP) {
+        QS_STAMP_T(te);
+        if (lane == 0) {
+            unsigned long long *o = stamps + (size_t)tile * 8;
+            o[0] = tl0 - tb; o[1] = acc_issue; o[2] = acc_l; o[3] = acc_slots; o[4] = acc_commit; o[5] = te - tl1; o[6] = te - tb; o[7] = n_groups;
+        }
+    }
 }
 
 hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
@@ -995,10 +1044,34 @@ hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const v
     if (g.total_tiles == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
+    // QS_STAMP=<file>: run the stamped diagnostic instance once and append the per-section cycle shares
+    const char *stamp_path = getenv("QS_STAMP");
+    if (stamp_path && count_bits == 32 && depth_bits <= 4) {
+        unsigned long long *dst = nullptr;
+        const size_t nb = (size_t)g.total_tiles * 8 * sizeof(unsigned long long);
+        if (hipMalloc(&dst, nb) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(dst, 0, nb, s);
+        hipLaunchKernelGGL((count_bitslice2_kernel<4, uint32_t, true>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,
+                           m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,
+                           (uint32_t *)table, overflow_flag, overwrite ? 1u : 0u, dst);
+        std::vector<unsigned long long> h((size_t)g.total_tiles * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), dst, nb, hipMemcpyDeviceToHost);
+        (void)hipFree(dst);
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t t = 0; t < g.total_tiles; ++t) for (int k2 = 0; k2 < 8; ++k2) sum[k2] += (double)h[t * 8 + k2];
+        if (FILE *f = fopen(stamp_path, "a")) {
+            fprintf(f, "tiles %u groups %.0f | cycles per wave: prologue %.0f  issue %.0f  L %.0f  slots %.0f  commit %.0f  epilogue %.0f  total %.0f\n",
+                    g.total_tiles, sum[7] / g.total_tiles, sum[0] / g.total_tiles, sum[1] / g.total_tiles, sum[2] / g.total_tiles,
+                    sum[3] / g.total_tiles, sum[4] / g.total_tiles, sum[5] / g.total_tiles, sum[6] / g.total_tiles);
+            fclose(f);
+        }
+        return hipGetLastError();
+    }
 #define QS_BS2(BB, CT)                                                                                              \
-    hipLaunchKernelGGL((count_bitslice2_kernel<BB, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,  \
+    hipLaunchKernelGGL((count_bitslice2_kernel<BB, CT, false>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,  \
                        m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, (unsigned long long *)nullptr)
 #define QS_BS2_B(CT)                                                                                                \
     do {                                                                                                            \
         if (depth_bits <= 4) QS_BS2(4, CT);                                                                         \
