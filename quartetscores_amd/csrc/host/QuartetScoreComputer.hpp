@@ -191,37 +191,69 @@ public:
     std::vector<double> getEQPICScores() { return EQPICScores; }
 
     // QuartetScoreComputer.hpp:623-690: "(a,b|c,d): qic" per quartet resolved in the reference tree.
+    // The GPU classifies and looks up a chunk of ranks (qs_raw_qic); the host formats the chunk with all
+    // ingest threads into per-thread buffers and writes them in order (the reference
+    // formats C(n,4) lines on one thread). Line order = table rank order; the reference's order is its
+    // Euler-tour loop order, the set of lines is the same.
     void printRawQICScores(Tree const &refTree, const std::string &rawPath) {
-        std::ofstream outfile(rawPath);
+        std::ofstream outfile(rawPath, std::ios::binary);
         const RefFlat &rf = quartetCounterLookup->reference();
         qs_ctx *ctx = quartetCounterLookup->context();
         qs_ref_tree rt;
         rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
         rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
-        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 20;
+        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 22;
         std::vector<uint8_t> topo(chunk);
         std::vector<uint64_t> q(chunk * 3);
-        // ranks in order: d outermost ... a innermost
-        uint64_t r = 0;
-        uint32_t a = 0, b = 1, c = 2, d = 3;
-        const uint32_t n = rt.n_taxa;
-        while (r < total) {
+        const unsigned threads = std::max(1u, raw_threads ? raw_threads : std::thread::hardware_concurrency());
+        std::vector<std::string> bufs(threads);
+        for (uint64_t r = 0; r < total; r += chunk) {
             const uint64_t nq = std::min(chunk, total - r);
             if (qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-            for (uint64_t i = 0; i < nq; ++i) {
-                if (topo[i] != 255) {
-                    const std::string &A = rf.names[a], &B = rf.names[b], &C = rf.names[c], &D = rf.names[d];
-                    double qic = log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
-                    if (topo[i] == 0) outfile << "(" << A << "," << B << "|" << C << "," << D << "): " << qic << "\n";
-                    else outfile << "(" << A << "," << D << "|" << B << "," << C << "): " << qic << "\n";
+            auto work = [&](unsigned w) {
+                const uint64_t lo = nq * w / threads, hi = nq * (w + 1) / threads;
+                std::string &out = bufs[w];
+                out.clear();
+                uint32_t s0, s1, s2, s3;
+                unrank(r + lo, s0, s1, s2, s3);
+                char num[64];
+                for (uint64_t i = lo; i < hi; ++i) {
+                    if (topo[i] != 255) {
+                        const std::string &A = rf.names[s0], &B = rf.names[s1], &C = rf.names[s2], &D = rf.names[s3];
+                        // operator<<(double) with default precision == "%g"
+                        snprintf(num, sizeof num, "%g", log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]));
+                        out += '(';
+                        if (topo[i] == 0) { out += A; out += ','; out += B; out += '|'; out += C; out += ','; out += D; }
+                        else { out += A; out += ','; out += D; out += '|'; out += B; out += ','; out += C; }
+                        out += "): "; out += num; out += '\n';
+                    }
+                    if (++s0 == s1) { s0 = 0; if (++s1 == s2) { s1 = 1; if (++s2 == s3) { s2 = 2; ++s3; } } } // next rank
                 }
-                // next 4-set in rank order
-                if (++a == b) { a = 0; if (++b == c) { b = 1; if (++c == d) { c = 2; ++d; } } }
+            };
+            if (threads == 1) work(0);
+            else {
+                std::vector<std::thread> pool;
+                for (unsigned w = 0; w < threads; ++w) pool.emplace_back(work, w);
+                for (auto &th : pool) th.join();
             }
-            r += nq;
+            for (auto &b : bufs) outfile.write(b.data(), (std::streamsize)b.size());
         }
-        (void)n;
         outfile.close();
+    }
+    unsigned raw_threads = 0; // threads that format the -q file (0 = hardware concurrency)
+
+    // rank -> sorted ids (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0)
+    static void unrank(uint64_t r, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3) {
+        auto c4 = [](uint64_t x) { return x < 4 ? 0 : x * (x - 1) * (x - 2) * (x - 3) / 24; };
+        auto c3 = [](uint64_t x) { return x < 3 ? 0 : x * (x - 1) * (x - 2) / 6; };
+        auto c2 = [](uint64_t x) { return x * (x - 1) / 2; };
+        uint64_t d = 3; while (c4(d + 1) <= r) ++d;
+        r -= c4(d);
+        uint64_t c = 2; while (c3(c + 1) <= r) ++c;
+        r -= c3(c);
+        uint64_t b = 1; while (c2(b + 1) <= r) ++b;
+        r -= c2(b);
+        s0 = (uint32_t)r; s1 = (uint32_t)b; s2 = (uint32_t)c; s3 = (uint32_t)d;
     }
 
     // QuartetScoreComputer.hpp:135-159 with the host libm

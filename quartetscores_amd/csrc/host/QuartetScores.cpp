@@ -86,6 +86,7 @@ void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double>
     lqic = qsc.getLQICScores();
     qpic = qsc.getQPICScores();
     eqpic = qsc.getEQPICScores();
+    qsc.raw_threads = a.dev.ingest_threads;
     if (!a.raw.empty()) qsc.printRawQICScores(referenceTree, a.raw);
 }
 
