@@ -36,6 +36,8 @@ struct qs_ctx {
     uint32_t n_dblk = 0, total_tiles = 0;
     uint32_t *dprefix2 = nullptr, *cprefix2 = nullptr; // tiling of the two-a-column kernel
     uint32_t total_tiles2 = 0;
+    uint32_t *gprefix = nullptr, *csuffix = nullptr;   // its group-major order (large n)
+    uint32_t n_groups_off = 0, n_groups = 0;
     // workspace
     void *panel = nullptr;
     size_t panel_bytes = 0;
@@ -127,6 +129,44 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
         if (hipMalloc(&c->dprefix2, dp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix2");
         if (hipMemcpy(c->cprefix2, cp2.data(), cp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix2");
         if (hipMemcpy(c->dprefix2, dp2.data(), dp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix2");
+        // group-major order of the same tile set: group = (b-block, a-pair) or a pair of diagonal blocks;
+        // its tiles are all (c, d-block) with c >= cmin(group) and some d > c in the block
+        if (c->n_dblk > 0 && d_hi >= 4) {
+            const uint32_t c_max = d_hi - 2;
+            std::vector<uint32_t> S(n_taxa + 2, 0); // S[c] = sum_{c' >= c} ndblk(c')
+            for (uint32_t cc = c_max; cc >= 2; --cc) {
+                const uint32_t fk = cc + 2 > d_start + kDB ? (cc + 2 - d_start - kDB + kDB - 1) / kDB : 0u;
+                const uint32_t nd = fk < c->n_dblk ? c->n_dblk - fk : 0u;
+                S[cc] = S[cc + 1] + nd;
+            }
+            S[1] = S[0] = S[2];
+            const uint32_t Tmax = (c_max + 7) / 8; // 8-blocks of ids below the largest c
+            const uint32_t n_off = (Tmax * Tmax) / 4, n_diag = (Tmax + 1) / 2;
+            std::vector<uint32_t> gp(n_off + n_diag + 1, 0);
+            uint64_t acc = 0;
+            uint32_t gi = 0;
+            for (uint32_t Bk = 1; Bk < Tmax; ++Bk)
+                for (uint32_t j = 0; j < (Bk + 1) / 2; ++j) {
+                    const uint32_t cmin = std::max(2u, 8 * Bk + 1);
+                    gp[gi++] = (uint32_t)acc;
+                    acc += cmin <= c_max ? S[cmin] : 0u;
+                }
+            for (uint32_t kd = 0; kd < n_diag; ++kd) {
+                const uint32_t cmin = std::max(2u, 16 * kd + 1);
+                gp[gi++] = (uint32_t)acc;
+                acc += cmin <= c_max ? S[cmin] : 0u;
+            }
+            gp[gi] = (uint32_t)acc;
+            if (gi == n_off + n_diag && acc == c->total_tiles2) { // the two enumerations cover the same tile set
+                c->n_groups_off = n_off; c->n_groups = gi;
+                if (hipMalloc(&c->gprefix, gp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc gprefix");
+                if (hipMalloc(&c->csuffix, S.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc csuffix");
+                if (hipMemcpy(c->gprefix, gp.data(), gp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy gprefix");
+                if (hipMemcpy(c->csuffix, S.data(), S.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy csuffix");
+            } else {
+                return cleanup(QS_ERR_STATE, "internal: group-major tile count " + std::to_string(acc) + " != " + std::to_string(c->total_tiles2));
+            }
+        }
     }
     if (hipMalloc(&c->dev_flags, 16) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc flags");
     if (hipMemset(c->dev_flags, 0, 16) != hipSuccess) return cleanup(QS_ERR_HIP, "memset flags");
@@ -145,6 +185,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->cprefix) (void)hipFree(c->cprefix);
     if (c->dprefix2) (void)hipFree(c->dprefix2);
     if (c->cprefix2) (void)hipFree(c->cprefix2);
+    if (c->gprefix) (void)hipFree(c->gprefix);
+    if (c->csuffix) (void)hipFree(c->csuffix);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
     for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -371,6 +413,13 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (use_bitslice && two_a) {
                 CountGeometry g2 = g;
                 g2.total_tiles = c->total_tiles2; g2.dprefix = c->dprefix2; g2.cprefix = c->cprefix2;
+                // QS_TILE_ORDER=group selects the group-major order (meant to reuse the private M[ab] elements in L2).
+                // Measured at 512 taxa x 10000 trees: 0.900 s vs 0.867 s for the plain order, so it stays opt-in.
+                const char *oe = getenv("QS_TILE_ORDER");
+                const bool group_major = oe && std::string(oe) == "group";
+                if (group_major && c->n_groups) {
+                    g2.n_groups_off = c->n_groups_off; g2.n_groups = c->n_groups; g2.gprefix = c->gprefix; g2.csuffix = c->csuffix;
+                }
                 QS_HIP(c, launch_count_bitslice2(c->stream, g2, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             } else if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));

@@ -566,6 +566,35 @@ template <bool HI> __device__ __forceinline__ Planes load_planes(const uint4 *p)
     else { r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0; }
     return r;
 }
+// NW = number of leading words of the 8-word panel element that are live (4..8): loads exactly those
+template <int NW> __device__ __forceinline__ Planes load_planes_nw(const char *base, uint32_t byte_off) {
+    Planes r;
+    const uint4 lo = *reinterpret_cast<const uint4 *>(base + byte_off);
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+    if (NW == 5) r.w[4] = *reinterpret_cast<const uint32_t *>(base + byte_off + 16);
+    else if (NW == 6) { const uint2 h = *reinterpret_cast<const uint2 *>(base + byte_off + 16); r.w[4] = h.x; r.w[5] = h.y; }
+    else if (NW >= 7) { const uint4 h = *reinterpret_cast<const uint4 *>(base + byte_off + 16); r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
+    return r;
+}
+// LDS image with HW (1, 2 or 4) upper words per slot: words 0..3 at buf[e], the upper words in an array
+// of HW-word records behind the `stride` 16-byte slots
+template <int HW> __device__ __forceinline__ Planes lds_load_hw(const uint4 *buf, uint32_t e, int stride) {
+    const uint4 lo = buf[e];
+    Planes r;
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+    if (HW == 1) r.w[4] = reinterpret_cast<const uint32_t *>(buf + stride)[e];
+    else if (HW == 2) { const uint2 h = reinterpret_cast<const uint2 *>(buf + stride)[e]; r.w[4] = h.x; r.w[5] = h.y; }
+    else { const uint4 h = buf[stride + e]; r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
+    return r;
+}
+template <int HW> __device__ __forceinline__ void lds_store_hw(uint4 *buf, uint32_t e, int stride, const Planes &r) {
+    buf[e] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+    if (HW == 1) reinterpret_cast<uint32_t *>(buf + stride)[e] = r.w[4];
+    else if (HW == 2) reinterpret_cast<uint2 *>(buf + stride)[e] = make_uint2(r.w[4], r.w[5]);
+    else buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+}
 // uniform base + 32-bit per-lane byte offset: lets hipcc use the SGPR-base addressing mode of global_load
 // instead of 64-bit per-lane pointer arithmetic
 template <bool HI> __device__ __forceinline__ Planes load_planes_off(const char *base, uint32_t byte_off) {
@@ -844,32 +873,75 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
                                                                         uint32_t n_dblk, uint32_t total_tiles,
                                                                         const uint32_t *__restrict__ dprefix,
                                                                         const uint32_t *__restrict__ cprefix,
+                                                                        uint32_t n_groups_off, uint32_t n_groups_all,
+                                                                        const uint32_t *__restrict__ gprefix,
+                                                                        const uint32_t *__restrict__ csuffix,
                                                                         CT *__restrict__ table,
                                                                         uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
                                                                         unsigned long long *__restrict__ stamps) {
     constexpr int NB = B + 1;
-    constexpr bool WIDE = (B > 4);
-    constexpr bool HI = (B > 4);
+    constexpr int NW = B < 4 ? 4 : B;                                  // live words of a raw panel element (planes of M)
+    constexpr int HW = NB <= 5 ? 1 : (NB == 6 ? 2 : 4);                // upper words of an LDS slot (R has B+1 planes)
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tb = 0, te = 0;
     unsigned long long acc_issue = 0, acc_l = 0, acc_slots = 0, acc_commit = 0;
     QS_STAMP_T(tb);
-    constexpr int kImg = WIDE ? kBs2Slots * 2 : kBs2Slots + kBs2Slots / 4;
+    constexpr int kImg = kBs2Slots + (kBs2Slots * HW + 3) / 4;         // uint4 slots per wave and buffer
     __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
-    if (tile >= total_tiles) return;
     uint4(*stage)[kImg] = stage_all[wave];
 
     // ---- tile decode (wave-uniform) ----
-    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
-    const uint32_t local = tile - dprefix[k];
-    const uint32_t d0 = d_lo + k * kDB;
-    const uint32_t d1 = min(d0 + (uint32_t)kDB, d_hi);
-    const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
-    const uint32_t T = (c + kTB - 1) / kTB, n_off = (T * T) / 4;
-    const uint32_t tl = local - cprefix[c];
+    uint32_t tile, k, c, d0, d1, tl, n_off;
+    if (n_groups_all == 0) {
+        // order (d-block, c, tile): consecutive workgroups sweep the (a,b) tiles of one (d-block, c)
+        tile = blockIdx.x * kWavesPerBlock + wave;
+        if (tile >= total_tiles) return;
+        k = upper_bound_le(dprefix, 0, n_dblk, tile);
+        const uint32_t local = tile - dprefix[k];
+        d0 = d_lo + k * kDB;
+        d1 = min(d0 + (uint32_t)kDB, d_hi);
+        c = upper_bound_le(cprefix, 2, d1 - 1, local);
+        const uint32_t T = (c + kTB - 1) / kTB;
+        n_off = (T * T) / 4;
+        tl = local - cprefix[c];
+    } else {
+        // GROUP-MAJOR order for large n: the slowest index is the (b-block, a-pair) group, whose private
+        // M[ab] elements are 60 % of a wave's panel traffic; all (c, d-block) combinations of one group
+        // follow each other. Workgroups with the same blockIdx % 8 share an XCD (observed dispatch
+        // rule, used for speed only), so the logical tile list is cut into 8 contiguous parts, one per XCD:
+        // the ~500 waves resident on an XCD then work on the same group and hit its M[ab] elements in L2.
+        const uint32_t nb = gridDim.x, bx = blockIdx.x;
+        const uint32_t q8 = nb / 8, r8 = nb % 8, xcd = bx % 8, y = bx / 8;
+        const uint32_t lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + y; // bijective
+        tile = lb * kWavesPerBlock + wave;
+        if (tile >= total_tiles) return;
+        const uint32_t g = upper_bound_le(gprefix, 0, n_groups_all, tile);
+        const uint32_t qq = tile - gprefix[g];
+        uint32_t cmin;
+        if (g < n_groups_off) {
+            uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)g + 1.0f));
+            while ((Bk * Bk) / 4 > g) --Bk;
+            while (((Bk + 1) * (Bk + 1)) / 4 <= g) ++Bk;
+            cmin = max(2u, kTB * Bk + 1);
+        } else {
+            cmin = max(2u, 2 * kTA * (g - n_groups_off) + 1);
+        }
+        // combos are ordered by c ascending, then d-block: offset(c) = S[cmin] - S[c]
+        const uint32_t s0 = csuffix[cmin];
+        uint32_t lo = cmin, hi = d_hi - 1; // largest c in [cmin, d_hi-2] with S[cmin] - S[c] <= qq
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s0 - csuffix[mid] <= qq) lo = mid; else hi = mid; }
+        c = lo;
+        const uint32_t dstart = d_lo; // first d of d-block 0 (the launcher passes max(shard d_lo, 3))
+        const uint32_t fk = c + 2 > dstart + kDB ? (c + 2 - dstart - kDB + kDB - 1) / kDB : 0u; // first d-block with some d > c
+        k = fk + (qq - (s0 - csuffix[c]));
+        d0 = d_lo + k * kDB;
+        d1 = min(d0 + (uint32_t)kDB, d_hi);
+        const uint32_t T = (c + kTB - 1) / kTB;
+        n_off = (T * T) / 4;
+        tl = g < n_groups_off ? g : n_off + (g - n_groups_off);
+    }
     const bool offdiag = tl < n_off;
     uint32_t blk[3];                 // id block of column groups 0..7, 8..15, 16..23 (0xFFFFFFFF = absent)
     uint32_t a1, a2, b, colA1, colA2, colB;
@@ -940,12 +1012,12 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
 #pragma unroll
         for (int s = 0; s < kBs2PerLane; ++s) {
             if (lane + s * kWave < n_stage) {
-                xr[s] = load_planes_off<HI>(base, xoff[s]);
-                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes_off<HI>(base, yoff[s]);
+                xr[s] = load_planes_nw<NW>(base, xoff[s]);
+                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes_nw<NW>(base, yoff[s]);
             }
         }
-        ab1_next = load_planes_off<HI>(base, ab1off);
-        if (has_a2) ab2_next = load_planes_off<HI>(base, ab2off);
+        ab1_next = load_planes_nw<NW>(base, ab1off);
+        if (has_a2) ab2_next = load_planes_nw<NW>(base, ab2off);
     };
     auto commit = [&](int bufi) {
 #pragma unroll
@@ -953,7 +1025,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
             if (lane + s * kWave < n_stage) {
                 Planes x = xr[s];
                 if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]);
-                lds_store<WIDE>(stage[bufi], slot[s], kBs2Slots, x);
+                lds_store_hw<HW>(stage[bufi], slot[s], kBs2Slots, x);
             }
         }
     };
@@ -974,18 +1046,18 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const ui
         const uint4 *buf = stage[g & 1];
         if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
         QS_STAMP_T(t1);
-        const Planes L1 = sub_biased<B>(ab1, lds_load<WIDE>(buf, colA1, kBs2Slots));
+        const Planes L1 = sub_biased<B>(ab1, lds_load_hw<HW>(buf, colA1, kBs2Slots));
         Planes L2 = L1;
-        if (has_a2) L2 = sub_biased<B>(ab2, lds_load<WIDE>(buf, colA2, kBs2Slots));
+        if (has_a2) L2 = sub_biased<B>(ab2, lds_load_hw<HW>(buf, colA2, kBs2Slots));
         QS_STAMP_T(t2);
         // the R element of slot j+1 is requested from LDS before slot j is computed (rows of slots outside
         // [jlo, jhi) hold don't-care data, reading them is harmless). Requesting all kDB up front was slower:
         // +35 VGPRs, 3 instead of 4 waves per SIMD.
-        Planes Rnext = lds_load<WIDE>(buf, kCols2 + colB, kBs2Slots);
+        Planes Rnext = lds_load_hw<HW>(buf, kCols2 + colB, kBs2Slots);
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
             const Planes Rb = Rnext;
-            if (j + 1 < kDB) Rnext = lds_load<WIDE>(buf, (2 + j) * kCols2 + colB, kBs2Slots);
+            if (j + 1 < kDB) Rnext = lds_load_hw<HW>(buf, (2 + j) * kCols2 + colB, kBs2Slots);
             if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
@@ -1053,6 +1125,7 @@ hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const v
         (void)hipMemsetAsync(dst, 0, nb, s);
         hipLaunchKernelGGL((count_bitslice2_kernel<4, uint32_t, true>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,
                            m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,
+                           g.n_groups_off, g.n_groups, g.gprefix, g.csuffix,
                            (uint32_t *)table, overflow_flag, overwrite ? 1u : 0u, dst);
         std::vector<unsigned long long> h((size_t)g.total_tiles * 8);
         (void)hipStreamSynchronize(s);
@@ -1071,6 +1144,7 @@ hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const v
 #define QS_BS2(BB, CT)                                                                                              \
     hipLaunchKernelGGL((count_bitslice2_kernel<BB, CT, false>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,  \
                        m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
+                       g.n_groups_off, g.n_groups, g.gprefix, g.csuffix,                                            \
                        (CT *)table, overflow_flag, overwrite ? 1u : 0u, (unsigned long long *)nullptr)
 #define QS_BS2_B(CT)                                                                                                \
     do {                                                                                                            \

@@ -43,6 +43,10 @@ struct CountGeometry {
     uint32_t total_tiles;
     const uint32_t *dprefix; // device, n_dblk+1
     const uint32_t *cprefix; // device, n+1
+    // group-major tile order of count_bitslice2_kernel (0 groups = use the (d-block, c, tile) order above)
+    uint32_t n_groups_off = 0, n_groups = 0; // off-diagonal (b-block, a-pair) groups, then diagonal-pair groups
+    const uint32_t *gprefix = nullptr;       // device, n_groups+1: tiles before group g
+    const uint32_t *csuffix = nullptr;       // device, n+2: S[c] = sum over c' >= c of the d-blocks holding some d > c'
 };
 
 // qs_count.hip

@@ -149,6 +149,26 @@ def test_binary_batches_on_table_shards(eng):
         assert T.shape[0] == r1 - r0 and (T.astype(np.uint64) == full[r0:r1]).all(), (d_lo, d_hi)
 
 
+@pytest.mark.parametrize("order", ["group", "plain"])
+def test_tile_orders_of_the_two_column_kernel(eng, monkeypatch, order):
+    """The group-major tile order (default from 256 taxa on) enumerates exactly the same tile set as the
+    (d-block, c, tile) order: forced here at small n, odd sizes and on table shards."""
+    monkeypatch.setenv("QS_TILE_ORDER", order)
+    for n, m, shard in ((4, 3, None), (9, 10, None), (17, 33, None), (40, 20, None), (64, 40, (20, 50)), (45, 12, (44, 45)),
+                        (70, 9, (0, 11))):
+        ref_nw, trees = make_case(n, m, 90 + n)
+        ref = flatten.flatten_reference(ref_nw)
+        batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+        full = oracle_counts(ref_nw, trees).counts()
+        d_lo, d_hi = shard or (0, n)
+        ctx = eng.Context(n, 32, d_lo=d_lo, d_hi=d_hi)
+        ctx.table_alloc()
+        ctx.count_trees(batch)
+        assert "x2" in ctx.last_count_variant()
+        r0, r1 = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
+        assert (ctx.table_download().astype(np.uint64) == full[r0:r1]).all(), (n, shard, order)
+
+
 def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     n = 96
     ref_nw = synth.reference_tree(n, 9)
