@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--no-score", action="store_true")
     ap.add_argument("--distinct-trees", type=int, default=0,
                     help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
+    ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees)")
+    ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees)")
     ap.add_argument("--table-shards", type=int, default=1,
                     help="table-sharded mode (configs[4]): split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=0, help="which shard this single-GPU run owns")
@@ -84,10 +86,11 @@ def main():
     # seeded inputs: seed = 1000 * config + tree set id; rank r counts tree set r
     ref_nw = synth.reference_tree(n, 2000)
     distinct = min(args.distinct_trees or m, m)
-    trees = synth.tree_set(n, distinct, 2001 + rank)
+    trees = synth.tree_set(n, distinct, 2001 + rank, collapse=args.collapse, dropout=args.dropout)
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
-    if distinct < m:  # tile the flattened trees (every tree holds all n taxa -> fixed stride)
+    if distinct < m:  # tile the flattened trees (needs every tree to hold all n taxa -> fixed stride)
+        assert args.dropout == 0.0, "--distinct-trees needs full trees"
         reps = -(-m // distinct)
         ids = np.tile(batch.leaf_ids, reps)[: m * n]
         dep = np.tile(batch.adj_depth, reps)[: m * n]
@@ -180,7 +183,9 @@ def main():
     # parity gate run with every measurement: table of this rank's trees, checked on rank 0
     step()
     ctx.sync()
-    if args.count_bits == 32:  # every tree resolves every quartet exactly once: checked on the device
+    if args.collapse or args.dropout:
+        parity = None                  # tuples sum to m only when every tree resolves every quartet
+    elif args.count_bits == 32:        # checked on the device
         parity = bool((table[: nq * 3].view(nq, 3).sum(dim=1) == m).all().item())
     else:
         parity = bool((ctx.table_download().sum(axis=1, dtype=np.uint64) == m).all())

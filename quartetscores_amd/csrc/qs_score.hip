@@ -79,20 +79,6 @@ __device__ __forceinline__ QuartetRef classify(const ScoreDevice &sd, uint64_t l
     return r;
 }
 
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
 // ---- pass 1 -----------------------------------------------------------------------------
 // A workgroup walks kP1Iters * 256 consecutive ranks. Consecutive ranks vary the smallest id a,
 // and along a the owning node pair is piecewise constant, so (1) each wave first reduces its
