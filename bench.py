@@ -48,6 +48,8 @@ def parse_args():
                     help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
     ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees)")
     ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees)")
+    ap.add_argument("--wire", choices=["auto", "u16", "u32"], default="auto",
+                    help="N>1: cell width on the wire of the table all-reduce (auto = u16 while world x trees < 65536)")
     ap.add_argument("--table-shards", type=int, default=1,
                     help="table-sharded mode (configs[4]): split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=0, help="which shard this single-GPU run owns")
@@ -110,10 +112,19 @@ def main():
     # N > 1: two tables, so that the RCCL all-reduce of step k's table (async, on RCCL's stream) overlaps
     # the counting of step k+1 into the other one. Needs 2x table memory: only when it comfortably fits.
     tables = [table]
-    if use_dist and 2 * ctx.table_bytes < 64 * (1 << 30):
+    # Wire format of the all-reduce: while the summed counts stay below 2^16 (world x m trees; the reference's own
+    # CINT rule, QuartetScores.cpp:115-147) the u32 table is packed to u16 cells first (qs_table_pack16) and the
+    # ranks exchange half the bytes; the reduced buffer is itself a valid count_bits=16 table for scoring.
+    wire16 = (use_dist and args.count_bits == 32 and args.algo == "gather"
+              and (args.wire == "u16" or (args.wire == "auto" and world * m < 65536)))
+    if wire16:
+        assert world * m < 65536, "--wire u16 needs world x trees < 65536"
+        wire = [torch.zeros((ctx.table_tuples * 3 + 1) // 2, dtype=torch.int32, device=dev) for _ in range(2)]
+    elif use_dist and 2 * ctx.table_bytes < 64 * (1 << 30):
         tables.append(torch.zeros(n_words, dtype=torch.int32, device=dev))
-    pending = [None] * len(tables)
+    pending = [None] * 2
     step_no = [0]
+    last_buf = [0]
     hb = ctx.batch_upload(batch, with_nodes=(args.algo == "scatter"))  # inputs resident in HBM before the timed region
     algo = engine.QS_ALGO_GATHER if args.algo == "gather" else engine.QS_ALGO_SCATTER
 
@@ -121,9 +132,9 @@ def main():
     step_algo = algo | engine.QS_COUNT_OVERWRITE if args.algo == "gather" else algo
 
     def step():
-        i = step_no[0] % len(tables)
+        i = step_no[0] % (2 if wire16 else len(tables))
         step_no[0] += 1
-        if pending[i] is not None:       # the all-reduce that last used this table must be done
+        if pending[i] is not None:       # the all-reduce that last used this buffer must be done
             pending[i].wait()
             pending[i] = None
         if len(tables) > 1:
@@ -131,8 +142,12 @@ def main():
         if args.algo != "gather":
             ctx.table_clear()
         ctx.count_batch(hb, step_algo)
-        if use_dist:
+        if use_dist and wire16:
+            ctx.table_pack16(wire[i])
+            pending[i] = dist.all_reduce(wire[i], op=dist.ReduceOp.SUM, async_op=True)
+        elif use_dist:
             pending[i] = dist.all_reduce(tables[i], op=dist.ReduceOp.SUM, async_op=True)
+        last_buf[0] = i
 
     def drain():
         for i, w in enumerate(pending):
@@ -167,6 +182,17 @@ def main():
         elapsed = float(tt.item())
 
     drain()
+    # gate on the REDUCED table of the last timed step: every tuple sums to world x m (binary, full trees)
+    reduced_ok = None
+    if use_dist and args.steps > 0 and not (args.collapse or args.dropout):
+        if wire16:
+            cells = (wire[last_buf[0]].view(torch.int16)[: nq * 3].to(torch.int32) & 0xFFFF)
+        elif args.count_bits == 32:
+            cells = tables[last_buf[0]][: nq * 3]
+        else:
+            cells = (tables[last_buf[0]].view(torch.int16)[: nq * 3].to(torch.int32) & 0xFFFF)
+        reduced_ok = bool((cells.view(nq, 3).sum(dim=1) == world * m).all().item())
+        del cells
     if len(tables) > 1:                  # measurements below run on one table without collectives
         ctx.table_attach(table)
         tables[:] = [table]
@@ -240,7 +266,9 @@ def main():
             "distinct_trees": distinct,
             "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + (" + RCCL all-reduce of the table (async, overlapped with the next step through a second table)" if use_dist_saved else ""),
+            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((" + pack to u16 cells + RCCL all-reduce of the packed table (async, overlapped with the next step; two wire buffers)" if wire16 else " + RCCL all-reduce of the table (async, overlapped with the next step through a second table)") if use_dist_saved else ""),
+            "allreduce_bytes_per_rank": (((ctx.table_tuples * 3 + 1) // 2) * 4 if wire16 else n_words * 4) if use_dist_saved else None,
+            "parity_reduced_tuple_sums_ok": reduced_ok,
             "parity_tuple_sums_ok": parity,
             "parity_bitslice_equals_swar_impl": impl_match,
             "panel_kernel_ms": panel_ms,

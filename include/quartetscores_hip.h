@@ -145,6 +145,12 @@ int qs_table_clear(qs_ctx *ctx);
 int qs_table_download(qs_ctx *ctx, void *host_dst, uint64_t bytes);
 int qs_table_upload(qs_ctx *ctx, const void *host_src, uint64_t bytes);
 
+/* Writes the u32 table as a u16 table (same [rank][3] layout, 2 bytes per cell, padded to a whole 32-bit word)
+ * into caller-owned device memory: the wire format for the multi-GPU all-reduce while all totals stay below 2^16
+ * (packed words add without carry between the halves), and itself a valid count_bits = 16 table that a second
+ * context can attach and score. A cell >= 65536 raises QS_ERR_OVERFLOW at the next qs_sync. Asynchronous. */
+int qs_table_pack16(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+
 /* ---- counting (QuartetCounterLookup::countQuartets) ------------------------------------ */
 
 /* Opaque device-resident copy of a batch. */

@@ -251,6 +251,16 @@ extern "C" int qs_table_upload(qs_ctx *c, const void *host_src, uint64_t bytes) 
     return QS_OK;
 }
 
+extern "C" int qs_table_pack16(qs_ctx *c, void *dst_device, uint64_t dst_bytes) {
+    if (!c || !c->table || !dst_device) return fail(c, QS_ERR_STATE, "qs_table_pack16: no table / NULL destination");
+    if (c->count_bits != 32) return fail(c, QS_ERR_ARG, "qs_table_pack16: the table already has 16-bit cells");
+    const uint64_t cells = c->n_tuples * 3, need = ((cells + 1) / 2) * 4;
+    if (dst_bytes < need) return fail(c, QS_ERR_ARG, "qs_table_pack16: destination smaller than " + std::to_string(need) + " bytes");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, launch_pack16(c->stream, c->table, dst_device, cells, c->dev_flags));
+    return QS_OK;
+}
+
 // ---- batches -----------------------------------------------------------------------------
 
 extern "C" void qs_batch_free(qs_ctx *c, qs_device_batch *b) {

@@ -1278,6 +1278,27 @@ hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n,
 }
 
 // ======================================================================================
+// u32 table -> u16 table (wire format of the multi-GPU all-reduce when all totals stay below 2^16)
+// ======================================================================================
+__global__ __launch_bounds__(256) void pack16_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                     uint64_t n_words, uint64_t n_cells, uint32_t *__restrict__ overflow_flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one output word = two cells
+    if (i >= n_words) return;
+    const uint32_t lo = src[2 * i];
+    const uint32_t hi = (2 * i + 1 < n_cells) ? src[2 * i + 1] : 0u;
+    if ((lo | hi) > 0xFFFFu) atomicOr(overflow_flag, 1u);
+    dst[i] = (lo & 0xFFFFu) | (hi << 16);
+}
+
+hipError_t launch_pack16(hipStream_t s, const void *table_u32, void *dst, uint64_t n_cells, uint32_t *overflow_flag) {
+    const uint64_t n_words = (n_cells + 1) / 2;
+    if (n_words == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_words + 255) / 256));
+    hipLaunchKernelGGL(pack16_kernel, grid, block, 0, s, (const uint32_t *)table_u32, (uint32_t *)dst, n_words, n_cells, overflow_flag);
+    return hipGetLastError();
+}
+
+// ======================================================================================
 // lookup (countQuartetOccurrences, QuartetCounterLookup.hpp:299-318)
 // ======================================================================================
 

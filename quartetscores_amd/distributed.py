@@ -51,28 +51,39 @@ def all_reduce_table(table, group=None):
     return table
 
 
-def count_tree_sharded(n_trees: int, count_local: Callable[[int, int], None], table, group=None):
+def count_tree_sharded(n_trees: int, count_local: Callable[[int, int], None], table, group=None, pre_reduce=None):
     """Run `count_local(lo, hi)` on this rank's tree range, then all-reduce `table`.
 
     count_local adds the quartet counts of trees [lo, hi) into `table` (on the GPU this is
-    Context.count_trees on a sliced batch with `table` attached)."""
+    Context.count_trees on a sliced batch with `table` attached). pre_reduce, if given, runs between the two
+    (the u16 wire format packs the counted u32 table into `table` there)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_range(n_trees, world, rank)
     if hi > lo:
         count_local(lo, hi)
+    if pre_reduce is not None:
+        pre_reduce()
     return all_reduce_table(table, group)
 
 
-def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, device=None):
+def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, device=None, wire: str = "auto"):
     """Tree-sharded counting on the current torch.distributed world (one rank per GPU).
-    Returns (Context, table tensor); every rank ends with the full reduced table."""
+    Returns (Context, table tensor); every rank ends with the full reduced table.
+
+    wire: cell width the ranks exchange. With a u32 table and fewer than 65536 trees in total ("auto", or "u16")
+    each rank packs its table to u16 cells (Context.table_pack16) and the all-reduce moves half the bytes; the
+    returned Context is then a count_bits=16 one attached to the reduced packed table."""
     import torch
     import torch.distributed as dist
     from . import engine
     if count_bits == 16 and batch.n_trees >= (1 << 16):
         raise ValueError("u16 tables need fewer than 65536 trees in total")
+    if wire not in ("auto", "u16", "u32"):
+        raise ValueError("wire must be auto, u16 or u32")
+    if wire == "u16" and batch.n_trees >= (1 << 16):
+        raise ValueError("a u16 wire format needs fewer than 65536 trees in total")
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.current_stream(dev)
     ctx = engine.Context(ref.n_taxa, count_bits, device=dev.index or 0, stream=stream.cuda_stream)
@@ -82,6 +93,15 @@ def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, devic
     def local(lo, hi):
         ctx.count_trees(batch.slice(lo, hi), algo)
 
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if count_bits == 32 and (wire == "u16" or (wire == "auto" and multi and batch.n_trees < (1 << 16))):
+        packed = torch.zeros(table_words(ctx.table_tuples, 16), dtype=torch.int32, device=dev)
+        count_tree_sharded(batch.n_trees, local, packed, pre_reduce=lambda: ctx.table_pack16(packed))
+        ctx16 = engine.Context(ref.n_taxa, 16, device=dev.index or 0, stream=stream.cuda_stream)
+        ctx16.table_attach(packed)
+        ctx.close()
+        torch.cuda.synchronize(dev)
+        return ctx16, packed
     count_tree_sharded(batch.n_trees, local, table)
     if dist.is_initialized():
         torch.cuda.synchronize(dev)

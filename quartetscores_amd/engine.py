@@ -82,6 +82,10 @@ class Context:
         self._chk(self.L.qs_table_attach(self.h, C.c_void_p(tensor.data_ptr()), nbytes))
         self._attached = tensor
 
+    def table_pack16(self, tensor):
+        """u32 table -> u16 table in `tensor` (torch CUDA tensor, >= ceil(cells/2)*4 bytes); asynchronous."""
+        self._chk(self.L.qs_table_pack16(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
+
     def table_clear(self):
         self._chk(self.L.qs_table_clear(self.h))
 

@@ -520,3 +520,60 @@ def test_config2_full_size_properties(eng):
     internal = [v for v in range(1, ref.n_nodes) if ref.nodes[v].children]
     assert np.isfinite(lq[internal]).all() and np.isfinite(qp[internal]).all() and np.isfinite(eqp[internal]).all()
     assert (eqp[internal] <= qp[internal]).all()                       # EQP-IC is a min that includes the edge's own pair
+
+
+def test_pack16_wire_format(eng):
+    """qs_table_pack16: the u32 table as u16 cells is a valid count_bits=16 table (same counts, same scores);
+    packed words add without carries (what the multi-GPU all-reduce relies on); a cell >= 2^16 is reported."""
+    import torch
+    from quartetscores_amd import distributed
+    n, m = 19, 300   # odd number of cells -> the padded last word is exercised too
+    ref_nw = synth.reference_tree(n, 71)
+    trees = synth.tree_set(n, m, 72, collapse=0.1, dropout=0.05)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    ctx.count_trees(batch)
+    want = ctx.table_download()
+    packed = torch.full((distributed.table_words(ctx.table_tuples, 16),), -1, dtype=torch.int32, device="cuda")
+    ctx.table_pack16(packed)
+    ctx.sync()
+    c16 = eng.Context(n, 16)
+    c16.table_attach(packed)
+    assert np.array_equal(c16.table_download().astype(np.uint32), want)
+    for a, b in zip(ctx.score(ref)[:3], c16.score(ref)[:3]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    # "all-reduce" of three ranks' packed tables == packed sum
+    total = packed * 3
+    c16.table_attach(total)
+    assert np.array_equal(c16.table_download().astype(np.uint32), want * 3)
+    # too small a destination / 16-bit source are argument errors
+    with pytest.raises(eng.QSError):
+        ctx.table_pack16(packed[:-1])
+    with pytest.raises(eng.QSError):
+        c16.table_pack16(packed)
+    # overflow
+    big = want.copy()
+    big[5, 1] = 70000
+    ctx.table_upload(big)
+    ctx.table_pack16(packed)
+    with pytest.raises(eng.QSError) as ei:
+        ctx.sync()
+    assert ei.value.code == -5
+
+
+def test_count_trees_multi_gpu_u16_wire_single_rank(eng):
+    """distributed.count_trees_multi_gpu(wire='u16') on one rank: same table and scores as the plain path."""
+    from quartetscores_amd import distributed
+    n, m = 16, 120
+    ref_nw = synth.reference_tree(n, 81)
+    trees = synth.tree_set(n, m, 82)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    c_a, _ = distributed.count_trees_multi_gpu(ref, batch, wire="u32")
+    c_b, _ = distributed.count_trees_multi_gpu(ref, batch, wire="u16")
+    assert c_b.count_bits == 16
+    assert np.array_equal(c_a.table_download(), c_b.table_download().astype(np.uint32))
+    for a, b in zip(c_a.score(ref)[:3], c_b.score(ref)[:3]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
