@@ -35,6 +35,8 @@ struct qs_ctx {
     uint32_t *dprefix = nullptr, *cprefix = nullptr;
     uint32_t n_dblk = 0, total_tiles = 0;
     uint32_t *dprefix2 = nullptr, *cprefix2 = nullptr; // tiling of the two-a-column kernel
+    uint32_t *dprefix3 = nullptr;                      // same tiles, d-blocks counted down from d_hi (count_bitslice3_kernel)
+    uint32_t total_tiles3 = 0;
     uint32_t total_tiles2 = 0;
     uint32_t *gprefix = nullptr, *csuffix = nullptr;   // its group-major order (large n)
     uint32_t n_groups_off = 0, n_groups = 0;
@@ -125,6 +127,11 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
             dp2[k + 1] = dp2[k] + cp2[d1 - 1];
         }
         c->total_tiles2 = dp2[c->n_dblk];
+        std::vector<uint32_t> dp3(c->n_dblk + 1, 0);
+        for (uint32_t k = 0; k < c->n_dblk; ++k) dp3[k + 1] = dp3[k] + cp2[d_hi - k * kDB - 1]; // block k = [max(d_start, d1 - 8), d1), d1 = d_hi - 8k
+        c->total_tiles3 = dp3[c->n_dblk];
+        if (hipMalloc(&c->dprefix3, dp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix3");
+        if (hipMemcpy(c->dprefix3, dp3.data(), dp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix3");
         if (hipMalloc(&c->cprefix2, cp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix2");
         if (hipMalloc(&c->dprefix2, dp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix2");
         if (hipMemcpy(c->cprefix2, cp2.data(), cp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix2");
@@ -184,6 +191,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->dprefix) (void)hipFree(c->dprefix);
     if (c->cprefix) (void)hipFree(c->cprefix);
     if (c->dprefix2) (void)hipFree(c->dprefix2);
+    if (c->dprefix3) (void)hipFree(c->dprefix3);
     if (c->cprefix2) (void)hipFree(c->cprefix2);
     if (c->gprefix) (void)hipFree(c->gprefix);
     if (c->csuffix) (void)hipFree(c->csuffix);
@@ -420,7 +428,11 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
             if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
-            if (use_bitslice && two_a) {
+            if (use_bitslice && two_a && !(tile_env && tile_env[0] == '2')) {
+                CountGeometry g3 = g;
+                g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix2;
+                QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+            } else if (use_bitslice && two_a) {
                 CountGeometry g2 = g;
                 g2.total_tiles = c->total_tiles2; g2.dprefix = c->dprefix2; g2.cprefix = c->cprefix2;
                 // QS_TILE_ORDER=group selects the group-major order (meant to reuse the private M[ab] elements in L2).
@@ -435,7 +447,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }
         if (use_bitslice)
-            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (two_a ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
+            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (two_a ? ((tile_env && tile_env[0] == '2') ? "x2" : "x2v3") : "") + "/count_u" + std::to_string(c->count_bits);
         else
             c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {

@@ -33,6 +33,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace qs {
@@ -548,9 +549,7 @@ struct Planes { uint32_t w[kBitWords]; };
 // expression shapes into bitop3 (it fell back to xnor/and_or pairs here), so the hot chains use it
 // explicitly. Full rate on gfx950 (tools/valu_rates.hip).
 template <int TT> __device__ __forceinline__ uint32_t lut3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t d;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(d) : "v"(a), "v"(b), "v"(c), "n"(TT));
-    return d;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 }
 constexpr int kTT_XOR3 = 0xF0 ^ 0xCC ^ 0xAA;                                  // a ^ b ^ c
 constexpr int kTT_LT = ((0x0F & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (~a & b) | (~(a ^ b) & c): borrow / less-than step
@@ -1156,6 +1155,255 @@ hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const v
     if (count_bits == 32) QS_BS2_B(uint32_t); else QS_BS2_B(uint16_t);
 #undef QS_BS2_B
 #undef QS_BS2
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// count_bitslice3_kernel: the binary_full fast path (every tree holds all taxa and is binary)
+// ======================================================================================
+// Same tile as the two-column kernel above (wave = d-block of 8 x c x (16 a x 8 b)), rebuilt around what its
+// ISA showed: 60 % of the instructions of one 32-tree step were not comparison chains. Differences:
+//   * panel reads are raw BUFFER loads: the per-lane byte offset inside one tree group is loop-invariant, the
+//     group advances through the (scalar) base address of the resource, lanes with nothing to load use an
+//     out-of-range offset and get zeros -- no 64-bit address arithmetic and no exec masking in the loop;
+//   * staging is branch-free: lane l owns R element (d-row l/8, b-column l%8), lanes 0..15 also own the
+//     M[x,c] element of a-column l;
+//   * the 32-tree step is unrolled twice with the two register sets / LDS buffers swapping roles, so the
+//     double buffering costs no register moves;
+//   * the step is instantiated for (second a-column present, all 8 d slots live, diagonal tile) and the wave
+//     picks its instance once: the hot instance has no branches inside the step;
+//   * d-blocks are aligned to the TOP of the shard (the partial block is the one with the smallest ids, where
+//     c < d leaves few tiles): 7 % fewer tiles at 128 taxa, 81 % instead of 65 % of them with all slots live.
+constexpr int kS3RSlots = kDB * 16;            // R elements: slot = d-row * 16 + b-column (0..15)
+constexpr int kS3Row0 = kS3RSlots;             // 16 elements M[x,c] of the a-columns
+constexpr int kS3Slots = kS3RSlots + 16;       // 144
+constexpr uint32_t kS3Inv = 0x80000000u;       // byte offset beyond any tree group: the buffer load returns zeros
+
+typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t qs_u32x2 __attribute__((ext_vector_type(2)));
+
+// first NW words (4..7) of the panel element at byte offset voff of the tree group behind `r`
+template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    Planes p;
+    const qs_u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    p.w[0] = lo.x; p.w[1] = lo.y; p.w[2] = lo.z; p.w[3] = lo.w;
+    p.w[4] = p.w[5] = p.w[6] = p.w[7] = 0;
+    if (NW == 5) p.w[4] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 16, 0);
+    else if (NW == 6) { const qs_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 16, 0); p.w[4] = h.x; p.w[5] = h.y; }
+    else if (NW >= 7) { const qs_u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 16, 0); p.w[4] = h.x; p.w[5] = h.y; p.w[6] = h.z; p.w[7] = h.w; }
+    return p;
+}
+
+uint32_t bitslice3_tiles_for_c(uint32_t c) { return bitslice2_tiles_for_c(c); }
+
+template <int B, typename CT>
+__global__ __launch_bounds__(kCountThreads) void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
+                                                                        uint32_t n_groups, uint32_t m_trees,
+                                                                        uint32_t d_start, uint32_t d_hi, uint64_t rank_lo,
+                                                                        uint32_t n_dblk, uint32_t total_tiles,
+                                                                        const uint32_t *__restrict__ dprefix,
+                                                                        const uint32_t *__restrict__ cprefix,
+                                                                        CT *__restrict__ table,
+                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
+    constexpr int NB = B + 1;
+    constexpr int NW = B < 4 ? 4 : B;                       // live words of a raw panel element (planes of M)
+    constexpr int HW = NB <= 5 ? 1 : (NB == 6 ? 2 : 4);     // upper words of an LDS slot (R has B+1 planes)
+    constexpr int kImg = kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
+    __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    uint4 *buf0 = stage_all[wave][0], *buf1 = stage_all[wave][1];
+
+    // ---- tile decode (wave-uniform): d-block k counts down from the top of the shard ----
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= total_tiles) return;
+    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
+    const uint32_t local = tile - dprefix[k];
+    const uint32_t d1 = d_hi - k * kDB;
+    const uint32_t d0 = d1 > d_start + kDB ? d1 - kDB : d_start;
+    const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
+    const uint32_t T = (c + kTB - 1) / kTB;
+    const uint32_t n_off = (T * T) / 4;
+    const uint32_t tl = local - cprefix[c];
+    const bool offdiag = tl < n_off;
+
+    uint32_t blk0, blk1, blkB;       // id blocks: a-columns 0..7, a-columns 8..15 (0xFFFFFFFF = absent), b-columns
+    uint32_t a1, a2, b, colA1, colA2, colB;
+    if (offdiag) {
+        uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f)); // largest Bk with floor(Bk^2 / 4) <= tl
+        while ((Bk * Bk) / 4 > tl) --Bk;
+        while (((Bk + 1) * (Bk + 1)) / 4 <= tl) ++Bk;
+        const uint32_t j = tl - (Bk * Bk) / 4;
+        blk0 = 2 * j; blk1 = (2 * j + 1 < Bk) ? 2 * j + 1 : 0xFFFFFFFFu; blkB = Bk;
+        const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
+        colA1 = ia; colA2 = kTA + ia; colB = ib;
+        a1 = blk0 * kTA + ia;
+        a2 = blk1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : blk1 * kTA + ia;
+        b = Bk * kTB + ib;
+    } else {
+        const uint32_t kd = tl - n_off;
+        blk0 = 2 * kd; blk1 = 2 * kd + 1; blkB = blk0;
+        const uint32_t h = lane >> 5, q = lane & 31;
+        uint32_t ia = 0, ib = 1;
+        if (q < 28) unrank2(q, ia, ib);
+        colA1 = h * kTA + ia; colA2 = colA1; colB = h * kTA + ib;
+        a1 = (h ? blk1 : blk0) * kTA + ia; a2 = 0xFFFFFFFFu;
+        b = q < 28 ? (h ? blk1 : blk0) * kTA + ib : 0xFFFFFFFFu;
+    }
+    const bool has_a2 = offdiag && blk1 != 0xFFFFFFFFu; // wave-uniform
+    const bool v1 = (a1 < b) && (b < c);
+    const bool v2 = has_a2 && (a2 < b) && (b < c);
+    const uint32_t pi1 = v1 ? (uint32_t)binom2(b) + a1 : 0u;
+    const uint32_t pi2 = v2 ? (uint32_t)binom2(b) + a2 : 0u;
+    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
+
+    // ---- loop-invariant byte offsets inside one tree group, and LDS slots ----
+    const uint32_t r_j = lane >> 3, r_col = lane & 7, dE = d0 + r_j;
+    const bool dok = dE < d1 && dE > c;
+    const uint32_t bE0 = blkB * kTB + r_col, bE1 = blk1 * kTB + r_col;   // blk1 is only used for diagonal tiles here
+    const bool ok0 = dok && bE0 < c, ok1 = dok && !offdiag && bE1 < c;
+    const uint32_t rowd = (uint32_t)binom2(dE);
+    const uint32_t x0off = ok0 ? (rowd + bE0) * 32u : kS3Inv, y0off = ok0 ? (rowd + c) * 32u : kS3Inv;
+    const uint32_t x1off = ok1 ? (rowd + bE1) * 32u : kS3Inv, y1off = ok1 ? (rowd + c) * 32u : kS3Inv;
+    const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
+    uint32_t xa = 0xFFFFFFFFu;
+    if (lane < 8) xa = blk0 * kTA + lane;
+    else if (lane < 16 && blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (lane - 8);
+    const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 32u : kS3Inv;
+    const uint32_t rowslot = kS3Row0 + lane;   // lanes 0..15
+    const uint32_t ab1off = v1 ? pi1 * 32u : kS3Inv, ab2off = v2 ? pi2 * 32u : kS3Inv;
+    const uint32_t group_bytes = npairs * 32u;
+
+    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB]; // counters of (a1,b) and (a2,b): topologies ab|cd and ac|bd per d slot
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
+
+    struct Staged { Planes x0, y0, x1, y1, row; };
+    auto rsrc_of = [&](uint32_t g) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(P + (size_t)g * npairs * 2), 0, (int)group_bytes, 0x00020000);
+    };
+    auto row0_load = [&](const uint4 *buf, uint32_t col) {
+        if (B <= 4) {
+            const uint4 lo = buf[kS3Row0 + col];
+            Planes r;
+            r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w; r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+            return r;
+        }
+        return lds_load_hw<HW>(buf, kS3Row0 + col, kS3Slots);
+    };
+
+    // one 32-tree step: request group g_next into (st, abn1, abn2), count group g from (cur, abc1, abc2), then
+    // turn the requested elements into the LDS image `nxt`
+    auto step = [&](uint32_t g_next, const uint4 *cur, uint4 *nxt, const Planes &abc1, const Planes &abc2, Planes &abn1,
+                    Planes &abn2, auto a2_tag, auto full_tag, auto diag_tag) {
+        constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value, DIAG = decltype(diag_tag)::value;
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(g_next);
+        Staged st;
+        st.x0 = buf_load_planes<NW>(r, x0off);
+        st.y0 = buf_load_planes<NW>(r, y0off);
+        if (DIAG) { st.x1 = buf_load_planes<NW>(r, x1off); st.y1 = buf_load_planes<NW>(r, y1off); }
+        st.row = buf_load_planes<NW>(r, rowoff);
+        abn1 = buf_load_planes<NW>(r, ab1off);
+        if (A2) abn2 = buf_load_planes<NW>(r, ab2off);
+
+        const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1));
+        Planes L2 = L1;
+        if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            if (FULL || ((uint32_t)j >= jlo && (uint32_t)j < jhi)) { // wave-uniform
+                const Planes Rb = lds_load_hw<HW>(cur, j * 16 + colB, kS3Slots);
+                uint32_t gt, lt;
+                cmp_planes<NB>(L1, Rb, gt, lt);
+                popc_acc(gt, x0[j]);
+                popc_acc(lt, x1[j]);
+                if (A2) {
+                    uint32_t gt2, lt2;
+                    cmp_planes<NB>(L2, Rb, gt2, lt2);
+                    popc_acc(gt2, y0[j]);
+                    popc_acc(lt2, y1[j]);
+                }
+            }
+        }
+        lds_store_hw<HW>(nxt, slot0, kS3Slots, sub_biased<B>(st.x0, st.y0));
+        if (DIAG) lds_store_hw<HW>(nxt, slot1, kS3Slots, sub_biased<B>(st.x1, st.y1));
+        if (lane < 16) {
+            if (B <= 4) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
+            else lds_store_hw<HW>(nxt, rowslot, kS3Slots, st.row);
+        }
+    };
+
+    auto run = [&](auto a2_tag, auto full_tag, auto diag_tag) {
+        constexpr bool A2 = decltype(a2_tag)::value, DIAG = decltype(diag_tag)::value;
+        Planes abA1, abA2, abB1, abB2;
+#pragma unroll
+        for (int w = 0; w < kBitWords; ++w) abA2.w[w] = abB2.w[w] = 0;
+        {   // group 0 -> buf0 / set A
+            const __amdgpu_buffer_rsrc_t r = rsrc_of(0);
+            lds_store_hw<HW>(buf0, slot0, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x0off), buf_load_planes<NW>(r, y0off)));
+            if (DIAG) lds_store_hw<HW>(buf0, slot1, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x1off), buf_load_planes<NW>(r, y1off)));
+            const Planes row = buf_load_planes<NW>(r, rowoff);
+            if (lane < 16) lds_store_hw<HW>(buf0, rowslot, kS3Slots, row);
+            abA1 = buf_load_planes<NW>(r, ab1off);
+            if (A2) abA2 = buf_load_planes<NW>(r, ab2off);
+        }
+        const uint32_t g_last = n_groups - 1;
+        for (uint32_t g = 0; g < n_groups; g += 2) {
+            // the request past the last group re-reads the last one (its image is never used)
+            step(min(g + 1, g_last), buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, diag_tag);
+            if (g + 1 < n_groups) step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, diag_tag);
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    if (has_a2) { if (jlo == 0 && jhi == (uint32_t)kDB) run(T_{}, T_{}, F_{}); else run(T_{}, F_{}, F_{}); }
+    else if (offdiag) run(F_{}, F_{}, F_{});
+    else run(F_{}, F_{}, T_{});
+
+    const uint64_t rcb = binom3(c);
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) {
+        const uint32_t d = d0 + j;
+        if (d < d1 && d > c) {
+            const uint64_t base = binom4(d) + rcb - rank_lo;
+            if (v1) {
+                const uint64_t idx = (base + pi1) * 3;
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = m_trees - x0[j] - x1[j];
+                if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
+                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+                table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
+            }
+            if (v2) {
+                const uint64_t idx = (base + pi2) * 3;
+                uint32_t w0 = y0[j], w1 = y1[j], w2 = m_trees - y0[j] - y1[j];
+                if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
+                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+                table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
+            }
+        }
+    }
+}
+
+hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
+                                  uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
+                                  bool overwrite) {
+    if (g.total_tiles == 0 || n_groups == 0) return hipSuccess;
+    const uint32_t npairs = (uint32_t)binom2(g.n);
+    dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
+#define QS_BS3(BB, CT)                                                                                              \
+    hipLaunchKernelGGL((count_bitslice3_kernel<BB, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
+                       m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u)
+#define QS_BS3_B(CT)                                                                                                \
+    do {                                                                                                            \
+        if (depth_bits <= 4) QS_BS3(4, CT);                                                                         \
+        else if (depth_bits == 5) QS_BS3(5, CT);                                                                    \
+        else if (depth_bits == 6) QS_BS3(6, CT);                                                                    \
+        else QS_BS3(7, CT);                                                                                         \
+    } while (0)
+    if (count_bits == 32) QS_BS3_B(uint32_t); else QS_BS3_B(uint16_t);
+#undef QS_BS3_B
+#undef QS_BS3
     return hipGetLastError();
 }
 
