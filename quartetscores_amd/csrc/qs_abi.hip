@@ -399,7 +399,9 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         int bits = 8;
         uint32_t tpc;            // trees per panel element
         size_t elem_bytes;       // bytes per (pair, element)
-        if (use_bitslice) { tpc = 32; elem_bytes = 32; }
+        const bool v3 = two_a && !(tile_env && tile_env[0] == '2');
+        const uint32_t compact_nw = v3 ? std::max(depth_bits, 4u) : 0u; // count_bitslice3_kernel reads the compact panel
+        if (use_bitslice) { tpc = 32; elem_bytes = v3 ? compact_nw * 4 : 32; }
         else {
             const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
             const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
@@ -425,10 +427,10 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             DeviceBatch sub = d;
             sub.leaf_off = d.leaf_off + t0; // offsets stay absolute into leaf_ids / adj_depth
             sub.n_trees = nt;
-            if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch));
+            if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
             if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
-            if (use_bitslice && two_a && !(tile_env && tile_env[0] == '2')) {
+            if (v3) {
                 CountGeometry g3 = g;
                 g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix2;
                 QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
                                                                     const uint16_t *__restrict__ leaf_ids,
                                                                     const uint16_t *__restrict__ adj_depth,
                                                                     uint32_t n_trees, uint32_t n, uint32_t npairs,
-                                                                    uint32_t levels, uint4 *__restrict__ Pb) {
+                                                                    uint32_t levels, uint4 *__restrict__ Pb, uint32_t compact_nw) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *out = smem;                                     // [kBPPB][32] depth bytes (0xFF = absent)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -518,14 +518,23 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
                 w[7] |= (absent ? 0u : 1u) << tbit;
             }
         }
-        uint4 *dst = Pb + ((size_t)g * npairs + p) * 2;
-        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        if (compact_nw) {
+            // compact layout of count_bitslice3_kernel: per tree group uint4 lo[npairs] (planes 0..3), then
+            // (compact_nw - 4) upper words per pair
+            char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * compact_nw * 4;
+            reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
+            uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (compact_nw - 4);
+            for (uint32_t k = 4; k < compact_nw; ++k) hi[k - 4] = w[k];
+        } else {
+            uint4 *dst = Pb + ((size_t)g * npairs + p) * 2;
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
     }
 }
 
 hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel,
-                                 uint32_t n_groups) {
+                                 uint32_t n_groups, uint32_t compact_nw) {
     const uint32_t npairs = (uint32_t)binom2(n);
     const uint32_t levels = panel_levels(n);
     const size_t lds = (size_t)kBPPB * kBitTrees + (size_t)(kBPThreads / kWave) * n * 2 * (1 + levels);
@@ -533,11 +542,11 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
     if (partial) {
         auto k = build_bitpanel_kernel<true>;
         if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel);
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel, compact_nw);
     } else {
         auto k = build_bitpanel_kernel<false>;
         if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel);
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel, compact_nw);
     }
     return hipGetLastError();
 }
@@ -1177,27 +1186,32 @@ hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const v
 constexpr int kS3RSlots = kDB * 16;            // R elements: slot = d-row * 16 + b-column (0..15)
 constexpr int kS3Row0 = kS3RSlots;             // 16 elements M[x,c] of the a-columns
 constexpr int kS3Slots = kS3RSlots + 16;       // 144
-constexpr uint32_t kS3Inv = 0x80000000u;       // byte offset beyond any tree group: the buffer load returns zeros
+constexpr uint32_t kS3Inv = 0x80000000u;       // offset beyond any tree group (also after >> 2): the buffer load returns zeros
 
 typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t qs_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t qs_u32x3 __attribute__((ext_vector_type(3)));
 
-// first NW words (4..7) of the panel element at byte offset voff of the tree group behind `r`
-template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+// panel element of the pair at 16-byte-slot offset voff (= pair * 16) of the tree group behind `r`: planes 0..3 from
+// the group's lo array, the NW - 4 upper planes from the array behind it (hi_base = npairs * 16 bytes into the group)
+template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t hi_base) {
     Planes p;
     const qs_u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
     p.w[0] = lo.x; p.w[1] = lo.y; p.w[2] = lo.z; p.w[3] = lo.w;
     p.w[4] = p.w[5] = p.w[6] = p.w[7] = 0;
-    if (NW == 5) p.w[4] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 16, 0);
-    else if (NW == 6) { const qs_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 16, 0); p.w[4] = h.x; p.w[5] = h.y; }
-    else if (NW >= 7) { const qs_u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 16, 0); p.w[4] = h.x; p.w[5] = h.y; p.w[6] = h.z; p.w[7] = h.w; }
+    if (NW == 5) p.w[4] = __builtin_amdgcn_raw_buffer_load_b32(r, voff >> 2, hi_base, 0);
+    else if (NW == 6) { const qs_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r, voff >> 1, hi_base, 0); p.w[4] = h.x; p.w[5] = h.y; }
+    else if (NW >= 7) { const qs_u32x3 h = __builtin_amdgcn_raw_buffer_load_b96(r, (voff >> 2) * 3, hi_base, 0); p.w[4] = h.x; p.w[5] = h.y; p.w[6] = h.z; }
     return p;
 }
 
-uint32_t bitslice3_tiles_for_c(uint32_t c) { return bitslice2_tiles_for_c(c); }
+#ifndef QS_BS3_WAVES
+#define QS_BS3_WAVES 4
+#endif
+#define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
 template <int B, typename CT>
-__global__ __launch_bounds__(kCountThreads) void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
+__global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees,
                                                                         uint32_t d_start, uint32_t d_hi, uint64_t rank_lo,
                                                                         uint32_t n_dblk, uint32_t total_tiles,
@@ -1264,16 +1278,16 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice3_kernel(const ui
     const uint32_t bE0 = blkB * kTB + r_col, bE1 = blk1 * kTB + r_col;   // blk1 is only used for diagonal tiles here
     const bool ok0 = dok && bE0 < c, ok1 = dok && !offdiag && bE1 < c;
     const uint32_t rowd = (uint32_t)binom2(dE);
-    const uint32_t x0off = ok0 ? (rowd + bE0) * 32u : kS3Inv, y0off = ok0 ? (rowd + c) * 32u : kS3Inv;
-    const uint32_t x1off = ok1 ? (rowd + bE1) * 32u : kS3Inv, y1off = ok1 ? (rowd + c) * 32u : kS3Inv;
+    const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, y0off = ok0 ? (rowd + c) * 16u : kS3Inv;
+    const uint32_t x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv, y1off = ok1 ? (rowd + c) * 16u : kS3Inv;
     const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
     uint32_t xa = 0xFFFFFFFFu;
     if (lane < 8) xa = blk0 * kTA + lane;
     else if (lane < 16 && blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (lane - 8);
-    const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 32u : kS3Inv;
+    const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
     const uint32_t rowslot = kS3Row0 + lane;   // lanes 0..15
-    const uint32_t ab1off = v1 ? pi1 * 32u : kS3Inv, ab2off = v2 ? pi2 * 32u : kS3Inv;
-    const uint32_t group_bytes = npairs * 32u;
+    const uint32_t ab1off = v1 ? pi1 * 16u : kS3Inv, ab2off = v2 ? pi2 * 16u : kS3Inv;
+    const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
     uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB]; // counters of (a1,b) and (a2,b): topologies ab|cd and ac|bd per d slot
 #pragma unroll
@@ -1281,7 +1295,7 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice3_kernel(const ui
 
     struct Staged { Planes x0, y0, x1, y1, row; };
     auto rsrc_of = [&](uint32_t g) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(P + (size_t)g * npairs * 2), 0, (int)group_bytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (int)group_bytes, 0x00020000);
     };
     auto row0_load = [&](const uint4 *buf, uint32_t col) {
         if (B <= 4) {
@@ -1300,12 +1314,12 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice3_kernel(const ui
         constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value, DIAG = decltype(diag_tag)::value;
         const __amdgpu_buffer_rsrc_t r = rsrc_of(g_next);
         Staged st;
-        st.x0 = buf_load_planes<NW>(r, x0off);
-        st.y0 = buf_load_planes<NW>(r, y0off);
-        if (DIAG) { st.x1 = buf_load_planes<NW>(r, x1off); st.y1 = buf_load_planes<NW>(r, y1off); }
-        st.row = buf_load_planes<NW>(r, rowoff);
-        abn1 = buf_load_planes<NW>(r, ab1off);
-        if (A2) abn2 = buf_load_planes<NW>(r, ab2off);
+        st.x0 = buf_load_planes<NW>(r, x0off, hi_base);
+        st.y0 = buf_load_planes<NW>(r, y0off, hi_base);
+        if (DIAG) { st.x1 = buf_load_planes<NW>(r, x1off, hi_base); st.y1 = buf_load_planes<NW>(r, y1off, hi_base); }
+        st.row = buf_load_planes<NW>(r, rowoff, hi_base);
+        abn1 = buf_load_planes<NW>(r, ab1off, hi_base);
+        if (A2) abn2 = buf_load_planes<NW>(r, ab2off, hi_base);
 
         const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1));
         Planes L2 = L1;
@@ -1341,12 +1355,12 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice3_kernel(const ui
         for (int w = 0; w < kBitWords; ++w) abA2.w[w] = abB2.w[w] = 0;
         {   // group 0 -> buf0 / set A
             const __amdgpu_buffer_rsrc_t r = rsrc_of(0);
-            lds_store_hw<HW>(buf0, slot0, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x0off), buf_load_planes<NW>(r, y0off)));
-            if (DIAG) lds_store_hw<HW>(buf0, slot1, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x1off), buf_load_planes<NW>(r, y1off)));
-            const Planes row = buf_load_planes<NW>(r, rowoff);
+            lds_store_hw<HW>(buf0, slot0, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x0off, hi_base), buf_load_planes<NW>(r, y0off, hi_base)));
+            if (DIAG) lds_store_hw<HW>(buf0, slot1, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x1off, hi_base), buf_load_planes<NW>(r, y1off, hi_base)));
+            const Planes row = buf_load_planes<NW>(r, rowoff, hi_base);
             if (lane < 16) lds_store_hw<HW>(buf0, rowslot, kS3Slots, row);
-            abA1 = buf_load_planes<NW>(r, ab1off);
-            if (A2) abA2 = buf_load_planes<NW>(r, ab2off);
+            abA1 = buf_load_planes<NW>(r, ab1off, hi_base);
+            if (A2) abA2 = buf_load_planes<NW>(r, ab2off, hi_base);
         }
         const uint32_t g_last = n_groups - 1;
         for (uint32_t g = 0; g < n_groups; g += 2) {
