@@ -55,7 +55,7 @@ static std::string g_create_err;
 static size_t panel_slice_bytes() {
     const char *e = getenv("QS_PANEL_SLICE_BYTES");
     if (e && *e) { long long v = atoll(e); if (v > 0) return (size_t)v; }
-    return 192ull << 20;
+    return 96ull << 20;
 }
 
 static int fail(qs_ctx *c, int code, const std::string &msg) {
@@ -390,9 +390,12 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         if (impl_env && std::string(impl_env) == "bitslice" && !bits_ok)
             return fail(c, QS_ERR_UNSUPPORTED, "QS_GATHER_IMPL=bitslice: tree depth needs more than 7 (6 with missing taxa) bits");
         // The panel of a sub-batch is kept at or below the slice size so that it stays resident in the
-        // 256 MiB Infinity Cache while every wave streams through it (measured at 512 taxa: 1.8e13
-        // quartets/s with a 260 MB panel, 1.35e13 with 1.3 GB). The table is read-modify-written once
-        // per sub-batch, which is cheap next to the counting itself.
+        // 256 MiB Infinity Cache while every wave streams through it; the price is one read-modify-write of
+        // the table per sub-batch. Measured at 512 taxa x 10000 trees (819 MB of panel, 34 GB table):
+        // 0.72 s with 50 MB slices, 0.60 s with 100 MB, 0.64 s with 192 MB, 0.71 s with 400 MB, 0.80 s unsliced.
+        // Two things that did NOT help (profiles/r01_experiments.md): visiting the tree groups in rotated order so
+        // that late tiles stay in phase with the resident ones (the panel still streams from HBM once per
+        // round of tiles), and non-temporal table accesses.
         // binary_full batches use the kernel with two a-columns per lane (QS_BITSLICE_TILE=1 selects the plain one)
         const char *tile_env = getenv("QS_BITSLICE_TILE");
         const bool two_a = use_bitslice && mode == MODE_BINARY_FULL && !(tile_env && tile_env[0] == '1');
