@@ -131,7 +131,7 @@ def main():
     # gather: QS_COUNT_OVERWRITE = "clear + count" in one pass (the kernel stores instead of accumulating)
     step_algo = algo | engine.QS_COUNT_OVERWRITE if args.algo == "gather" else algo
 
-    def step():
+    def step(timed=False):
         i = step_no[0] % (2 if wire16 else len(tables))
         step_no[0] += 1
         if pending[i] is not None:       # the all-reduce that last used this buffer must be done
@@ -141,7 +141,7 @@ def main():
             ctx.table_attach(tables[i])
         if args.algo != "gather":
             ctx.table_clear()
-        ctx.count_batch(hb, step_algo)
+        ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
         if use_dist and wire16:
             ctx.table_pack16(wire[i])
             pending[i] = dist.all_reduce(wire[i], op=dist.ReduceOp.SUM, async_op=True)
@@ -167,15 +167,21 @@ def main():
     ctx.sync()
     fence()
     kern_ms = []
+    # HIP events on the launch stream: two bracket the whole timed region (GPU time per step); the kernels of
+    # the LAST timed step are bracketed individually inside qs_count_batch (QS_COUNT_TIMED; bracketing every
+    # launch costs ~5 % of a 0.25 ms step, and reading events inside the loop would synchronise).
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP events are recorded on the launch stream inside qs_count_batch; reading them
-        # here would synchronise, so only the last step's events are read after the loop.
+    ev0.record(stream)
+    for k_ in range(args.steps):
+        step(timed=(k_ == args.steps - 1))
+    ev1.record(stream)
     fence()
     t1 = time.perf_counter()
     ctx.sync()
     elapsed = t1 - t0
+    region_gpu_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
+    last_step_ms = ctx.last_count_ms() if args.steps > 0 else None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -200,7 +206,7 @@ def main():
     use_dist_saved, use_dist = use_dist, False
     # per-kernel durations: an extra, untimed pass that reads the HIP events after every launch
     for _ in range(max(3, min(args.steps, 10))):
-        step()
+        step(timed=True)
         kern_ms.append(ctx.last_count_ms())
     panel_ms = float(np.mean([k[0] for k in kern_ms]))
     count_ms = float(np.mean([k[1] for k in kern_ms]))
@@ -273,6 +279,8 @@ def main():
             "parity_bitslice_equals_swar_impl": impl_match,
             "panel_kernel_ms": panel_ms,
             "count_kernel_ms": count_ms,
+            "count_kernel_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
+            "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
             "score_phase_ms": score_ms,
         },
         "roofline": {
@@ -282,7 +290,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": (("count_bitslice2_kernel" if "x2/" in variant else "count_bitslice_kernel") if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
+            "kernel": (("count_bitslice3_kernel" if "x2/" in variant else "count_bitslice_kernel") if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
             "algorithmic_bytes_per_launch": m * nq * bytes_per_unit,
             "avg_launch_ms": count_ms,
             "note": "achieved = algorithmic RMW bytes of the reference formulation (8 B per tree x quartet) / kernel time; "
@@ -296,14 +304,15 @@ def main():
     # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is, KB -> bytes)
     try:
         if (n, m, args.count_bits, args.table_shards) == (128, 1000, 32, 1):
-            with open(os.path.join(ROOT, "profiles", "r01_final_bench_pmc_hbm.json")) as f:
-                pmc = json.load(f)
+            with open(os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")) as f:
+                pmc = json.load(f)["counters"]
             kname = out["roofline"]["kernel"]
             fk = [v for k_, v in pmc["FETCH_SIZE"].items() if kname in k_]
             wk = [v for k_, v in pmc["WRITE_SIZE"].items() if kname in k_]
             if fk and wk:
-                out["roofline"]["traffic"] = (2 * fk[0]["avg_KB_per_dispatch"] + wk[0]["avg_KB_per_dispatch"]) * 1024
-                out["roofline"]["traffic_source"] = "profiles/r01_final_bench_pmc_hbm.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)"
+                out["roofline"]["traffic"] = (2 * fk[0]["avg_per_dispatch"] + wk[0]["avg_per_dispatch"]) * 1024
+                out["roofline"]["traffic_source"] = ("profiles/r01_final_pmc_summary.json (tools/pmc_collect.sh: rocprofv3 --pmc, "
+                                                     "separate FETCH_SIZE / WRITE_SIZE passes; L2 miss traffic, most of it served by the Infinity Cache)")
     except Exception:
         pass
 

@@ -73,6 +73,9 @@ enum {
 /* OR-ed into `algo`: the table's previous contents are discarded -- same result as qs_table_clear
  * followed by the count, without the extra clear and read passes over the table (gather only) */
 #define QS_COUNT_OVERWRITE 0x100u
+/* OR-ed into `algo`: bracket the kernels of this call with HIP events for qs_last_count_ms (costs ~5 % of a
+ * 0.25 ms batch, so it is off unless asked for) */
+#define QS_COUNT_TIMED 0x200u
 
 /* qs_score flags */
 #define QS_SCORE_QP_WRAP32 0u   /* reference-compatible: QP sums kept mod 2^32 (QuartetScoreComputer.hpp:382) */
@@ -221,8 +224,9 @@ int qs_raw_qic(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, ui
 
 /* ---- measurement hooks ------------------------------------------------------------------ */
 
-/* Device time in milliseconds of the most recent qs_count_batch, split by kernel
- * (HIP events on the context's stream): [0] pair-panel build, [1] count kernel, [2] total. */
+/* Device time in milliseconds of the most recent qs_count_batch that carried QS_COUNT_TIMED, split by kernel
+ * (HIP events on the context's stream): [0] pair-panel build, [1] count kernel, [2] total. QS_ERR_STATE if the
+ * most recent call was not timed. */
 int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);

@@ -12,6 +12,7 @@ QS_OK = 0
 QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEVICE, QS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER = 0, 1, 2
 QS_COUNT_OVERWRITE = 0x100
+QS_COUNT_TIMED = 0x200
 QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
 QS_SCORE_CAND_SLOTS = 8
 

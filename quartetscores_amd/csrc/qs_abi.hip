@@ -34,17 +34,14 @@ struct qs_ctx {
     // geometry
     uint32_t *dprefix = nullptr, *cprefix = nullptr;
     uint32_t n_dblk = 0, total_tiles = 0;
-    uint32_t *dprefix2 = nullptr, *cprefix2 = nullptr; // tiling of the two-a-column kernel
-    uint32_t *dprefix3 = nullptr;                      // same tiles, d-blocks counted down from d_hi (count_bitslice3_kernel)
+    uint32_t *dprefix3 = nullptr, *cprefix3 = nullptr; // tiling of count_bitslice3_kernel (16x8 tiles, d-blocks counted down from d_hi)
     uint32_t total_tiles3 = 0;
-    uint32_t total_tiles2 = 0;
-    uint32_t *gprefix = nullptr, *csuffix = nullptr;   // its group-major order (large n)
-    uint32_t n_groups_off = 0, n_groups = 0;
     // workspace
     void *panel = nullptr;
     size_t panel_bytes = 0;
     uint32_t *dev_flags = nullptr; // [0] counter overflow, [1] score flags
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool last_timed = false;
     bool ev_valid = false;
     std::string variant;
     std::string err;
@@ -119,61 +116,17 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     if (hipMalloc(&c->dprefix, dp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix");
     if (hipMemcpy(c->cprefix, cp.data(), cp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix");
     if (hipMemcpy(c->dprefix, dp.data(), dp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix");
-    {   // the same for the 16x8 tiles of count_bitslice2_kernel
-        std::vector<uint32_t> cp2(n_taxa + 2, 0), dp2(c->n_dblk + 1, 0);
-        for (uint32_t cc = 2; cc <= n_taxa; ++cc) cp2[cc + 1] = cp2[cc] + bitslice2_tiles_for_c(cc);
-        for (uint32_t k = 0; k < c->n_dblk; ++k) {
-            uint32_t d0 = d_start + k * kDB, d1 = std::min(d0 + (uint32_t)kDB, d_hi);
-            dp2[k + 1] = dp2[k] + cp2[d1 - 1];
-        }
-        c->total_tiles2 = dp2[c->n_dblk];
-        std::vector<uint32_t> dp3(c->n_dblk + 1, 0);
-        for (uint32_t k = 0; k < c->n_dblk; ++k) dp3[k + 1] = dp3[k] + cp2[d_hi - k * kDB - 1]; // block k = [max(d_start, d1 - 8), d1), d1 = d_hi - 8k
+    {   // the 16x8 tiles of count_bitslice3_kernel; block k = [max(d_start, d1 - 8), d1) with d1 = d_hi - 8k
+        std::vector<uint32_t> cp3(n_taxa + 2, 0), dp3(c->n_dblk + 1, 0);
+        for (uint32_t cc = 2; cc <= n_taxa; ++cc) cp3[cc + 1] = cp3[cc] + bitslice3_tiles_for_c(cc);
+        uint64_t t3 = 0;
+        for (uint32_t k = 0; k < c->n_dblk; ++k) { t3 += cp3[d_hi - k * kDB - 1]; dp3[k + 1] = (uint32_t)t3; }
+        if (t3 >= (1ull << 31)) return cleanup(QS_ERR_UNSUPPORTED, "qs_create: shard too large for one launch; use a narrower [d_lo, d_hi)");
         c->total_tiles3 = dp3[c->n_dblk];
+        if (hipMalloc(&c->cprefix3, cp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix3");
         if (hipMalloc(&c->dprefix3, dp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix3");
+        if (hipMemcpy(c->cprefix3, cp3.data(), cp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix3");
         if (hipMemcpy(c->dprefix3, dp3.data(), dp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix3");
-        if (hipMalloc(&c->cprefix2, cp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix2");
-        if (hipMalloc(&c->dprefix2, dp2.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix2");
-        if (hipMemcpy(c->cprefix2, cp2.data(), cp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix2");
-        if (hipMemcpy(c->dprefix2, dp2.data(), dp2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix2");
-        // group-major order of the same tile set: group = (b-block, a-pair) or a pair of diagonal blocks;
-        // its tiles are all (c, d-block) with c >= cmin(group) and some d > c in the block
-        if (c->n_dblk > 0 && d_hi >= 4) {
-            const uint32_t c_max = d_hi - 2;
-            std::vector<uint32_t> S(n_taxa + 2, 0); // S[c] = sum_{c' >= c} ndblk(c')
-            for (uint32_t cc = c_max; cc >= 2; --cc) {
-                const uint32_t fk = cc + 2 > d_start + kDB ? (cc + 2 - d_start - kDB + kDB - 1) / kDB : 0u;
-                const uint32_t nd = fk < c->n_dblk ? c->n_dblk - fk : 0u;
-                S[cc] = S[cc + 1] + nd;
-            }
-            S[1] = S[0] = S[2];
-            const uint32_t Tmax = (c_max + 7) / 8; // 8-blocks of ids below the largest c
-            const uint32_t n_off = (Tmax * Tmax) / 4, n_diag = (Tmax + 1) / 2;
-            std::vector<uint32_t> gp(n_off + n_diag + 1, 0);
-            uint64_t acc = 0;
-            uint32_t gi = 0;
-            for (uint32_t Bk = 1; Bk < Tmax; ++Bk)
-                for (uint32_t j = 0; j < (Bk + 1) / 2; ++j) {
-                    const uint32_t cmin = std::max(2u, 8 * Bk + 1);
-                    gp[gi++] = (uint32_t)acc;
-                    acc += cmin <= c_max ? S[cmin] : 0u;
-                }
-            for (uint32_t kd = 0; kd < n_diag; ++kd) {
-                const uint32_t cmin = std::max(2u, 16 * kd + 1);
-                gp[gi++] = (uint32_t)acc;
-                acc += cmin <= c_max ? S[cmin] : 0u;
-            }
-            gp[gi] = (uint32_t)acc;
-            if (gi == n_off + n_diag && acc == c->total_tiles2) { // the two enumerations cover the same tile set
-                c->n_groups_off = n_off; c->n_groups = gi;
-                if (hipMalloc(&c->gprefix, gp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc gprefix");
-                if (hipMalloc(&c->csuffix, S.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc csuffix");
-                if (hipMemcpy(c->gprefix, gp.data(), gp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy gprefix");
-                if (hipMemcpy(c->csuffix, S.data(), S.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy csuffix");
-            } else {
-                return cleanup(QS_ERR_STATE, "internal: group-major tile count " + std::to_string(acc) + " != " + std::to_string(c->total_tiles2));
-            }
-        }
     }
     if (hipMalloc(&c->dev_flags, 16) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc flags");
     if (hipMemset(c->dev_flags, 0, 16) != hipSuccess) return cleanup(QS_ERR_HIP, "memset flags");
@@ -190,11 +143,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->panel) (void)hipFree(c->panel);
     if (c->dprefix) (void)hipFree(c->dprefix);
     if (c->cprefix) (void)hipFree(c->cprefix);
-    if (c->dprefix2) (void)hipFree(c->dprefix2);
     if (c->dprefix3) (void)hipFree(c->dprefix3);
-    if (c->cprefix2) (void)hipFree(c->cprefix2);
-    if (c->gprefix) (void)hipFree(c->gprefix);
-    if (c->csuffix) (void)hipFree(c->csuffix);
+    if (c->cprefix3) (void)hipFree(c->cprefix3);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
     for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -368,11 +318,12 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     if (c->count_bits == 16 && ((algo & QS_COUNT_OVERWRITE) ? 0 : c->trees_counted) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "qs_count_batch: more than 65535 trees need count_bits = 32");
     const bool overwrite = (algo & QS_COUNT_OVERWRITE) != 0;
-    algo &= ~QS_COUNT_OVERWRITE;
+    const bool timed = (algo & QS_COUNT_TIMED) != 0;
+    algo &= ~(QS_COUNT_OVERWRITE | QS_COUNT_TIMED);
     if (algo == QS_ALGO_AUTO) algo = QS_ALGO_GATHER;
     if (overwrite && algo != QS_ALGO_GATHER) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_COUNT_OVERWRITE needs the gather algorithm");
     if (overwrite) c->trees_counted = 0;
-    QS_HIP(c, hipEventRecord(c->ev[0], c->stream));
+    if (timed) QS_HIP(c, hipEventRecord(c->ev[0], c->stream));
     if (algo == QS_ALGO_GATHER) {
         int mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
         static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
@@ -396,13 +347,13 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         // Two things that did NOT help (profiles/r01_experiments.md): visiting the tree groups in rotated order so
         // that late tiles stay in phase with the resident ones (the panel still streams from HBM once per
         // round of tiles), and non-temporal table accesses.
-        // binary_full batches use the kernel with two a-columns per lane (QS_BITSLICE_TILE=1 selects the plain one)
+        // binary_full batches use count_bitslice3_kernel (two a-columns per lane, compact panel);
+        // QS_BITSLICE_TILE=1 forces the general one-column kernel (tests / A-B runs)
         const char *tile_env = getenv("QS_BITSLICE_TILE");
-        const bool two_a = use_bitslice && mode == MODE_BINARY_FULL && !(tile_env && tile_env[0] == '1');
+        const bool v3 = use_bitslice && mode == MODE_BINARY_FULL && !(tile_env && tile_env[0] == '1');
         int bits = 8;
         uint32_t tpc;            // trees per panel element
         size_t elem_bytes;       // bytes per (pair, element)
-        const bool v3 = two_a && !(tile_env && tile_env[0] == '2');
         const uint32_t compact_nw = v3 ? std::max(depth_bits, 4u) : 0u; // count_bitslice3_kernel reads the compact panel
         if (use_bitslice) { tpc = 32; elem_bytes = v3 ? compact_nw * 4 : 32; }
         else {
@@ -432,39 +383,29 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             sub.n_trees = nt;
             if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
-            if (ch0 == 0) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
+            if (ch0 == 0 && timed) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
             if (v3) {
                 CountGeometry g3 = g;
-                g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix2;
+                g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3;
                 QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
-            } else if (use_bitslice && two_a) {
-                CountGeometry g2 = g;
-                g2.total_tiles = c->total_tiles2; g2.dprefix = c->dprefix2; g2.cprefix = c->cprefix2;
-                // QS_TILE_ORDER=group selects the group-major order (meant to reuse the private M[ab] elements in L2).
-                // Measured at 512 taxa x 10000 trees: 0.900 s vs 0.867 s for the plain order, so it stays opt-in.
-                const char *oe = getenv("QS_TILE_ORDER");
-                const bool group_major = oe && std::string(oe) == "group";
-                if (group_major && c->n_groups) {
-                    g2.n_groups_off = c->n_groups_off; g2.n_groups = c->n_groups; g2.gprefix = c->gprefix; g2.csuffix = c->csuffix;
-                }
-                QS_HIP(c, launch_count_bitslice2(c->stream, g2, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             } else if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }
         if (use_bitslice)
-            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (two_a ? ((tile_env && tile_env[0] == '2') ? "x2" : "x2v3") : "") + "/count_u" + std::to_string(c->count_bits);
+            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (v3 ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
         else
             c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");
-        QS_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        if (timed) QS_HIP(c, hipEventRecord(c->ev[1], c->stream));
         QS_HIP(c, launch_count_scatter(c->stream, d, c->n, c->d_lo, c->d_hi, c->rank_lo, c->table, (int)c->count_bits));
         c->variant = std::string("scatter/atomic/count_u") + std::to_string(c->count_bits);
     } else {
         return fail(c, QS_ERR_ARG, "qs_count_batch: unknown algo");
     }
-    QS_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    if (timed) QS_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    c->last_timed = timed;
     c->ev_valid = true;
     c->trees_counted += d.n_trees;
     return QS_OK;
@@ -494,7 +435,7 @@ extern "C" int qs_count_trees(qs_ctx *c, const qs_tree_batch *batch, uint32_t al
 }
 
 extern "C" int qs_last_count_ms(qs_ctx *c, float out_ms[3]) {
-    if (!c || !c->ev_valid) return fail(c, QS_ERR_STATE, "qs_last_count_ms: no count yet");
+    if (!c || !c->ev_valid || !c->last_timed) return fail(c, QS_ERR_STATE, "qs_last_count_ms: the last qs_count_batch did not carry QS_COUNT_TIMED");
     QS_HIP(c, hipEventSynchronize(c->ev[2]));
     QS_HIP(c, hipEventElapsedTime(&out_ms[0], c->ev[0], c->ev[1]));
     QS_HIP(c, hipEventElapsedTime(&out_ms[1], c->ev[1], c->ev[2]));

@@ -533,10 +533,114 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
     }
 }
 
+// Small-n variant (the tables of all 32 trees of a group fit in LDS together, n <= ~256): workgroup = (group,
+// 1024 pairs), 16 waves. Phase 1: every wave builds the leaf positions and the sparse table (u8: depths are
+// < 128 whenever the bit-plane panel is used) of two trees in its own LDS region. Phase 2: thread = pair; it
+// answers its pair's query in all 32 trees and assembles the planes in registers -- no byte staging, no
+// transposition pass, and the tables are built 4x less often than with 256-pair workgroups. 128 taxa x 1000
+// trees: 35 us -> see DESIGN.md.
+constexpr int kBPSThreads = 1024;
+template <bool PARTIAL, int NWC>
+__global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const uint32_t *__restrict__ leaf_off,
+                                                                          const uint16_t *__restrict__ leaf_ids,
+                                                                          const uint16_t *__restrict__ adj_depth,
+                                                                          uint32_t n_trees, uint32_t n, uint32_t npairs,
+                                                                          uint32_t levels, uint32_t tree_bytes,
+                                                                          uint4 *__restrict__ Pb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const uint32_t g = blockIdx.y, p0 = blockIdx.x * kBPSThreads;
+    constexpr int kWaves = kBPSThreads / kWave;
+
+    for (int j = (int)wave; j < kBitTrees; j += kWaves) {
+        const uint32_t t = g * kBitTrees + j;
+        if (t >= n_trees) continue;
+        uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)j * tree_bytes); // [n]
+        uint8_t *st = reinterpret_cast<uint8_t *>(pos + n);                          // [levels][n]
+        const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
+        for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
+        for (uint32_t i = lane; i < L; i += kWave) {
+            pos[leaf_ids[base + i]] = (uint16_t)i;
+            st[i] = (uint8_t)adj_depth[base + i];
+        }
+        for (uint32_t k = 1; k < levels; ++k) {
+            const uint32_t half = 1u << (k - 1), span = 1u << k;
+            if (span + 1 <= L)
+                for (uint32_t i = lane; i + span <= L - 1; i += kWave)
+                    st[k * n + i] = min(st[(k - 1) * n + i], st[(k - 1) * n + i + half]);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t p = p0 + tid;
+    if (p >= npairs) return;
+    uint32_t x, y;
+    unrank2(p, x, y);
+    constexpr int kPlanes = NWC ? NWC : 7;
+    uint32_t w[kBitWords];
+#pragma unroll
+    for (int k = 0; k < kBitWords; ++k) w[k] = 0;
+#pragma unroll
+    for (int j = 0; j < kBitTrees; ++j) {
+        const uint32_t t = g * kBitTrees + j;
+        if (t >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
+            if (!PARTIAL) w[7] |= 1u << j;
+            continue;
+        }
+        const uint16_t *pos = reinterpret_cast<const uint16_t *>(smem + (size_t)j * tree_bytes);
+        const uint8_t *st = reinterpret_cast<const uint8_t *>(pos + n);
+        const uint32_t a = pos[x], b = pos[y];
+        if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) continue;
+        const uint32_t lo = min(a, b), hi = max(a, b), len = hi - lo;
+        const uint32_t k = 31u - (uint32_t)__clz((int)len);
+        const uint32_t val = min((uint32_t)st[k * n + lo], (uint32_t)st[k * n + hi - (1u << k)]);
+#pragma unroll
+        for (int q = 0; q < kPlanes; ++q) w[q] |= ((val >> q) & 1u) << j;
+        w[7] |= 1u << j;
+    }
+    if (NWC) {
+        char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * NWC * 4;
+        reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
+        uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
+#pragma unroll
+        for (int k = 4; k < NWC; ++k) hi[k - 4] = w[k];
+    } else {
+        uint4 *dst = Pb + ((size_t)g * npairs + p) * 2;
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
 hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel,
                                  uint32_t n_groups, uint32_t compact_nw) {
     const uint32_t npairs = (uint32_t)binom2(n);
     const uint32_t levels = panel_levels(n);
+    {   // all 32 trees' tables resident at once -> the small-n kernel
+        const uint32_t tree_bytes = (n * 2 + levels * n + 3) & ~3u;
+        const size_t lds_small = (size_t)kBitTrees * tree_bytes;
+        const char *pe = getenv("QS_PANEL_KERNEL"); // "big" forces the general kernel (tests / A-B runs)
+        if (lds_small <= 96 * 1024 && !(pe && pe[0] == 'b') && (compact_nw == 0 || !partial)) {
+            dim3 grid((npairs + kBPSThreads - 1) / kBPSThreads, n_groups), block(kBPSThreads);
+#define QS_BPS(PART, NWC)                                                                                          \
+    do {                                                                                                           \
+        auto k = build_bitpanel_small_kernel<PART, NWC>;                                                           \
+        if (lds_small > 48 * 1024) {                                                                               \
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small); \
+            if (e != hipSuccess) return e;                                                                         \
+        }                                                                                                          \
+        hipLaunchKernelGGL(k, grid, block, lds_small, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
+                           tree_bytes, (uint4 *)panel);                                                            \
+    } while (0)
+            if (compact_nw == 0) { if (partial) QS_BPS(true, 0); else QS_BPS(false, 0); }
+            else if (compact_nw <= 4) QS_BPS(false, 4);
+            else if (compact_nw == 5) QS_BPS(false, 5);
+            else if (compact_nw == 6) QS_BPS(false, 6);
+            else QS_BPS(false, 7);
+#undef QS_BPS
+            return hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)kBPPB * kBitTrees + (size_t)(kBPThreads / kWave) * n * 2 * (1 + levels);
     dim3 grid((npairs + kBPPB - 1) / kBPPB, n_groups), block(kBPThreads);
     if (partial) {
@@ -574,17 +678,6 @@ template <bool HI> __device__ __forceinline__ Planes load_planes(const uint4 *p)
     else { r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0; }
     return r;
 }
-// NW = number of leading words of the 8-word panel element that are live (4..8): loads exactly those
-template <int NW> __device__ __forceinline__ Planes load_planes_nw(const char *base, uint32_t byte_off) {
-    Planes r;
-    const uint4 lo = *reinterpret_cast<const uint4 *>(base + byte_off);
-    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
-    r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
-    if (NW == 5) r.w[4] = *reinterpret_cast<const uint32_t *>(base + byte_off + 16);
-    else if (NW == 6) { const uint2 h = *reinterpret_cast<const uint2 *>(base + byte_off + 16); r.w[4] = h.x; r.w[5] = h.y; }
-    else if (NW >= 7) { const uint4 h = *reinterpret_cast<const uint4 *>(base + byte_off + 16); r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
-    return r;
-}
 // LDS image with HW (1, 2 or 4) upper words per slot: words 0..3 at buf[e], the upper words in an array
 // of HW-word records behind the `stride` 16-byte slots
 template <int HW> __device__ __forceinline__ Planes lds_load_hw(const uint4 *buf, uint32_t e, int stride) {
@@ -602,11 +695,6 @@ template <int HW> __device__ __forceinline__ void lds_store_hw(uint4 *buf, uint3
     if (HW == 1) reinterpret_cast<uint32_t *>(buf + stride)[e] = r.w[4];
     else if (HW == 2) reinterpret_cast<uint2 *>(buf + stride)[e] = make_uint2(r.w[4], r.w[5]);
     else buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
-}
-// uniform base + 32-bit per-lane byte offset: lets hipcc use the SGPR-base addressing mode of global_load
-// instead of 64-bit per-lane pointer arithmetic
-template <bool HI> __device__ __forceinline__ Planes load_planes_off(const char *base, uint32_t byte_off) {
-    return load_planes<HI>(reinterpret_cast<const uint4 *>(base + byte_off));
 }
 // LDS image: words 0..3 of element e at buf[e], words 4..7 at buf[kBsElems + e] (consecutive lanes ->
 // consecutive 16-byte slots: no bank conflicts)
@@ -847,342 +935,35 @@ __global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uin
     }
 }
 
-// ---- binary_full variant with TWO a-columns per lane ---------------------------------------------
-// Same arithmetic; the tile is 16 a x 8 b: lane (ia, ib) owns a1 = 8*A1+ia, a2 = 8*A2+ia and b = 8*Bk+ib
-// (A1 < A2 < Bk are 8-blocks of ids below c; A2 may be absent). The staged R element of (b,d) is read
-// from LDS once and compared against both L(a1,b,c) and L(a2,b,c): LDS reads, staging loads and LDS
-// writes per quartet drop by ~40 %. Diagonal tiles keep the packing of count_bitslice_kernel (two
-// diagonal blocks per wave, one a per lane). Staged slots: row * 24 + col, cols 0..7 = block A1,
-// 8..15 = block A2, 16..23 = block Bk; an off-diagonal tile fills row 0 at cols 0..15 and rows 1..kDB at
-// cols 16..23 (80 elements), a diagonal tile rows 0..kDB at cols 0..15 (144).
-constexpr int kCols2 = 3 * kTA;
-constexpr int kBs2Slots = (1 + kDB) * kCols2;          // 216
-constexpr int kBs2PerLane = 3;                         // max(80, 144) / 64 rounded up
-
-uint32_t bitslice2_tiles_for_c(uint32_t c) {
-    const uint32_t T = (c + kTB - 1) / kTB;
-    return (T * T) / 4 + (T + 1) / 2; // pairs of a-blocks below every b-block + pairs of diagonal blocks
-}
-
-// in-kernel stamps (diagnostic build only, QS_STAMP=<file>): shader-clock cycles per section, summed per wave
-#define QS_STAMP_T(t)                                                                                     \
-    do {                                                                                                  \
-        if (STAMP) {                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");                    \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
-        }                                                                                                 \
-    } while (0)
-
-template <int B, typename CT, bool STAMP>
-__global__ __launch_bounds__(kCountThreads) void count_bitslice2_kernel(const uint4 *__restrict__ P, uint32_t npairs,
-                                                                        uint32_t n_groups, uint32_t m_trees, uint32_t n,
-                                                                        uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
-                                                                        uint32_t n_dblk, uint32_t total_tiles,
-                                                                        const uint32_t *__restrict__ dprefix,
-                                                                        const uint32_t *__restrict__ cprefix,
-                                                                        uint32_t n_groups_off, uint32_t n_groups_all,
-                                                                        const uint32_t *__restrict__ gprefix,
-                                                                        const uint32_t *__restrict__ csuffix,
-                                                                        CT *__restrict__ table,
-                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
-                                                                        unsigned long long *__restrict__ stamps) {
-    constexpr int NB = B + 1;
-    constexpr int NW = B < 4 ? 4 : B;                                  // live words of a raw panel element (planes of M)
-    constexpr int HW = NB <= 5 ? 1 : (NB == 6 ? 2 : 4);                // upper words of an LDS slot (R has B+1 planes)
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tb = 0, te = 0;
-    unsigned long long acc_issue = 0, acc_l = 0, acc_slots = 0, acc_commit = 0;
-    QS_STAMP_T(tb);
-    constexpr int kImg = kBs2Slots + (kBs2Slots * HW + 3) / 4;         // uint4 slots per wave and buffer
-    __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
-
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    uint4(*stage)[kImg] = stage_all[wave];
-
-    // ---- tile decode (wave-uniform) ----
-    uint32_t tile, k, c, d0, d1, tl, n_off;
-    if (n_groups_all == 0) {
-        // order (d-block, c, tile): consecutive workgroups sweep the (a,b) tiles of one (d-block, c)
-        tile = blockIdx.x * kWavesPerBlock + wave;
-        if (tile >= total_tiles) return;
-        k = upper_bound_le(dprefix, 0, n_dblk, tile);
-        const uint32_t local = tile - dprefix[k];
-        d0 = d_lo + k * kDB;
-        d1 = min(d0 + (uint32_t)kDB, d_hi);
-        c = upper_bound_le(cprefix, 2, d1 - 1, local);
-        const uint32_t T = (c + kTB - 1) / kTB;
-        n_off = (T * T) / 4;
-        tl = local - cprefix[c];
-    } else {
-        // GROUP-MAJOR order for large n: the slowest index is the (b-block, a-pair) group, whose private
-        // M[ab] elements are 60 % of a wave's panel traffic; all (c, d-block) combinations of one group
-        // follow each other. Workgroups with the same blockIdx % 8 share an XCD (observed dispatch
-        // rule, used for speed only), so the logical tile list is cut into 8 contiguous parts, one per XCD:
-        // the ~500 waves resident on an XCD then work on the same group and hit its M[ab] elements in L2.
-        const uint32_t nb = gridDim.x, bx = blockIdx.x;
-        const uint32_t q8 = nb / 8, r8 = nb % 8, xcd = bx % 8, y = bx / 8;
-        const uint32_t lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + y; // bijective
-        tile = lb * kWavesPerBlock + wave;
-        if (tile >= total_tiles) return;
-        const uint32_t g = upper_bound_le(gprefix, 0, n_groups_all, tile);
-        const uint32_t qq = tile - gprefix[g];
-        uint32_t cmin;
-        if (g < n_groups_off) {
-            uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)g + 1.0f));
-            while ((Bk * Bk) / 4 > g) --Bk;
-            while (((Bk + 1) * (Bk + 1)) / 4 <= g) ++Bk;
-            cmin = max(2u, kTB * Bk + 1);
-        } else {
-            cmin = max(2u, 2 * kTA * (g - n_groups_off) + 1);
-        }
-        // combos are ordered by c ascending, then d-block: offset(c) = S[cmin] - S[c]
-        const uint32_t s0 = csuffix[cmin];
-        uint32_t lo = cmin, hi = d_hi - 1; // largest c in [cmin, d_hi-2] with S[cmin] - S[c] <= qq
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s0 - csuffix[mid] <= qq) lo = mid; else hi = mid; }
-        c = lo;
-        const uint32_t dstart = d_lo; // first d of d-block 0 (the launcher passes max(shard d_lo, 3))
-        const uint32_t fk = c + 2 > dstart + kDB ? (c + 2 - dstart - kDB + kDB - 1) / kDB : 0u; // first d-block with some d > c
-        k = fk + (qq - (s0 - csuffix[c]));
-        d0 = d_lo + k * kDB;
-        d1 = min(d0 + (uint32_t)kDB, d_hi);
-        const uint32_t T = (c + kTB - 1) / kTB;
-        n_off = (T * T) / 4;
-        tl = g < n_groups_off ? g : n_off + (g - n_groups_off);
-    }
-    const bool offdiag = tl < n_off;
-    uint32_t blk[3];                 // id block of column groups 0..7, 8..15, 16..23 (0xFFFFFFFF = absent)
-    uint32_t a1, a2, b, colA1, colA2, colB;
-    if (offdiag) {
-        // b-block Bk = largest k with floor(k*k/4) <= tl
-        uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f));
-        while ((Bk * Bk) / 4 > tl) --Bk;
-        while (((Bk + 1) * (Bk + 1)) / 4 <= tl) ++Bk;
-        const uint32_t j = tl - (Bk * Bk) / 4;
-        blk[0] = 2 * j; blk[1] = (2 * j + 1 < Bk) ? 2 * j + 1 : 0xFFFFFFFFu; blk[2] = Bk;
-        const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
-        colA1 = ia; colA2 = kTA + ia; colB = 2 * kTA + ib;
-        a1 = blk[0] * kTA + ia;
-        a2 = blk[1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : blk[1] * kTA + ia;
-        b = Bk * kTB + ib;
-    } else {
-        const uint32_t kd = tl - n_off;
-        blk[0] = 2 * kd; blk[1] = 2 * kd + 1; blk[2] = 0xFFFFFFFFu;
-        const uint32_t h = lane >> 5, q = lane & 31;
-        uint32_t ia = 0, ib = 1;
-        if (q < 28) unrank2(q, ia, ib);
-        colA1 = h * kTA + ia; colA2 = colA1; colB = h * kTA + ib;
-        a1 = blk[h] * kTA + ia; a2 = 0xFFFFFFFFu;
-        b = q < 28 ? blk[h] * kTA + ib : 0xFFFFFFFFu;
-    }
-    const bool has_a2 = offdiag && blk[1] != 0xFFFFFFFFu; // wave-uniform
-    const bool v1 = (a1 < b) && (b < c);
-    const bool v2 = has_a2 && (a2 < b) && (b < c);
-    const uint32_t pi1 = v1 ? (uint32_t)binom2(b) + a1 : 0u;
-    const uint32_t pi2 = v2 ? (uint32_t)binom2(b) + a2 : 0u;
-
-    const uint32_t n_stage = offdiag ? (uint32_t)(2 * kTA + kDB * kTB) : (uint32_t)((1 + kDB) * 2 * kTA);
-    uint32_t src[kBs2PerLane], sub[kBs2PerLane], slot[kBs2PerLane];
-#pragma unroll
-    for (int s = 0; s < kBs2PerLane; ++s) {
-        const uint32_t e = lane + s * kWave;
-        uint32_t p = 0u, q = 0xFFFFFFFFu, sl = 0u;
-        if (e < n_stage) {
-            uint32_t row, col;
-            if (offdiag) {
-                if (e < (uint32_t)(2 * kTA)) { row = 0; col = e; }
-                else { row = 1 + (e - 2 * kTA) / kTB; col = 2 * kTA + (e - 2 * kTA) % kTB; }
-            } else { row = e / (2 * kTA); col = e % (2 * kTA); }
-            sl = row * kCols2 + col;
-            const uint32_t bk = blk[col / kTA];
-            const uint32_t x = bk == 0xFFFFFFFFu ? 0xFFFFFFFFu : bk * kTA + (col % kTA);
-            const uint32_t y = row == 0 ? c : d0 + (row - 1);
-            const bool ok = x < c && y < d1 && (row == 0 || y > c);
-            if (ok) p = (uint32_t)binom2(y) + x;
-            if (row != 0) q = ok ? (uint32_t)binom2(y) + c : 0u;
-        }
-        src[s] = p; sub[s] = q; slot[s] = sl;
-    }
-    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
-
-    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB]; // counters of (a1,b) and (a2,b)
-#pragma unroll
-    for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
-
-    Planes xr[kBs2PerLane], yr[kBs2PerLane], ab1_next, ab2_next;
-    // byte offsets inside one tree group of the panel (a group is npairs * 32 bytes <= 17 MB at 1024 taxa)
-    uint32_t xoff[kBs2PerLane], yoff[kBs2PerLane];
-#pragma unroll
-    for (int s = 0; s < kBs2PerLane; ++s) { xoff[s] = src[s] * 32u; yoff[s] = sub[s] == 0xFFFFFFFFu ? 0u : sub[s] * 32u; }
-    const uint32_t ab1off = pi1 * 32u, ab2off = pi2 * 32u;
-    auto issue = [&](const uint4 *Pg) {
-        const char *base = reinterpret_cast<const char *>(Pg);
-#pragma unroll
-        for (int s = 0; s < kBs2PerLane; ++s) {
-            if (lane + s * kWave < n_stage) {
-                xr[s] = load_planes_nw<NW>(base, xoff[s]);
-                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes_nw<NW>(base, yoff[s]);
-            }
-        }
-        ab1_next = load_planes_nw<NW>(base, ab1off);
-        if (has_a2) ab2_next = load_planes_nw<NW>(base, ab2off);
-    };
-    auto commit = [&](int bufi) {
-#pragma unroll
-        for (int s = 0; s < kBs2PerLane; ++s) {
-            if (lane + s * kWave < n_stage) {
-                Planes x = xr[s];
-                if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]);
-                lds_store_hw<HW>(stage[bufi], slot[s], kBs2Slots, x);
-            }
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < kBs2PerLane; ++s)
-#pragma unroll
-        for (int k2 = 0; k2 < kBitWords; ++k2) { xr[s].w[k2] = 0; yr[s].w[k2] = 0; }
-#pragma unroll
-    for (int k2 = 0; k2 < kBitWords; ++k2) ab2_next.w[k2] = 0;
-    issue(P);
-    commit(0);
-
-    unsigned long long tl0 = 0;
-    QS_STAMP_T(tl0);
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        QS_STAMP_T(t0);
-        const Planes ab1 = ab1_next, ab2 = ab2_next;
-        const uint4 *buf = stage[g & 1];
-        if (g + 1 < n_groups) issue(P + (size_t)(g + 1) * npairs * 2);
-        QS_STAMP_T(t1);
-        const Planes L1 = sub_biased<B>(ab1, lds_load_hw<HW>(buf, colA1, kBs2Slots));
-        Planes L2 = L1;
-        if (has_a2) L2 = sub_biased<B>(ab2, lds_load_hw<HW>(buf, colA2, kBs2Slots));
-        QS_STAMP_T(t2);
-        // the R element of slot j+1 is requested from LDS before slot j is computed (rows of slots outside
-        // [jlo, jhi) hold don't-care data, reading them is harmless). Requesting all kDB up front was slower:
-        // +35 VGPRs, 3 instead of 4 waves per SIMD.
-        Planes Rnext = lds_load_hw<HW>(buf, kCols2 + colB, kBs2Slots);
-#pragma unroll
-        for (int j = 0; j < kDB; ++j) {
-            const Planes Rb = Rnext;
-            if (j + 1 < kDB) Rnext = lds_load_hw<HW>(buf, (2 + j) * kCols2 + colB, kBs2Slots);
-            if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
-                uint32_t gt, lt;
-                cmp_planes<NB>(L1, Rb, gt, lt);
-                popc_acc(gt, x0[j]);
-                popc_acc(lt, x1[j]);
-                if (has_a2) {
-                    uint32_t gt2, lt2;
-                    cmp_planes<NB>(L2, Rb, gt2, lt2);
-                    popc_acc(gt2, y0[j]);
-                    popc_acc(lt2, y1[j]);
-                }
-            }
-        }
-        QS_STAMP_T(t3);
-        if (g + 1 < n_groups) commit((g + 1) & 1);
-        QS_STAMP_T(t4);
-        if (STAMP) { acc_issue += t1 - t0; acc_l += t2 - t1; acc_slots += t3 - t2; acc_commit += t4 - t3; }
-    }
-    unsigned long long tl1 = 0;
-    QS_STAMP_T(tl1);
-
-    const uint64_t rcb = binom3(c);
-#pragma unroll
-    for (int j = 0; j < kDB; ++j) {
-        const uint32_t d = d0 + j;
-        if (d < d1 && d > c) {
-            const uint64_t base = binom4(d) + rcb - rank_lo;
-            if (v1) {
-                const uint64_t idx = (base + pi1) * 3;
-                uint32_t w0 = x0[j], w1 = x1[j], w2 = m_trees - x0[j] - x1[j];
-                if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
-                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
-                table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
-            }
-            if (v2) {
-                const uint64_t idx = (base + pi2) * 3;
-                uint32_t w0 = y0[j], w1 = y1[j], w2 = m_trees - y0[j] - y1[j];
-                if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
-                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
-                table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
-            }
-        }
-    }
-    if (STAMP) {
-        QS_STAMP_T(te);
-        if (lane == 0) {
-            unsigned long long *o = stamps + (size_t)tile * 8;
-            o[0] = tl0 - tb; o[1] = acc_issue; o[2] = acc_l; o[3] = acc_slots; o[4] = acc_commit; o[5] = te - tl1; o[6] = te - tb; o[7] = n_groups;
-        }
-    }
-}
-
-hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
-                                  uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
-                                  bool overwrite) {
-    if (g.total_tiles == 0) return hipSuccess;
-    const uint32_t npairs = (uint32_t)binom2(g.n);
-    dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
-    // QS_STAMP=<file>: run the stamped diagnostic instance once and append the per-section cycle shares
-    const char *stamp_path = getenv("QS_STAMP");
-    if (stamp_path && count_bits == 32 && depth_bits <= 4) {
-        unsigned long long *dst = nullptr;
-        const size_t nb = (size_t)g.total_tiles * 8 * sizeof(unsigned long long);
-        if (hipMalloc(&dst, nb) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemsetAsync(dst, 0, nb, s);
-        hipLaunchKernelGGL((count_bitslice2_kernel<4, uint32_t, true>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,
-                           m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,
-                           g.n_groups_off, g.n_groups, g.gprefix, g.csuffix,
-                           (uint32_t *)table, overflow_flag, overwrite ? 1u : 0u, dst);
-        std::vector<unsigned long long> h((size_t)g.total_tiles * 8);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h.data(), dst, nb, hipMemcpyDeviceToHost);
-        (void)hipFree(dst);
-        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t t = 0; t < g.total_tiles; ++t) for (int k2 = 0; k2 < 8; ++k2) sum[k2] += (double)h[t * 8 + k2];
-        if (FILE *f = fopen(stamp_path, "a")) {
-            fprintf(f, "tiles %u groups %.0f | cycles per wave: prologue %.0f  issue %.0f  L %.0f  slots %.0f  commit %.0f  epilogue %.0f  total %.0f\n",
-                    g.total_tiles, sum[7] / g.total_tiles, sum[0] / g.total_tiles, sum[1] / g.total_tiles, sum[2] / g.total_tiles,
-                    sum[3] / g.total_tiles, sum[4] / g.total_tiles, sum[5] / g.total_tiles, sum[6] / g.total_tiles);
-            fclose(f);
-        }
-        return hipGetLastError();
-    }
-#define QS_BS2(BB, CT)                                                                                              \
-    hipLaunchKernelGGL((count_bitslice2_kernel<BB, CT, false>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups,  \
-                       m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
-                       g.n_groups_off, g.n_groups, g.gprefix, g.csuffix,                                            \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, (unsigned long long *)nullptr)
-#define QS_BS2_B(CT)                                                                                                \
-    do {                                                                                                            \
-        if (depth_bits <= 4) QS_BS2(4, CT);                                                                         \
-        else if (depth_bits == 5) QS_BS2(5, CT);                                                                    \
-        else if (depth_bits == 6) QS_BS2(6, CT);                                                                    \
-        else QS_BS2(7, CT);                                                                                         \
-    } while (0)
-    if (count_bits == 32) QS_BS2_B(uint32_t); else QS_BS2_B(uint16_t);
-#undef QS_BS2_B
-#undef QS_BS2
-    return hipGetLastError();
-}
-
 // ======================================================================================
 // count_bitslice3_kernel: the binary_full fast path (every tree holds all taxa and is binary)
 // ======================================================================================
-// Same tile as the two-column kernel above (wave = d-block of 8 x c x (16 a x 8 b)), rebuilt around what its
-// ISA showed: 60 % of the instructions of one 32-tree step were not comparison chains. Differences:
-//   * panel reads are raw BUFFER loads: the per-lane byte offset inside one tree group is loop-invariant, the
+// Same arithmetic as count_bitslice_kernel, two topologies counted (the third is m minus the other two), and TWO
+// a-columns per lane: the tile is 16 a x 8 b, lane (ia, ib) owns a1 = 8*A1+ia, a2 = 8*A2+ia and b = 8*Bk+ib
+// (A1 < A2 < Bk are 8-blocks of ids below c; A2 is absent in the last tile of an odd Bk). The staged R element of
+// (b,d) is read from LDS once and compared against both L(a1,b,c) and L(a2,b,c). Diagonal tiles keep the packing
+// of count_bitslice_kernel (two diagonal blocks per wave, one a per lane).
+// The step over 32 trees is built around what the ISA of its predecessor showed (60 % of the instructions were not
+// comparison chains; profiles/r01_experiments.md):
+//   * the panel is COMPACT: per tree group uint4 lo[npairs] (planes 0..3) followed by the B-4 upper planes per
+//     pair, so a 16-byte load fetches only live data (build_bitpanel_kernel, compact_nw);
+//   * panel reads are raw BUFFER loads: the per-lane offset inside one tree group is loop-invariant, the
 //     group advances through the (scalar) base address of the resource, lanes with nothing to load use an
 //     out-of-range offset and get zeros -- no 64-bit address arithmetic and no exec masking in the loop;
 //   * staging is branch-free: lane l owns R element (d-row l/8, b-column l%8), lanes 0..15 also own the
 //     M[x,c] element of a-column l;
-//   * the 32-tree step is unrolled twice with the two register sets / LDS buffers swapping roles, so the
+//   * the step is unrolled twice with the two register sets / LDS buffers swapping roles, so the
 //     double buffering costs no register moves;
 //   * the step is instantiated for (second a-column present, all 8 d slots live, diagonal tile) and the wave
 //     picks its instance once: the hot instance has no branches inside the step;
 //   * d-blocks are aligned to the TOP of the shard (the partial block is the one with the smallest ids, where
 //     c < d leaves few tiles): 7 % fewer tiles at 128 taxa, 81 % instead of 65 % of them with all slots live.
+// LDS image per wave and buffer: slots 0..127 = R elements (d-row * 16 + b-column), 128..143 = M[x,c].
+uint32_t bitslice3_tiles_for_c(uint32_t c) {
+    const uint32_t T = (c + kTB - 1) / kTB;
+    return (T * T) / 4 + (T + 1) / 2; // pairs of a-blocks below every b-block + pairs of diagonal blocks
+}
+
 constexpr int kS3RSlots = kDB * 16;            // R elements: slot = d-row * 16 + b-column (0..15)
 constexpr int kS3Row0 = kS3RSlots;             // 16 elements M[x,c] of the a-columns
 constexpr int kS3Slots = kS3RSlots + 16;       // 144

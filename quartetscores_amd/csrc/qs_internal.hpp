@@ -43,10 +43,6 @@ struct CountGeometry {
     uint32_t total_tiles;
     const uint32_t *dprefix; // device, n_dblk+1
     const uint32_t *cprefix; // device, n+1
-    // group-major tile order of count_bitslice2_kernel (0 groups = use the (d-block, c, tile) order above)
-    uint32_t n_groups_off = 0, n_groups = 0; // off-diagonal (b-block, a-pair) groups, then diagonal-pair groups
-    const uint32_t *gprefix = nullptr;       // device, n_groups+1: tiles before group g
-    const uint32_t *csuffix = nullptr;       // device, n+2: S[c] = sum over c' >= c of the d-blocks holding some d > c'
 };
 
 // qs_count.hip
@@ -63,10 +59,7 @@ hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const vo
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite);
-uint32_t bitslice2_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of the two-a-column kernel
-hipError_t launch_count_bitslice2(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
-                                  uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
-                                  bool overwrite);
+uint32_t bitslice3_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of count_bitslice3_kernel
 hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
                                 uint64_t rank_lo, void *table, int count_bits);
 hipError_t launch_pack16(hipStream_t s, const void *table_u32, void *dst, uint64_t n_cells, uint32_t *overflow_flag);

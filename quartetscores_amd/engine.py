@@ -18,7 +18,7 @@ from typing import Iterable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 
 from . import _lib, flatten, newick
-from ._lib import (QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_COUNT_OVERWRITE, QS_SCORE_QP_EXACT64,  # noqa: F401
+from ._lib import (QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_COUNT_OVERWRITE, QS_COUNT_TIMED, QS_SCORE_QP_EXACT64,  # noqa: F401
                    QS_SCORE_QP_WRAP32)
 
 

@@ -64,12 +64,16 @@ CASES = [
 
 @pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES)
 @pytest.mark.parametrize("count_bits", [32, 16])
-@pytest.mark.parametrize("impl", ["bitslice", "bitslice1", "swar"])
+@pytest.mark.parametrize("impl", ["bitslice", "bitslice1", "bitslice_bigpanel", "swar"])
 def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, rooted, seed, variant, count_bits, impl):
     """All gather implementations: bit-sliced (default; binary_full batches take the kernel with two a-columns
-    per lane, "bitslice1" forces the one-column kernel) and the byte-SWAR one (fallback for deep trees)."""
+    per lane, "bitslice1" forces the one-column kernel, "bitslice_bigpanel" the panel builder meant for
+    n > ~256) and the byte-SWAR one (fallback for deep trees)."""
     if impl == "bitslice1":
         monkeypatch.setenv("QS_BITSLICE_TILE", "1")
+        impl = "bitslice"
+    elif impl == "bitslice_bigpanel":
+        monkeypatch.setenv("QS_PANEL_KERNEL", "big")
         impl = "bitslice"
     monkeypatch.setenv("QS_GATHER_IMPL", impl)
     ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
@@ -149,13 +153,11 @@ def test_binary_batches_on_table_shards(eng):
         assert T.shape[0] == r1 - r0 and (T.astype(np.uint64) == full[r0:r1]).all(), (d_lo, d_hi)
 
 
-@pytest.mark.parametrize("order", ["group", "plain"])
-def test_tile_orders_of_the_two_column_kernel(eng, monkeypatch, order):
-    """The group-major tile order (default from 256 taxa on) enumerates exactly the same tile set as the
-    (d-block, c, tile) order: forced here at small n, odd sizes and on table shards."""
-    monkeypatch.setenv("QS_TILE_ORDER", order)
+def test_two_column_kernel_tile_set(eng):
+    """count_bitslice3_kernel enumerates every quartet exactly once at small n, odd sizes and on table shards
+    (d-blocks are counted down from d_hi, the partial block sits at the bottom)."""
     for n, m, shard in ((4, 3, None), (9, 10, None), (17, 33, None), (40, 20, None), (64, 40, (20, 50)), (45, 12, (44, 45)),
-                        (70, 9, (0, 11))):
+                        (70, 9, (0, 11)), (70, 9, (5, 14)), (33, 70, (3, 33))):
         ref_nw, trees = make_case(n, m, 90 + n)
         ref = flatten.flatten_reference(ref_nw)
         batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
@@ -166,7 +168,7 @@ def test_tile_orders_of_the_two_column_kernel(eng, monkeypatch, order):
         ctx.count_trees(batch)
         assert "x2" in ctx.last_count_variant()
         r0, r1 = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
-        assert (ctx.table_download().astype(np.uint64) == full[r0:r1]).all(), (n, shard, order)
+        assert (ctx.table_download().astype(np.uint64) == full[r0:r1]).all(), (n, shard)
 
 
 def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
