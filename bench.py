@@ -48,6 +48,8 @@ def parse_args():
                     help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
     ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees)")
     ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees)")
+    ap.add_argument("--reduce", choices=["scatter", "all"], default="scatter",
+                    help="N>1: reduce-scatter (each rank keeps and scores a shard of the reduced table) or all-reduce")
     ap.add_argument("--wire", choices=["auto", "u16", "u32"], default="auto",
                     help="N>1: cell width on the wire of the table all-reduce (auto = u16 while world x trees < 65536)")
     ap.add_argument("--table-shards", type=int, default=1,
@@ -109,19 +111,35 @@ def main():
     n_words = (ctx.table_bytes + 3) // 4
     table = torch.zeros(n_words, dtype=torch.int32, device=dev)  # u16 tables all-reduce as packed words
     ctx.table_attach(table)
-    # N > 1: two tables, so that the RCCL all-reduce of step k's table (async, on RCCL's stream) overlaps
-    # the counting of step k+1 into the other one. Needs 2x table memory: only when it comfortably fits.
+    # N > 1: the per-rank tables are combined with ONE collective per step, asynchronous on RCCL's stream, so that
+    # it overlaps the counting of the next step (two buffers in flight).
+    #   --reduce scatter (default): reduce-scatter; rank r ends with tuples [r*T, (r+1)*T) of the reduced table and
+    #       scores that shard (distributed.score_sharded): half the bytes per link of an all-reduce.
+    #   --reduce all: all-reduce, every rank ends with the full table (the wording of BASELINE.json north_star).
+    # Wire format: while the summed counts stay below 2^16 (world x m trees; the reference's own CINT rule,
+    # QuartetScores.cpp:115-147) the u32 table is packed to u16 cells first (qs_table_pack16): half the bytes again.
+    from quartetscores_amd import distributed
     tables = [table]
-    # Wire format of the all-reduce: while the summed counts stay below 2^16 (world x m trees; the reference's own
-    # CINT rule, QuartetScores.cpp:115-147) the u32 table is packed to u16 cells first (qs_table_pack16) and the
-    # ranks exchange half the bytes; the reduced buffer is itself a valid count_bits=16 table for scoring.
     wire16 = (use_dist and args.count_bits == 32 and args.algo == "gather"
               and (args.wire == "u16" or (args.wire == "auto" and world * m < 65536)))
+    reduce_mode = args.reduce if use_dist else None
+    bits_wire = 16 if wire16 else args.count_bits
+    chunk_words = 0
+    if reduce_mode == "scatter":
+        _, chunk_words = distributed.scatter_layout(ctx.table_tuples, world, bits_wire)
+        send_words = world * chunk_words
+        recv = [torch.zeros(chunk_words, dtype=torch.int32, device=dev) for _ in range(2)]
+    else:
+        send_words = distributed.table_words(ctx.table_tuples, bits_wire)
     if wire16:
         assert world * m < 65536, "--wire u16 needs world x trees < 65536"
-        wire = [torch.zeros((ctx.table_tuples * 3 + 1) // 2, dtype=torch.int32, device=dev) for _ in range(2)]
-    elif use_dist and 2 * ctx.table_bytes < 64 * (1 << 30):
-        tables.append(torch.zeros(n_words, dtype=torch.int32, device=dev))
+        wire = [torch.zeros(send_words, dtype=torch.int32, device=dev) for _ in range(2)]
+    elif use_dist:
+        table = torch.zeros(max(n_words, send_words), dtype=torch.int32, device=dev)  # padded to world chunks
+        ctx.table_attach(table)
+        tables = [table]
+        if 2 * table.numel() * 4 < 64 * (1 << 30):
+            tables.append(torch.zeros_like(table))
     pending = [None] * 2
     step_no = [0]
     last_buf = [0]
@@ -142,11 +160,16 @@ def main():
         if args.algo != "gather":
             ctx.table_clear()
         ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
-        if use_dist and wire16:
-            ctx.table_pack16(wire[i])
-            pending[i] = dist.all_reduce(wire[i], op=dist.ReduceOp.SUM, async_op=True)
-        elif use_dist:
-            pending[i] = dist.all_reduce(tables[i], op=dist.ReduceOp.SUM, async_op=True)
+        if use_dist:
+            if wire16:
+                ctx.table_pack16(wire[i])
+                src = wire[i]
+            else:
+                src = tables[i]
+            if reduce_mode == "scatter":
+                pending[i] = dist.reduce_scatter_tensor(recv[i], src[:send_words], op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                pending[i] = dist.all_reduce(src, op=dist.ReduceOp.SUM, async_op=True)
         last_buf[0] = i
 
     def drain():
@@ -191,13 +214,15 @@ def main():
     # gate on the REDUCED table of the last timed step: every tuple sums to world x m (binary, full trees)
     reduced_ok = None
     if use_dist and args.steps > 0 and not (args.collapse or args.dropout):
-        if wire16:
-            cells = (wire[last_buf[0]].view(torch.int16)[: nq * 3].to(torch.int32) & 0xFFFF)
-        elif args.count_bits == 32:
-            cells = tables[last_buf[0]][: nq * 3]
+        if reduce_mode == "scatter":
+            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, bits_wire)
+            red, n_red = recv[last_buf[0]], own_n
         else:
-            cells = (tables[last_buf[0]].view(torch.int16)[: nq * 3].to(torch.int32) & 0xFFFF)
-        reduced_ok = bool((cells.view(nq, 3).sum(dim=1) == world * m).all().item())
+            red, n_red = (wire if wire16 else tables)[last_buf[0]], nq
+        cells = red[: n_red * 3] if bits_wire == 32 else (red.view(torch.int16)[: n_red * 3].to(torch.int32) & 0xFFFF)
+        ok = torch.tensor([int((cells.view(n_red, 3).sum(dim=1) == world * m).all().item())], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank's shard must pass
+        reduced_ok = bool(ok.item())
         del cells
     if len(tables) > 1:                  # measurements below run on one table without collectives
         ctx.table_attach(table)
@@ -241,7 +266,14 @@ def main():
     if not args.no_score and args.count_bits == 32 and args.table_shards == 1:
         torch.cuda.synchronize(dev)
         s0 = time.perf_counter()
-        ctx.score(ref)
+        if reduce_mode == "scatter" and args.steps > 0:
+            # every rank scores the shard it received (view), accumulators combined with small collectives
+            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, bits_wire)
+            ctx.score_set_view(recv[last_buf[0]], bits_wire, own_lo, own_n)
+            distributed.score_sharded(ctx, ref)
+            ctx.score_set_view(None, 0, 0, 0)
+        else:
+            ctx.score(ref)
         score_ms = (time.perf_counter() - s0) * 1e3
 
     if rank != 0:
@@ -272,8 +304,9 @@ def main():
             "distinct_trees": distinct,
             "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((" + pack to u16 cells + RCCL all-reduce of the packed table (async, overlapped with the next step; two wire buffers)" if wire16 else " + RCCL all-reduce of the table (async, overlapped with the next step through a second table)") if use_dist_saved else ""),
-            "allreduce_bytes_per_rank": (((ctx.table_tuples * 3 + 1) // 2) * 4 if wire16 else n_words * 4) if use_dist_saved else None,
+            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + (((" + pack to u16 cells" if wire16 else "") + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if use_dist_saved else ""),
+            "collective": reduce_mode,
+            "collective_input_bytes_per_rank": send_words * 4 if use_dist_saved else None,
             "parity_reduced_tuple_sums_ok": reduced_ok,
             "parity_tuple_sums_ok": parity,
             "parity_bitslice_equals_swar_impl": impl_match,

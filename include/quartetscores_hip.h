@@ -208,6 +208,11 @@ int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, 
  */
 #define QS_SCORE_CAND_SLOTS 8
 uint64_t qs_score_pair_slots(const qs_ref_tree *ref);
+/* Scoring view: qs_score_pass1 / qs_score_pass2 read the tuples of ranks [rank_lo, rank_lo + n_tuples) from
+ * caller-owned device memory ([tuple][3] cells of count_bits bits) instead of the context's own table -- the
+ * shard a rank holds after a reduce-scatter of the count table. table_dev = NULL returns to the own table.
+ * qs_score / qs_lookup / qs_raw_qic keep using the context's own table. */
+int qs_score_set_view(qs_ctx *ctx, const void *table_dev, uint32_t count_bits, uint64_t rank_lo, uint64_t n_tuples);
 int qs_score_pass1(qs_ctx *ctx, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev);
 int qs_score_pass2(qs_ctx *ctx, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev);
 int qs_score_finish(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,

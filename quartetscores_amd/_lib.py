@@ -21,7 +21,7 @@ EXPORTS = [
     "qs_create", "qs_destroy", "qs_last_error", "qs_version", "qs_table_tuples", "qs_table_bytes", "qs_table_alloc",
     "qs_table_attach", "qs_table_pack16", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
-    "qs_score", "qs_score_pair_slots", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
+    "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
 ]
 
 
@@ -103,6 +103,8 @@ def load():
     L.qs_score.argtypes = [vp, C.POINTER(RefTreeC), u32, vp, vp, vp, C.POINTER(i32)]
     L.qs_score_pair_slots.restype = u64
     L.qs_score_pair_slots.argtypes = [C.POINTER(RefTreeC)]
+    L.qs_score_set_view.restype = i32
+    L.qs_score_set_view.argtypes = [vp, vp, u32, u64, u64]
     L.qs_score_pass1.restype = i32
     L.qs_score_pass1.argtypes = [vp, C.POINTER(RefTreeC), vp, vp]
     L.qs_score_pass2.restype = i32

@@ -43,6 +43,10 @@ struct qs_ctx {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
     bool ev_valid = false;
+    // scoring view (qs_score_set_view): tuples [view_rank_lo, view_rank_lo + view_n) in caller-owned device memory
+    const void *view_table = nullptr;
+    uint32_t view_bits = 0;
+    uint64_t view_rank_lo = 0, view_n = 0;
     std::string variant;
     std::string err;
 };
@@ -580,6 +584,7 @@ struct DevPtr { // RAII for a hipMalloc'ed pointer
 static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t *lca_dev, ScoreDevice &sd) {
     sd.ref_lca = lca_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
+    if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
     sd.frame = R.bifurcating ? 0 : 1;
 }
@@ -594,9 +599,18 @@ extern "C" uint64_t qs_score_pair_slots(const qs_ref_tree *ref) {
     return ni * ni;
 }
 
+extern "C" int qs_score_set_view(qs_ctx *c, const void *table_dev, uint32_t count_bits, uint64_t rank_lo, uint64_t n_tuples) {
+    if (!c) return QS_ERR_ARG;
+    if (!table_dev) { c->view_table = nullptr; c->view_bits = 0; c->view_rank_lo = c->view_n = 0; return QS_OK; }
+    if (count_bits != 16 && count_bits != 32) return fail(c, QS_ERR_ARG, "qs_score_set_view: count_bits must be 16 or 32");
+    if (rank_lo > binom4(c->n) || n_tuples > binom4(c->n) - rank_lo) return fail(c, QS_ERR_ARG, "qs_score_set_view: rank range outside C(n,4)");
+    c->view_table = table_dev; c->view_bits = count_bits; c->view_rank_lo = rank_lo; c->view_n = n_tuples;
+    return QS_OK;
+}
+
 extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev) {
     if (!c || !sums_dev || !min_dev) return fail(c, QS_ERR_ARG, "qs_score_pass1: NULL");
-    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score_pass1: no table");
+    if (!c->table && !c->view_table) return fail(c, QS_ERR_STATE, "qs_score_pass1: no table");
     RefHost R;
     int rc = build_ref(c, ref, R);
     if (rc != QS_OK) return rc;
@@ -617,7 +631,7 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
 
 extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev) {
     if (!c || !min_dev || !cand_dev) return fail(c, QS_ERR_ARG, "qs_score_pass2: NULL");
-    if (!c->table) return fail(c, QS_ERR_STATE, "qs_score_pass2: no table");
+    if (!c->table && !c->view_table) return fail(c, QS_ERR_STATE, "qs_score_pass2: no table");
     RefHost R;
     int rc = build_ref(c, ref, R);
     if (rc != QS_OK) return rc;

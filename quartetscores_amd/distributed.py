@@ -1,5 +1,9 @@
 """Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
 
+Two ways to combine the per-rank tables of the tree-sharded mode: all_reduce_table (every rank ends with the
+full table; BASELINE.json north_star's wording) and reduce_scatter_table (every rank ends with 1/world of it and
+scores that shard: half the link traffic, same scores).
+
 Tree-sharded mode (BASELINE.json north_star): evaluation trees are independent
 and counts add, so rank r counts trees [lo_r, hi_r) into a private full table and ONE in-place
 all-reduce (sum) of the table follows. The table lives in a torch tensor that the C-ABI context
@@ -24,6 +28,33 @@ def shard_range(m: int, world: int, rank: int) -> Tuple[int, int]:
 def table_words(n_tuples: int, count_bits: int) -> int:
     """int32 words needed to hold the [rank][3] table (u16 tables are padded to a whole word)."""
     return (n_tuples * 3 * (count_bits // 8) + 3) // 4
+
+
+def scatter_layout(n_tuples: int, world: int, count_bits: int) -> Tuple[int, int]:
+    """Reduce-scatter layout of the [rank][3] table: rank r ends with tuples [r * T, min((r + 1) * T, n_tuples)).
+    Returns (T, words): T tuples per rank (even, so a u16 chunk is a whole number of 32-bit words) and the int32
+    words per chunk; the send buffer is world * words long (zero padded behind the table)."""
+    t = -(-n_tuples // world)
+    t += t & 1
+    return t, t * 3 * (count_bits // 8) // 4
+
+
+def scatter_owned(n_tuples: int, world: int, rank: int, count_bits: int) -> Tuple[int, int]:
+    """(first tuple rank, number of tuples) that `rank` owns after reduce_scatter_table."""
+    t, _ = scatter_layout(n_tuples, world, count_bits)
+    lo = min(rank * t, n_tuples)
+    return lo, min(lo + t, n_tuples) - lo
+
+
+def reduce_scatter_table(send, recv, group=None, async_op=False):
+    """Sum over the ranks of `send` (world * words int32 words, scatter_layout); this rank's chunk lands in `recv`
+    (words int32 words). Half the bytes per rank of an all-reduce -- xGMI links are the bottleneck of the
+    tree-sharded mode -- and the LQ/QP/EQP reduction works on shards anyway (score_sharded with a view)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    recv.copy_(send[: recv.numel()])
+    return None
 
 
 def shard_of_largest_id(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -106,6 +137,44 @@ def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, devic
     if dist.is_initialized():
         torch.cuda.synchronize(dev)
     return ctx, table
+
+
+def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str = "auto", group=None):
+    """Tree-sharded counting that ends with the table SHARDED over the ranks (reduce-scatter instead of
+    all-reduce). Returns (ctx, shard, bits, rank_lo, n_owned): `shard` holds tuples [rank_lo, rank_lo + n_owned)
+    with `bits`-bit cells; ctx has that range set as its scoring view, so score_sharded(ctx, ref) gives the scores."""
+    import torch
+    import torch.distributed as dist
+    from . import engine
+    if wire not in ("auto", "u16", "u32"):
+        raise ValueError("wire must be auto, u16 or u32")
+    if wire == "u16" and batch.n_trees >= (1 << 16):
+        raise ValueError("a u16 wire format needs fewer than 65536 trees in total")
+    bits = 16 if (wire == "u16" or (wire == "auto" and batch.n_trees < (1 << 16))) else 32
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    stream = torch.cuda.current_stream(dev)
+    ctx = engine.Context(ref.n_taxa, 32, device=dev.index or 0, stream=stream.cuda_stream)
+    t_chunk, words = scatter_layout(ctx.table_tuples, world, bits)
+    send = torch.zeros(world * words, dtype=torch.int32, device=dev)
+    if bits == 32:
+        ctx.table_attach(send)                     # counted in place, padded to world chunks
+    else:
+        table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
+        ctx.table_attach(table)
+    lo, hi = shard_range(batch.n_trees, world, rank)
+    if hi > lo:
+        ctx.count_trees(batch.slice(lo, hi), algo)
+    if bits == 16:
+        ctx.table_pack16(send)
+    recv = torch.zeros(words, dtype=torch.int32, device=dev)
+    reduce_scatter_table(send, recv, group)
+    rank_lo, n_owned = scatter_owned(ctx.table_tuples, world, rank, bits)
+    ctx.score_set_view(recv, bits, rank_lo, n_owned)
+    torch.cuda.synchronize(dev)
+    return ctx, recv, bits, rank_lo, n_owned
 
 
 def score_sharded(ctx, ref, flags: int = 0, group=None, device=None):

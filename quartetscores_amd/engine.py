@@ -172,6 +172,18 @@ class Context:
         s, keep = self._ref_struct(ref)
         return int(self.L.qs_score_pair_slots(C.byref(s)))
 
+    def score_set_view(self, tensor, count_bits: int, rank_lo: int, n_tuples: int):
+        """score_pass1/2 read tuples [rank_lo, rank_lo + n_tuples) from `tensor` (torch CUDA tensor; None = own table)."""
+        if tensor is None:
+            self._chk(self.L.qs_score_set_view(self.h, None, 0, 0, 0))
+            self._view = None
+            return
+        need = n_tuples * 3 * (count_bits // 8)
+        if tensor.numel() * tensor.element_size() < need:
+            raise ValueError("view tensor smaller than the tuple range")
+        self._chk(self.L.qs_score_set_view(self.h, C.c_void_p(tensor.data_ptr()), count_bits, rank_lo, n_tuples))
+        self._view = tensor
+
     def score_pass1(self, ref: flatten.RefTree, sums, mins):
         s, keep = self._ref_struct(ref)
         self._chk(self.L.qs_score_pass1(self.h, C.byref(s), C.c_void_p(sums.data_ptr()), C.c_void_p(mins.data_ptr())))

@@ -59,6 +59,60 @@ def test_tree_sharded_allreduce_equals_single_process(tmp_path, count_bits):
         assert (np.load(tmp_path / f"t{r}.npy").astype(np.uint64) == full).all()
 
 
+def _rs_worker(rank, world, port, count_bits, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulate
+    from quartetscores_amd import distributed, flatten, ranks, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m = 9, 23
+    ref = flatten.flatten_reference(synth.reference_tree(n, 5))
+    batch = flatten.flatten_eval_trees(synth.tree_set(n, m, 6, collapse=0.2, dropout=0.1), ref.name_to_id)
+    nq = ranks.n_quartets(n)   # 126 tuples over 2 ranks: 63 -> 64 per rank (even), 2 padding tuples
+    t_chunk, words = distributed.scatter_layout(nq, world, count_bits)
+    send = torch.zeros(world * words, dtype=torch.int32)
+    dt = np.uint32 if count_bits == 32 else np.uint16
+    lo, hi = distributed.shard_range(m, world, rank)
+    send.numpy().view(dt)[: nq * 3].reshape(nq, 3)[...] = emulate.counts_from_batch(batch.slice(lo, hi), n).astype(dt)
+    recv = torch.zeros(words, dtype=torch.int32)
+    distributed.reduce_scatter_table(send, recv)
+    r_lo, n_own = distributed.scatter_owned(nq, world, rank, count_bits)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), recv.numpy().view(dt)[: n_own * 3].reshape(n_own, 3).copy())
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([r_lo, n_own, t_chunk]))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full.npy"), emulate.counts_from_batch(batch, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_tree_sharded_reduce_scatter_gives_each_rank_its_shard(tmp_path, count_bits):
+    world = 2
+    mp.spawn(_rs_worker, args=(world, _free_port(), count_bits, str(tmp_path)), nprocs=world, join=True)
+    full = np.load(tmp_path / "full.npy")
+    covered = 0
+    for r in range(world):
+        r_lo, n_own, t_chunk = (int(v) for v in np.load(tmp_path / f"r{r}.npy"))
+        assert r_lo == covered and t_chunk % 2 == 0
+        assert (np.load(tmp_path / f"s{r}.npy").astype(np.uint64) == full[r_lo:r_lo + n_own]).all()
+        covered += n_own
+    assert covered == full.shape[0]
+
+
+def test_scatter_layout_properties():
+    from quartetscores_amd import distributed
+    for nq in (1, 2, 70, 126, 10668000, 2862209280):
+        for w in (1, 2, 3, 8):
+            for bits in (16, 32):
+                t, words = distributed.scatter_layout(nq, w, bits)
+                assert t % 2 == 0 and t * w >= nq and words * 4 == t * 3 * bits // 8
+                owned = [distributed.scatter_owned(nq, w, r, bits) for r in range(w)]
+                assert owned[0][0] == 0 and sum(c for _, c in owned) == nq
+                assert all(a[0] + a[1] == b[0] for a, b in zip(owned, owned[1:]))
+
+
 def test_shard_ranges_cover_and_balance():
     from quartetscores_amd import distributed
     for m in (0, 1, 7, 1000, 100001):

@@ -579,3 +579,69 @@ def test_count_trees_multi_gpu_u16_wire_single_rank(eng):
     assert np.array_equal(c_a.table_download(), c_b.table_download().astype(np.uint32))
     for a, b in zip(c_a.score(ref)[:3], c_b.score(ref)[:3]):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize("bits", [16, 32])
+def test_scoring_views_of_a_reduce_scattered_table(eng, bits):
+    """The shard a rank holds after distributed.reduce_scatter_table (tuples [r*T, (r+1)*T) in its own buffer) is
+    scored through qs_score_set_view; three views on one GPU stand in for three ranks, combined like
+    distributed.score_sharded does with collectives. Same scores as the unsharded path, bit for bit."""
+    import torch
+    from quartetscores_amd import distributed
+    n, m, W = 23, 60, 3
+    ref_nw, trees = make_case(n, m, 91, collapse=0.1, dropout=0.1)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    whole = eng.Context(n, 32)
+    whole.table_alloc()
+    whole.count_trees(batch)
+    want = whole.score(ref)
+    full = whole.table_download()
+    nq = full.shape[0]
+    t_chunk, words = distributed.scatter_layout(nq, W, bits)
+    dt = np.uint16 if bits == 16 else np.uint32
+    ctx = eng.Context(n, 32)            # no table of its own: views only
+    P = ctx.score_pair_slots(ref)
+    sums, mins, shards = None, None, []
+    for r in range(W):
+        r_lo, n_own = distributed.scatter_owned(nq, W, r, bits)
+        buf = np.zeros(words * 4 // dt().itemsize, dtype=dt)
+        buf[: n_own * 3] = full[r_lo:r_lo + n_own].astype(dt).ravel()
+        shard = torch.from_numpy(buf.view(np.int32)).cuda()
+        shards.append((shard, r_lo, n_own))
+        ctx.score_set_view(shard, bits, r_lo, n_own)
+        s_ = torch.empty(3 * P, dtype=torch.int64, device="cuda"); m_ = torch.empty(P, dtype=torch.int64, device="cuda")
+        ctx.score_pass1(ref, s_, m_)
+        sums = s_ if sums is None else sums + s_
+        mins = m_ if mins is None else torch.minimum(mins, m_)
+    cands = []
+    for shard, r_lo, n_own in shards:
+        ctx.score_set_view(shard, bits, r_lo, n_own)
+        c_ = torch.empty(8 * P, dtype=torch.int64, device="cuda")
+        ctx.score_pass2(ref, mins, c_)
+        cands.append(c_.cpu().numpy())
+    got = ctx.score_finish(ref, sums.cpu().numpy(), np.stack(cands))
+    for a, b in zip(got[:3], want[:3]):
+        assert np.array_equal(a, b, equal_nan=True)
+    # argument checks; clearing the view without an own table is a state error again
+    with pytest.raises(eng.QSError):
+        ctx.score_set_view(shards[0][0], bits, ranks.n_quartets(n), 1)
+    ctx.score_set_view(None, 0, 0, 0)
+    with pytest.raises(eng.QSError):
+        ctx.score_pass1(ref, sums, mins)
+
+
+def test_count_trees_reduce_scatter_single_rank(eng):
+    from quartetscores_amd import distributed
+    n, m = 18, 90
+    ref_nw, trees = make_case(n, m, 93)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    plain, _ = distributed.count_trees_multi_gpu(ref, batch, wire="u32")
+    want = plain.score(ref)
+    for wire in ("u16", "u32"):
+        ctx, shard, bits, r_lo, n_own = distributed.count_trees_reduce_scatter(ref, batch, wire=wire)
+        assert (bits, r_lo, n_own) == (16 if wire == "u16" else 32, 0, ranks.n_quartets(n))
+        got = distributed.score_sharded(ctx, ref)
+        for a, b in zip(got[:3], want[:3]):
+            assert np.array_equal(a, b, equal_nan=True)
