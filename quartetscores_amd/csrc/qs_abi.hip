@@ -34,8 +34,10 @@ struct qs_ctx {
     // geometry
     uint32_t *dprefix = nullptr, *cprefix = nullptr;
     uint32_t n_dblk = 0, total_tiles = 0;
-    uint32_t *dprefix3 = nullptr, *cprefix3 = nullptr; // tiling of count_bitslice3_kernel (16x8 tiles, d-blocks counted down from d_hi)
+    uint32_t *dprefix3 = nullptr, *cprefix3 = nullptr; // tiling of count_bitslice3_kernel, binary batches (16x8 tiles, d-blocks counted down from d_hi)
     uint32_t total_tiles3 = 0;
+    uint32_t *dprefix1t = nullptr;                     // the same kernel on general / partial batches: 8x8 tiles (cprefix), d-blocks counted down
+    uint32_t total_tiles1t = 0;
     // workspace
     void *panel = nullptr;
     size_t panel_bytes = 0;
@@ -127,6 +129,11 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
         for (uint32_t k = 0; k < c->n_dblk; ++k) { t3 += cp3[d_hi - k * kDB - 1]; dp3[k + 1] = (uint32_t)t3; }
         if (t3 >= (1ull << 31)) return cleanup(QS_ERR_UNSUPPORTED, "qs_create: shard too large for one launch; use a narrower [d_lo, d_hi)");
         c->total_tiles3 = dp3[c->n_dblk];
+        std::vector<uint32_t> dp1(c->n_dblk + 1, 0);
+        for (uint32_t k = 0; k < c->n_dblk; ++k) dp1[k + 1] = dp1[k] + cp[d_hi - k * kDB - 1]; // total equals total_tiles (< 2^31, checked above)
+        c->total_tiles1t = dp1[c->n_dblk];
+        if (hipMalloc(&c->dprefix1t, dp1.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix1t");
+        if (hipMemcpy(c->dprefix1t, dp1.data(), dp1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix1t");
         if (hipMalloc(&c->cprefix3, cp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix3");
         if (hipMalloc(&c->dprefix3, dp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix3");
         if (hipMemcpy(c->cprefix3, cp3.data(), cp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix3");
@@ -148,6 +155,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->dprefix) (void)hipFree(c->dprefix);
     if (c->cprefix) (void)hipFree(c->cprefix);
     if (c->dprefix3) (void)hipFree(c->dprefix3);
+    if (c->dprefix1t) (void)hipFree(c->dprefix1t);
     if (c->cprefix3) (void)hipFree(c->cprefix3);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
     for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -317,8 +325,15 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     if (!c || !b) return fail(c, QS_ERR_ARG, "qs_count_batch: NULL argument");
     if (!c->table) return fail(c, QS_ERR_STATE, "qs_count_batch: no table (qs_table_alloc / qs_table_attach first)");
     const DeviceBatch &d = b->d;
-    if (d.n_trees == 0) return QS_OK;
     QS_HIP(c, hipSetDevice(c->device));
+    if (d.n_trees == 0) {
+        if (algo & QS_COUNT_OVERWRITE) { // "discard the previous contents" holds for an empty batch too
+            QS_HIP(c, hipMemsetAsync(c->table, 0, c->n_tuples * 3 * (c->count_bits / 8), c->stream));
+            c->trees_counted = 0;
+        }
+        c->last_timed = false;
+        return QS_OK;
+    }
     if (c->count_bits == 16 && ((algo & QS_COUNT_OVERWRITE) ? 0 : c->trees_counted) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "qs_count_batch: more than 65535 trees need count_bits = 32");
     const bool overwrite = (algo & QS_COUNT_OVERWRITE) != 0;
@@ -351,14 +366,14 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         // Two things that did NOT help (profiles/r01_experiments.md): visiting the tree groups in rotated order so
         // that late tiles stay in phase with the resident ones (the panel still streams from HBM once per
         // round of tiles), and non-temporal table accesses.
-        // binary_full batches use count_bitslice3_kernel (two a-columns per lane, compact panel);
-        // QS_BITSLICE_TILE=1 forces the general one-column kernel (tests / A-B runs)
+        // bit-sliced batches run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane);
+        // QS_BITSLICE_TILE=1 forces its predecessor count_bitslice_kernel (tests / A-B runs)
         const char *tile_env = getenv("QS_BITSLICE_TILE");
-        const bool v3 = use_bitslice && mode == MODE_BINARY_FULL && !(tile_env && tile_env[0] == '1');
+        const bool v3 = use_bitslice && !(tile_env && tile_env[0] == '1');
         int bits = 8;
         uint32_t tpc;            // trees per panel element
         size_t elem_bytes;       // bytes per (pair, element)
-        const uint32_t compact_nw = v3 ? std::max(depth_bits, 4u) : 0u; // count_bitslice3_kernel reads the compact panel
+        const uint32_t compact_nw = v3 ? std::max(depth_bits, 4u) + (mode == MODE_PARTIAL ? 1u : 0u) : 0u; // words per compact panel element
         if (use_bitslice) { tpc = 32; elem_bytes = v3 ? compact_nw * 4 : 32; }
         else {
             const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
@@ -390,13 +405,14 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (ch0 == 0 && timed) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
             if (v3) {
                 CountGeometry g3 = g;
-                g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3;
-                QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+                if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
+                else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
+                QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             } else if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }
         if (use_bitslice)
-            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (v3 ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
+            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (v3 ? (mode == MODE_BINARY_FULL ? "x2" : "v3") : "old") + "/count_u" + std::to_string(c->count_bits);
         else
             c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
         }
         if (compact_nw) {
             // compact layout of count_bitslice3_kernel: per tree group uint4 lo[npairs] (planes 0..3), then
-            // (compact_nw - 4) upper words per pair
+            // (compact_nw - 4) upper words per pair; partial batches: the last word is the presence plane
+            if (PARTIAL) w[compact_nw - 1] = w[7];
             char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * compact_nw * 4;
             reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
             uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (compact_nw - 4);
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
     if (p >= npairs) return;
     uint32_t x, y;
     unrank2(p, x, y);
-    constexpr int kPlanes = NWC ? NWC : 7;
+    constexpr int kPlanes = NWC ? (PARTIAL ? NWC - 1 : NWC) : 7; // compact partial elements end with the presence word
     uint32_t w[kBitWords];
 #pragma unroll
     for (int k = 0; k < kBitWords; ++k) w[k] = 0;
@@ -600,6 +601,7 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
         w[7] |= 1u << j;
     }
     if (NWC) {
+        if (PARTIAL) w[NWC - 1] = w[7];
         char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * NWC * 4;
         reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
         uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
@@ -620,7 +622,7 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
         const uint32_t tree_bytes = (n * 2 + levels * n + 3) & ~3u;
         const size_t lds_small = (size_t)kBitTrees * tree_bytes;
         const char *pe = getenv("QS_PANEL_KERNEL"); // "big" forces the general kernel (tests / A-B runs)
-        if (lds_small <= 96 * 1024 && !(pe && pe[0] == 'b') && (compact_nw == 0 || !partial)) {
+        if (lds_small <= 96 * 1024 && !(pe && pe[0] == 'b')) {
             dim3 grid((npairs + kBPSThreads - 1) / kBPSThreads, n_groups), block(kBPSThreads);
 #define QS_BPS(PART, NWC)                                                                                          \
     do {                                                                                                           \
@@ -633,6 +635,11 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
                            tree_bytes, (uint4 *)panel);                                                            \
     } while (0)
             if (compact_nw == 0) { if (partial) QS_BPS(true, 0); else QS_BPS(false, 0); }
+            else if (partial) { // planes + presence word: 5..7
+                if (compact_nw <= 5) QS_BPS(true, 5);
+                else if (compact_nw == 6) QS_BPS(true, 6);
+                else QS_BPS(true, 7);
+            }
             else if (compact_nw <= 4) QS_BPS(false, 4);
             else if (compact_nw == 5) QS_BPS(false, 5);
             else if (compact_nw == 6) QS_BPS(false, 6);
@@ -991,7 +998,7 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 #endif
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
-template <int B, typename CT>
+template <int B, int MODE, typename CT>
 __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees,
                                                                         uint32_t d_start, uint32_t d_hi, uint64_t rank_lo,
@@ -1000,9 +1007,14 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
                                                                         const uint32_t *__restrict__ cprefix,
                                                                         CT *__restrict__ table,
                                                                         uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
+    constexpr bool BIN = MODE == MODE_BINARY_FULL, PART = MODE == MODE_PARTIAL;
     constexpr int NB = B + 1;
-    constexpr int NW = B < 4 ? 4 : B;                       // live words of a raw panel element (planes of M)
-    constexpr int HW = NB <= 5 ? 1 : (NB == 6 ? 2 : 4);     // upper words of an LDS slot (R has B+1 planes)
+    constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
+    constexpr int NW = NWP < 4 ? 4 : NWP;
+    constexpr int RW = NB + (PART ? 1 : 0);                 // words of an LDS element (R has B+1 planes [+ presence])
+    constexpr int HW = RW <= 5 ? 1 : (RW == 6 ? 2 : 4);     // upper words of an LDS slot
+    constexpr int PW = B + 1;                               // where the presence word travels in an LDS element
+    static_assert(!PART || B <= 6, "partial batches carry at most 6 depth bits");
     constexpr int kImg = kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
     __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
 
@@ -1019,13 +1031,16 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     const uint32_t d0 = d1 > d_start + kDB ? d1 - kDB : d_start;
     const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
     const uint32_t T = (c + kTB - 1) / kTB;
-    const uint32_t n_off = (T * T) / 4;
+    const uint32_t n_off = BIN ? (T * T) / 4 : T * (T - 1) / 2;
     const uint32_t tl = local - cprefix[c];
     const bool offdiag = tl < n_off;
 
-    uint32_t blk0, blk1, blkB;       // id blocks: a-columns 0..7, a-columns 8..15 (0xFFFFFFFF = absent), b-columns
+    // id blocks behind the 16 staged columns: columns 0..7 = blk0, 8..15 = blk1 (0xFFFFFFFF = absent). Binary
+    // tiles: blk0/blk1 = the two a-blocks, blkB = the b-block (its R elements use columns 0..7). General / partial
+    // tiles (one a-column per lane; they also need R of (a,d) and M[bc]): blk0 = a-block, blk1 = b-block.
+    uint32_t blk0, blk1, blkB;
     uint32_t a1, a2, b, colA1, colA2, colB;
-    if (offdiag) {
+    if (offdiag && BIN) {
         uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f)); // largest Bk with floor(Bk^2 / 4) <= tl
         while ((Bk * Bk) / 4 > tl) --Bk;
         while (((Bk + 1) * (Bk + 1)) / 4 <= tl) ++Bk;
@@ -1036,6 +1051,13 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         a1 = blk0 * kTA + ia;
         a2 = blk1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : blk1 * kTA + ia;
         b = Bk * kTB + ib;
+    } else if (offdiag) {
+        unrank2(tl, blk0, blk1);
+        blkB = blk1;
+        const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
+        colA1 = ia; colA2 = ia; colB = kTA + ib;
+        a1 = blk0 * kTA + ia; a2 = 0xFFFFFFFFu;
+        b = blk1 * kTB + ib;
     } else {
         const uint32_t kd = tl - n_off;
         blk0 = 2 * kd; blk1 = 2 * kd + 1; blkB = blk0;
@@ -1046,21 +1068,22 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         a1 = (h ? blk1 : blk0) * kTA + ia; a2 = 0xFFFFFFFFu;
         b = q < 28 ? (h ? blk1 : blk0) * kTA + ib : 0xFFFFFFFFu;
     }
-    const bool has_a2 = offdiag && blk1 != 0xFFFFFFFFu; // wave-uniform
+    const bool has_a2 = BIN && offdiag && blk1 != 0xFFFFFFFFu; // wave-uniform
+    const bool two_r = !BIN || !offdiag;                        // R elements for all 16 columns (else 8: the b-block)
     const bool v1 = (a1 < b) && (b < c);
     const bool v2 = has_a2 && (a2 < b) && (b < c);
     const uint32_t pi1 = v1 ? (uint32_t)binom2(b) + a1 : 0u;
     const uint32_t pi2 = v2 ? (uint32_t)binom2(b) + a2 : 0u;
     const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
 
-    // ---- loop-invariant byte offsets inside one tree group, and LDS slots ----
+    // ---- loop-invariant offsets inside one tree group (16 bytes per pair in the lo array), and LDS slots ----
     const uint32_t r_j = lane >> 3, r_col = lane & 7, dE = d0 + r_j;
     const bool dok = dE < d1 && dE > c;
-    const uint32_t bE0 = blkB * kTB + r_col, bE1 = blk1 * kTB + r_col;   // blk1 is only used for diagonal tiles here
-    const bool ok0 = dok && bE0 < c, ok1 = dok && !offdiag && bE1 < c;
+    const uint32_t bE0 = (two_r ? blk0 : blkB) * kTB + r_col, bE1 = blk1 * kTB + r_col;
+    const bool ok0 = dok && bE0 < c, ok1 = dok && two_r && bE1 < c;
     const uint32_t rowd = (uint32_t)binom2(dE);
-    const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, y0off = ok0 ? (rowd + c) * 16u : kS3Inv;
-    const uint32_t x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv, y1off = ok1 ? (rowd + c) * 16u : kS3Inv;
+    const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv;
+    const uint32_t yoff = dok ? (rowd + c) * 16u : kS3Inv;      // M[c,d]: shared by both R elements of the lane
     const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
     uint32_t xa = 0xFFFFFFFFu;
     if (lane < 8) xa = blk0 * kTA + lane;
@@ -1070,90 +1093,127 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     const uint32_t ab1off = v1 ? pi1 * 16u : kS3Inv, ab2off = v2 ? pi2 * 16u : kS3Inv;
     const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
-    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB]; // counters of (a1,b) and (a2,b): topologies ab|cd and ac|bd per d slot
+    // counters per d slot. Binary: x0/x1 = ab|cd, ac|bd of (a1,b); y0/y1 the same of (a2,b).
+    // General / partial: x0/x1/y0 = ab|cd, ac|bd, ad|bc of (a1,b).
+    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB];
 #pragma unroll
     for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
 
-    struct Staged { Planes x0, y0, x1, y1, row; };
     auto rsrc_of = [&](uint32_t g) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (int)group_bytes, 0x00020000);
     };
+    // compact panel element -> planes in w[0..B-1], presence (partial) in w[7]
+    auto gload = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+        Planes p = buf_load_planes<NW>(r, voff, hi_base);
+        if (PART) { p.w[7] = p.w[B]; p.w[B] = 0; }
+        return p;
+    };
+    // LDS element: words 0..B [+ presence at word B+1]
+    auto lstore = [&](uint4 *buf, uint32_t slot, Planes x) {
+        if (PART && PW != 7) x.w[PW] = x.w[7];
+        lds_store_hw<HW>(buf, slot, kS3Slots, x);
+    };
+    auto lload = [&](const uint4 *buf, uint32_t slot) {
+        Planes r = lds_load_hw<HW>(buf, slot, kS3Slots);
+        if (PART && PW != 7) { r.w[7] = r.w[PW]; r.w[PW] = 0; }
+        return r;
+    };
     auto row0_load = [&](const uint4 *buf, uint32_t col) {
-        if (B <= 4) {
+        if (B <= 4 && !PART) {
             const uint4 lo = buf[kS3Row0 + col];
             Planes r;
             r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w; r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
             return r;
         }
-        return lds_load_hw<HW>(buf, kS3Row0 + col, kS3Slots);
+        return lload(buf, kS3Row0 + col);
     };
+    struct Staged { Planes x0, x1, y, row; };
 
     // one 32-tree step: request group g_next into (st, abn1, abn2), count group g from (cur, abc1, abc2), then
     // turn the requested elements into the LDS image `nxt`
     auto step = [&](uint32_t g_next, const uint4 *cur, uint4 *nxt, const Planes &abc1, const Planes &abc2, Planes &abn1,
-                    Planes &abn2, auto a2_tag, auto full_tag, auto diag_tag) {
-        constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value, DIAG = decltype(diag_tag)::value;
+                    Planes &abn2, auto a2_tag, auto full_tag, auto two_tag) {
+        constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value, TWO = decltype(two_tag)::value;
         const __amdgpu_buffer_rsrc_t r = rsrc_of(g_next);
         Staged st;
-        st.x0 = buf_load_planes<NW>(r, x0off, hi_base);
-        st.y0 = buf_load_planes<NW>(r, y0off, hi_base);
-        if (DIAG) { st.x1 = buf_load_planes<NW>(r, x1off, hi_base); st.y1 = buf_load_planes<NW>(r, y1off, hi_base); }
-        st.row = buf_load_planes<NW>(r, rowoff, hi_base);
-        abn1 = buf_load_planes<NW>(r, ab1off, hi_base);
-        if (A2) abn2 = buf_load_planes<NW>(r, ab2off, hi_base);
+        st.x0 = gload(r, x0off);
+        st.y = gload(r, yoff);
+        if (TWO) st.x1 = gload(r, x1off);
+        st.row = gload(r, rowoff);
+        abn1 = gload(r, ab1off);
+        if (A2) abn2 = gload(r, ab2off);
 
-        const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1));
+        const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1)); // M[ab] - M[ac] + 2^B
         Planes L2 = L1;
         if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));
+        if (!BIN) L2 = sub_biased<B>(abc1, row0_load(cur, colB));     // M[ab] - M[bc] + 2^B
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
             if (FULL || ((uint32_t)j >= jlo && (uint32_t)j < jhi)) { // wave-uniform
-                const Planes Rb = lds_load_hw<HW>(cur, j * 16 + colB, kS3Slots);
+                const Planes Rb = lload(cur, j * 16 + colB);         // M[bd] - M[cd] + 2^B
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
-                popc_acc(gt, x0[j]);
-                popc_acc(lt, x1[j]);
-                if (A2) {
-                    uint32_t gt2, lt2;
-                    cmp_planes<NB>(L2, Rb, gt2, lt2);
-                    popc_acc(gt2, y0[j]);
-                    popc_acc(lt2, y1[j]);
+                if (BIN) {
+                    popc_acc(gt, x0[j]);
+                    popc_acc(lt, x1[j]);
+                    if (A2) {
+                        uint32_t gt2, lt2;
+                        cmp_planes<NB>(L2, Rb, gt2, lt2);
+                        popc_acc(gt2, y0[j]);
+                        popc_acc(lt2, y1[j]);
+                    }
+                } else {
+                    const Planes Ra = lload(cur, j * 16 + colA1);    // M[ad] - M[cd] + 2^B
+                    uint32_t g3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, L2), gt, lt); // S1 == S2 and S3 > S1
+                    if (PART) {
+                        const uint32_t v = L1.w[7] & Rb.w[7]; // a, b, c, d all present
+                        gt &= v; lt &= v; g3 &= v;
+                    }
+                    popc_acc(gt, x0[j]);
+                    popc_acc(lt, x1[j]);
+                    popc_acc(g3, y0[j]);
                 }
             }
         }
-        lds_store_hw<HW>(nxt, slot0, kS3Slots, sub_biased<B>(st.x0, st.y0));
-        if (DIAG) lds_store_hw<HW>(nxt, slot1, kS3Slots, sub_biased<B>(st.x1, st.y1));
+        lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
+        if (TWO) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
         if (lane < 16) {
-            if (B <= 4) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
-            else lds_store_hw<HW>(nxt, rowslot, kS3Slots, st.row);
+            if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
+            else lstore(nxt, rowslot, st.row);
         }
     };
 
-    auto run = [&](auto a2_tag, auto full_tag, auto diag_tag) {
-        constexpr bool A2 = decltype(a2_tag)::value, DIAG = decltype(diag_tag)::value;
+    auto run = [&](auto a2_tag, auto full_tag, auto two_tag) {
+        constexpr bool A2 = decltype(a2_tag)::value, TWO = decltype(two_tag)::value;
         Planes abA1, abA2, abB1, abB2;
 #pragma unroll
         for (int w = 0; w < kBitWords; ++w) abA2.w[w] = abB2.w[w] = 0;
         {   // group 0 -> buf0 / set A
             const __amdgpu_buffer_rsrc_t r = rsrc_of(0);
-            lds_store_hw<HW>(buf0, slot0, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x0off, hi_base), buf_load_planes<NW>(r, y0off, hi_base)));
-            if (DIAG) lds_store_hw<HW>(buf0, slot1, kS3Slots, sub_biased<B>(buf_load_planes<NW>(r, x1off, hi_base), buf_load_planes<NW>(r, y1off, hi_base)));
-            const Planes row = buf_load_planes<NW>(r, rowoff, hi_base);
-            if (lane < 16) lds_store_hw<HW>(buf0, rowslot, kS3Slots, row);
-            abA1 = buf_load_planes<NW>(r, ab1off, hi_base);
-            if (A2) abA2 = buf_load_planes<NW>(r, ab2off, hi_base);
+            const Planes y = gload(r, yoff);
+            lstore(buf0, slot0, sub_biased<B>(gload(r, x0off), y));
+            if (TWO) lstore(buf0, slot1, sub_biased<B>(gload(r, x1off), y));
+            const Planes row = gload(r, rowoff);
+            if (lane < 16) lstore(buf0, rowslot, row);
+            abA1 = gload(r, ab1off);
+            if (A2) abA2 = gload(r, ab2off);
         }
         const uint32_t g_last = n_groups - 1;
         for (uint32_t g = 0; g < n_groups; g += 2) {
             // the request past the last group re-reads the last one (its image is never used)
-            step(min(g + 1, g_last), buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, diag_tag);
-            if (g + 1 < n_groups) step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, diag_tag);
+            step(min(g + 1, g_last), buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, two_tag);
+            if (g + 1 < n_groups) step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, two_tag);
         }
     };
     using T_ = std::true_type; using F_ = std::false_type;
-    if (has_a2) { if (jlo == 0 && jhi == (uint32_t)kDB) run(T_{}, T_{}, F_{}); else run(T_{}, F_{}, F_{}); }
-    else if (offdiag) run(F_{}, F_{}, F_{});
-    else run(F_{}, F_{}, T_{});
+    const bool full = jlo == 0 && jhi == (uint32_t)kDB;
+    if (BIN) {
+        if (has_a2) { if (full) run(T_{}, T_{}, F_{}); else run(T_{}, F_{}, F_{}); }
+        else if (offdiag) run(F_{}, F_{}, F_{});
+        else run(F_{}, F_{}, T_{});
+    } else {
+        if (full) run(F_{}, T_{}, T_{}); else run(F_{}, F_{}, T_{});
+    }
 
     const uint64_t rcb = binom3(c);
 #pragma unroll
@@ -1163,12 +1223,12 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
             const uint64_t base = binom4(d) + rcb - rank_lo;
             if (v1) {
                 const uint64_t idx = (base + pi1) * 3;
-                uint32_t w0 = x0[j], w1 = x1[j], w2 = m_trees - x0[j] - x1[j];
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = BIN ? m_trees - x0[j] - x1[j] : y0[j];
                 if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 table[idx] = (CT)w0; table[idx + 1] = (CT)w1; table[idx + 2] = (CT)w2;
             }
-            if (v2) {
+            if (BIN && v2) {
                 const uint64_t idx = (base + pi2) * 3;
                 uint32_t w0 = y0[j], w1 = y1[j], w2 = m_trees - y0[j] - y1[j];
                 if (!overwrite) { w0 += (uint32_t)table[idx]; w1 += (uint32_t)table[idx + 1]; w2 += (uint32_t)table[idx + 2]; }
@@ -1179,24 +1239,40 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     }
 }
 
-hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
+hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite) {
     if (g.total_tiles == 0 || n_groups == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
-#define QS_BS3(BB, CT)                                                                                              \
-    hipLaunchKernelGGL((count_bitslice3_kernel<BB, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
+#define QS_BS3(BB, MM, CT)                                                                                          \
+    hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
                        (CT *)table, overflow_flag, overwrite ? 1u : 0u)
-#define QS_BS3_B(CT)                                                                                                \
+#define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
-        if (depth_bits <= 4) QS_BS3(4, CT);                                                                         \
-        else if (depth_bits == 5) QS_BS3(5, CT);                                                                    \
-        else if (depth_bits == 6) QS_BS3(6, CT);                                                                    \
-        else QS_BS3(7, CT);                                                                                         \
+        if (depth_bits <= 4) QS_BS3(4, MM, CT);                                                                     \
+        else if (depth_bits == 5) QS_BS3(5, MM, CT);                                                                \
+        else if (depth_bits == 6) QS_BS3(6, MM, CT);                                                                \
+        else QS_BS3(7, MM, CT);                                                                                     \
     } while (0)
-    if (count_bits == 32) QS_BS3_B(uint32_t); else QS_BS3_B(uint16_t);
+#define QS_BS3_BP(CT)                                                                                               \
+    do {                                                                                                            \
+        if (depth_bits <= 4) QS_BS3(4, MODE_PARTIAL, CT);                                                           \
+        else if (depth_bits == 5) QS_BS3(5, MODE_PARTIAL, CT);                                                      \
+        else QS_BS3(6, MODE_PARTIAL, CT);                                                                           \
+    } while (0)
+    if (mode == MODE_PARTIAL && depth_bits > 6) return hipErrorInvalidValue;
+    if (count_bits == 32) {
+        if (mode == MODE_BINARY_FULL) QS_BS3_B(MODE_BINARY_FULL, uint32_t);
+        else if (mode == MODE_GENERAL_FULL) QS_BS3_B(MODE_GENERAL_FULL, uint32_t);
+        else QS_BS3_BP(uint32_t);
+    } else {
+        if (mode == MODE_BINARY_FULL) QS_BS3_B(MODE_BINARY_FULL, uint16_t);
+        else if (mode == MODE_GENERAL_FULL) QS_BS3_B(MODE_GENERAL_FULL, uint16_t);
+        else QS_BS3_BP(uint16_t);
+    }
+#undef QS_BS3_BP
 #undef QS_BS3_B
 #undef QS_BS3
     return hipGetLastError();

@@ -56,7 +56,7 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
 hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                  uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                  bool overwrite);
-hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits,
+hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite);
 uint32_t bitslice3_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of count_bitslice3_kernel

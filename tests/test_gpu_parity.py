@@ -134,6 +134,9 @@ def test_degenerate_batches(eng):
     o = oracle_counts(ref_nw, [t for t in trees if t.count(",") >= 1])  # the oracle's parser needs >= 2 leaves
     assert (T.astype(np.uint64) == o.counts()).all()
     assert ctx.trees_counted == len(trees)
+    # overwrite mode with an empty batch still discards the previous contents
+    ctx.count_trees(flatten.flatten_eval_trees([], ref.name_to_id), eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    assert ctx.trees_counted == 0 and not ctx.table_download().any()
 
 
 def test_binary_batches_on_table_shards(eng):
