@@ -366,15 +366,12 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         // Two things that did NOT help (profiles/r01_experiments.md): visiting the tree groups in rotated order so
         // that late tiles stay in phase with the resident ones (the panel still streams from HBM once per
         // round of tiles), and non-temporal table accesses.
-        // bit-sliced batches run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane);
-        // QS_BITSLICE_TILE=1 forces its predecessor count_bitslice_kernel (tests / A-B runs)
-        const char *tile_env = getenv("QS_BITSLICE_TILE");
-        const bool v3 = use_bitslice && !(tile_env && tile_env[0] == '1');
+        // bit-sliced batches run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane)
         int bits = 8;
         uint32_t tpc;            // trees per panel element
         size_t elem_bytes;       // bytes per (pair, element)
-        const uint32_t compact_nw = v3 ? std::max(depth_bits, 4u) + (mode == MODE_PARTIAL ? 1u : 0u) : 0u; // words per compact panel element
-        if (use_bitslice) { tpc = 32; elem_bytes = v3 ? compact_nw * 4 : 32; }
+        const uint32_t compact_nw = std::max(depth_bits, 4u) + (mode == MODE_PARTIAL ? 1u : 0u); // words per compact panel element
+        if (use_bitslice) { tpc = 32; elem_bytes = compact_nw * 4; }
         else {
             const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
             const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
@@ -403,16 +400,16 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
             if (ch0 == 0 && timed) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
-            if (v3) {
+            if (use_bitslice) {
                 CountGeometry g3 = g;
                 if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
                 else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
                 QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
-            } else if (use_bitslice) QS_HIP(c, launch_count_bitslice(c->stream, g, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+            }
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }
         if (use_bitslice)
-            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (v3 ? (mode == MODE_BINARY_FULL ? "x2" : "v3") : "old") + "/count_u" + std::to_string(c->count_bits);
+            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (mode == MODE_BINARY_FULL ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
         else
             c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {

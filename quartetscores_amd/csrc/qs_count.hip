@@ -419,9 +419,9 @@ hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void
 //
 // The SWAR kernel above is bound by VALU issue: 7 integer ops per (quartet, 4 trees), two of them
 // half-rate popcounts (tools/valu_rates.hip). Bit-slicing removes most of that work. The panel is
-// transposed into bit planes: one element = 8 words = the planes of one taxon pair for 32 trees
-// (word k, bit t = bit k of the LCA depth in tree t; word 7 = "pair present in tree t" for partial
-// batches). With
+// transposed into bit planes: one element = the planes of one taxon pair for 32 trees (word k, bit t =
+// bit k of the LCA depth in tree t; partial batches append a word "pair present in tree t"), stored
+// compactly: only the B planes the batch needs exist in memory. With
 //     L = M[ab] - M[ac] + 2^B   (per lane and c, once per 32 trees)
 //     R = M[bd] - M[cd] + 2^B   (per staged row element, computed by the staging lanes once per wave)
 // the topology test  ab|cd <=> M[ab]+M[cd] > M[ac]+M[bd] <=> L > R  is a (B+1)-bit magnitude
@@ -437,12 +437,11 @@ constexpr int kBPThreads = 256;
 constexpr int kBPPPT = 1;      // pairs per thread (small workgroups: many resident per CU hide the LDS round trips)
 constexpr int kBPPB = kBPThreads * kBPPPT;
 
-// Bit-plane panel: uint4 Pb[n_groups][npairs][2]. Workgroup = (group of 32 trees, 1024 pairs). The
-// four waves work on different trees at the same time: a wave builds the tree's leaf positions and
-// sparse table (range minimum over adj_depth) in its own LDS region -- DS operations of one wave
-// execute in order, so no workgroup barrier is needed -- and answers the workgroup's 1024 pair queries
-// for that tree (2 LDS reads + min each). One barrier, then the 32 depth bytes of every pair are
-// transposed to 7 planes + the presence plane and stored as two coalesced uint4.
+// Bit-plane panel, general builder (any n). Workgroup = (group of 32 trees, 256 pairs). The four waves work on
+// different trees at the same time: a wave builds the tree's leaf positions and sparse table (range minimum over
+// adj_depth) in its own LDS region -- DS operations of one wave execute in order, so no workgroup barrier is
+// needed -- and answers the workgroup's pair queries for that tree (2 LDS reads + min each). One barrier, then
+// the 32 depth bytes of every pair are transposed to planes (+ the presence plane) and stored in the compact layout.
 template <bool PARTIAL>
 __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32_t *__restrict__ leaf_off,
                                                                     const uint16_t *__restrict__ leaf_ids,
@@ -518,19 +517,16 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
                 w[7] |= (absent ? 0u : 1u) << tbit;
             }
         }
-        if (compact_nw) {
-            // compact layout of count_bitslice3_kernel: per tree group uint4 lo[npairs] (planes 0..3), then
-            // (compact_nw - 4) upper words per pair; partial batches: the last word is the presence plane
-            if (PARTIAL) w[compact_nw - 1] = w[7];
-            char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * compact_nw * 4;
-            reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
-            uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (compact_nw - 4);
-            for (uint32_t k = 4; k < compact_nw; ++k) hi[k - 4] = w[k];
-        } else {
-            uint4 *dst = Pb + ((size_t)g * npairs + p) * 2;
-            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        }
+        // compact layout: per tree group uint4 lo[npairs] (planes 0..3), then (compact_nw - 4) upper words per pair;
+        // partial batches: the last word is the presence plane
+        char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * compact_nw * 4;
+        reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
+        uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (compact_nw - 4);
+        const uint32_t plane_words = PARTIAL ? compact_nw - 1 : compact_nw;
+#pragma unroll
+        for (int k = 4; k < 7; ++k)
+            if ((uint32_t)k < plane_words) hi[k - 4] = w[k];
+        if (PARTIAL) hi[compact_nw - 5] = w[7];
     }
 }
 
@@ -578,7 +574,7 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
     if (p >= npairs) return;
     uint32_t x, y;
     unrank2(p, x, y);
-    constexpr int kPlanes = NWC ? (PARTIAL ? NWC - 1 : NWC) : 7; // compact partial elements end with the presence word
+    constexpr int kPlanes = PARTIAL ? NWC - 1 : NWC; // partial elements end with the presence word
     uint32_t w[kBitWords];
 #pragma unroll
     for (int k = 0; k < kBitWords; ++k) w[k] = 0;
@@ -600,18 +596,12 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
         for (int q = 0; q < kPlanes; ++q) w[q] |= ((val >> q) & 1u) << j;
         w[7] |= 1u << j;
     }
-    if (NWC) {
-        if (PARTIAL) w[NWC - 1] = w[7];
-        char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * NWC * 4;
-        reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
-        uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
+    if (PARTIAL) w[NWC - 1] = w[7];
+    char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * NWC * 4;
+    reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
+    uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
 #pragma unroll
-        for (int k = 4; k < NWC; ++k) hi[k - 4] = w[k];
-    } else {
-        uint4 *dst = Pb + ((size_t)g * npairs + p) * 2;
-        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
+    for (int k = 4; k < NWC; ++k) hi[k - 4] = w[k];
 }
 
 hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel,
@@ -634,8 +624,7 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
         hipLaunchKernelGGL(k, grid, block, lds_small, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
                            tree_bytes, (uint4 *)panel);                                                            \
     } while (0)
-            if (compact_nw == 0) { if (partial) QS_BPS(true, 0); else QS_BPS(false, 0); }
-            else if (partial) { // planes + presence word: 5..7
+            if (partial) { // planes + presence word: 5..7
                 if (compact_nw <= 5) QS_BPS(true, 5);
                 else if (compact_nw == 6) QS_BPS(true, 6);
                 else QS_BPS(true, 7);
@@ -676,15 +665,6 @@ constexpr int kTT_LT = ((0x0F & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      //
 constexpr int kTT_GT = ((0xF0 & 0x33) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (a & ~b) | (~(a ^ b) & c): greater-than step
 constexpr int kTT_NOR_AND = (0xF0 & ~(0xCC | 0xAA)) & 0xFF;                   // a & ~(b | c)
 
-// global panel element -> registers; HI = false skips words 4..7 (depth bits < 5 and no presence plane needed)
-template <bool HI> __device__ __forceinline__ Planes load_planes(const uint4 *p) {
-    Planes r;
-    const uint4 lo = p[0];
-    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
-    if (HI) { const uint4 hi = p[1]; r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w; }
-    else { r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0; }
-    return r;
-}
 // LDS image with HW (1, 2 or 4) upper words per slot: words 0..3 at buf[e], the upper words in an array
 // of HW-word records behind the `stride` 16-byte slots
 template <int HW> __device__ __forceinline__ Planes lds_load_hw(const uint4 *buf, uint32_t e, int stride) {
@@ -703,29 +683,6 @@ template <int HW> __device__ __forceinline__ void lds_store_hw(uint4 *buf, uint3
     else if (HW == 2) reinterpret_cast<uint2 *>(buf + stride)[e] = make_uint2(r.w[4], r.w[5]);
     else buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
 }
-// LDS image: words 0..3 of element e at buf[e], words 4..7 at buf[kBsElems + e] (consecutive lanes ->
-// consecutive 16-byte slots: no bank conflicts)
-// WIDE = false: only word 4 of the upper half is live (B <= 4, no presence plane): it is kept in a
-// 4-byte array behind the 16-byte one, which shrinks the image from 32 to 20 bytes per element.
-template <bool WIDE> __device__ __forceinline__ Planes lds_load(const uint4 *buf, uint32_t e, int stride) {
-    const uint4 lo = buf[e];
-    Planes r;
-    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
-    if (WIDE) {
-        const uint4 hi = buf[stride + e];
-        r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
-    } else {
-        r.w[4] = reinterpret_cast<const uint32_t *>(buf + stride)[e];
-        r.w[5] = r.w[6] = r.w[7] = 0;
-    }
-    return r;
-}
-template <bool WIDE> __device__ __forceinline__ void lds_store(uint4 *buf, uint32_t e, int stride, const Planes &r) {
-    buf[e] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
-    if (WIDE) buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
-    else reinterpret_cast<uint32_t *>(buf + stride)[e] = r.w[4];
-}
-
 // x - y + 2^B over B planes -> B+1 planes (unsigned, bias 2^B); word 7 = presence(x) & presence(y)
 template <int B>
 __device__ __forceinline__ Planes sub_biased(const Planes &x, const Planes &y) {
@@ -764,182 +721,6 @@ __device__ __forceinline__ uint32_t gt_planes(const Planes &l, const Planes &r) 
         gt = lut3<kTT_GT>(a, b, gt);
     }
     return gt;
-}
-
-constexpr int kBsElems = (1 + kDB) * kCols;                 // 144 staged elements per wave and buffer
-constexpr int kBsPerLane = (kBsElems + kWave - 1) / kWave;  // 3
-
-// Same work decomposition as count_gather_kernel (wave = tile, lane = (a,b), kDB d slots).
-// B = depth bits; MODE as above.
-template <int B, int MODE, typename CT>
-__global__ __launch_bounds__(kCountThreads) void count_bitslice_kernel(const uint4 *__restrict__ P, uint32_t npairs,
-                                                                       uint32_t n_groups, uint32_t m_trees, uint32_t n,
-                                                                       uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo,
-                                                                       uint32_t n_dblk, uint32_t total_tiles,
-                                                                       const uint32_t *__restrict__ dprefix,
-                                                                       const uint32_t *__restrict__ cprefix,
-                                                                       CT *__restrict__ table,
-                                                                       uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
-                                                                       uint32_t diag) {
-    // diag (QS_DIAG, timing experiments only; results are wrong when set): 1 = no global loads after the
-    // first group, 2 = no LDS commits after the first group, 4 = skip the compare/popcount work
-    constexpr int NB = B + 1;
-    constexpr bool WIDE = (B > 4) || (MODE == MODE_PARTIAL);           // LDS image holds words 4..7
-    constexpr int kImg = WIDE ? kBsElems * 2 : kBsElems + kBsElems / 4; // uint4 slots per wave and buffer
-    __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
-
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
-    if (tile >= total_tiles) return;
-    uint4(*stage)[kImg] = stage_all[wave];
-
-    // ---- tile decode (wave-uniform), identical to count_gather_kernel ----
-    const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
-    const uint32_t local = tile - dprefix[k];
-    const uint32_t d0 = d_lo + k * kDB;
-    const uint32_t d1 = min(d0 + (uint32_t)kDB, d_hi);
-    const uint32_t c = upper_bound_le(cprefix, 2, d1 - 1, local);
-    const uint32_t T = (c + kTB - 1) / kTB, n_off = T * (T - 1) / 2;
-    const uint32_t tl = local - cprefix[c];
-    uint32_t a0, b0, a, b, colA, colB;
-    if (tl < n_off) {
-        uint32_t at, bt;
-        unrank2(tl, at, bt);
-        a0 = at * kTA; b0 = bt * kTB;
-        colA = lane & (kTA - 1); colB = kTA + lane / kTA;
-        a = a0 + colA; b = b0 + (colB - kTA);
-    } else {
-        const uint32_t kd = tl - n_off;
-        a0 = (2 * kd) * kTA; b0 = (2 * kd + 1) * kTB;
-        const uint32_t h = lane >> 5, q = lane & 31;
-        uint32_t ia = 0, ib = 1;
-        if (q < 28) unrank2(q, ia, ib);
-        colA = h * kTA + ia; colB = h * kTA + ib;
-        a = (h ? b0 : a0) + ia; b = (h ? b0 : a0) + ib;
-        if (q >= 28) b = 0xFFFFFFFFu;
-    }
-    const bool lane_valid = (a < b) && (b < c);
-    const uint32_t pi = lane_valid ? (uint32_t)binom2(b) + a : 0u;
-
-    // staging map. LDS slot = row * 16 + col; row 0: pair (x, c); row 1+j: pair (x, d0+j) MINUS pair (c, d0+j);
-    // col < 8: x = a0+col, else x = b0+col-8. An off-diagonal tile of the binary_full variant only ever reads
-    // row 0 at its a-columns (M[ac]) and rows 1..kDB at its b-columns (R of (b,d)): 72 of the 144 slots, so
-    // only those are loaded and written. Diagonal tiles (a and b from the same block) and the general
-    // variants (which also need M[bc] and R of (a,d)) stage all 144.
-    const bool half_stage = (MODE == MODE_BINARY_FULL) && (tl < n_off);
-    const uint32_t n_stage = half_stage ? (uint32_t)(kTA + kDB * kTB) : (uint32_t)kBsElems;
-    uint32_t src[kBsPerLane], sub[kBsPerLane], slot[kBsPerLane];
-#pragma unroll
-    for (int s = 0; s < kBsPerLane; ++s) {
-        const uint32_t e = lane + s * kWave;
-        uint32_t p = 0u, q = 0xFFFFFFFFu, sl = 0u;
-        if (e < n_stage) {
-            uint32_t row, col;
-            if (half_stage) {
-                if (e < (uint32_t)kTA) { row = 0; col = e; }
-                else { row = 1 + (e - kTA) / kTB; col = kTA + (e - kTA) % kTB; }
-            } else { row = e / kCols; col = e % kCols; }
-            sl = row * kCols + col;
-            const uint32_t x = col < (uint32_t)kTA ? a0 + col : b0 + (col - kTA);
-            const uint32_t y = row == 0 ? c : d0 + (row - 1);
-            const bool ok = x < c && y < d1 && (row == 0 || y > c);
-            if (ok) p = (uint32_t)binom2(y) + x;
-            if (row != 0) q = ok ? (uint32_t)binom2(y) + c : 0u;
-        }
-        src[s] = p; sub[s] = q; slot[s] = sl;
-    }
-    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
-
-    uint32_t c0[kDB], c1[kDB], c2[kDB];
-#pragma unroll
-    for (int j = 0; j < kDB; ++j) c0[j] = c1[j] = c2[j] = 0;
-
-    // Software pipeline: the raw panel elements of group g+1 are loaded into registers BEFORE the compute
-    // of group g; the subtraction R = M[x,d] - M[c,d] + 2^B and the LDS write happen AFTER it, so the
-    // load latency is covered by the compute of the current group.
-    constexpr bool HI = (B > 4) || (MODE == MODE_PARTIAL); // words 4..7 of a panel element are needed
-    Planes xr[kBsPerLane], yr[kBsPerLane], ab_next;
-    auto issue = [&](const uint4 *Pg) {
-#pragma unroll
-        for (int s = 0; s < kBsPerLane; ++s) {
-            if (lane + s * kWave < n_stage) {
-                xr[s] = load_planes<HI>(Pg + (size_t)src[s] * 2);
-                if (sub[s] != 0xFFFFFFFFu) yr[s] = load_planes<HI>(Pg + (size_t)sub[s] * 2);
-            }
-        }
-        ab_next = load_planes<HI>(Pg + (size_t)pi * 2);
-    };
-    auto commit = [&](int bufi) {
-#pragma unroll
-        for (int s = 0; s < kBsPerLane; ++s) {
-            if (lane + s * kWave < n_stage) {
-                Planes x = xr[s];
-                if (sub[s] != 0xFFFFFFFFu) x = sub_biased<B>(x, yr[s]); // rows 1..kDB
-                lds_store<WIDE>(stage[bufi], slot[s], kBsElems, x);
-            }
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < kBsPerLane; ++s)
-#pragma unroll
-        for (int k2 = 0; k2 < kBitWords; ++k2) { xr[s].w[k2] = 0; yr[s].w[k2] = 0; }
-    issue(P);
-    commit(0);
-
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        const Planes ab = ab_next;
-        const uint4 *buf = stage[g & 1];
-        if (g + 1 < n_groups && !(diag & 1u)) issue(P + (size_t)(g + 1) * npairs * 2);
-        const Planes ac = lds_load<WIDE>(buf, colA, kBsElems);
-        const Planes L1 = sub_biased<B>(ab, ac); // M[ab] - M[ac] + 2^B ; w[7] = present(a,b) & present(a,c)
-        Planes L2;
-        if (MODE != MODE_BINARY_FULL) {
-            const Planes bc = lds_load<WIDE>(buf, colB, kBsElems);
-            L2 = sub_biased<B>(ab, bc);          // M[ab] - M[bc] + 2^B
-        }
-        if (diag & 4u) c0[0] += L1.w[0]; else
-#pragma unroll
-        for (int j = 0; j < kDB; ++j) {
-            if ((uint32_t)j >= jlo && (uint32_t)j < jhi) { // wave-uniform
-                const Planes Rb = lds_load<WIDE>(buf, (1 + j) * kCols + colB, kBsElems); // M[bd] - M[cd] + 2^B
-                uint32_t gt, lt;
-                cmp_planes<NB>(L1, Rb, gt, lt);
-                if (MODE == MODE_BINARY_FULL) {
-                    popc_acc(gt, c0[j]);
-                    popc_acc(lt, c1[j]);
-                } else {
-                    const Planes Ra = lds_load<WIDE>(buf, (1 + j) * kCols + colA, kBsElems); // M[ad] - M[cd] + 2^B
-                    uint32_t g2 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, L2), gt, lt);    // S1 == S2 and S3 > S1
-                    if (MODE == MODE_PARTIAL) {
-                        const uint32_t v = L1.w[7] & Rb.w[7]; // a,b,c,d all present
-                        gt &= v; lt &= v; g2 &= v;
-                    }
-                    popc_acc(gt, c0[j]);
-                    popc_acc(lt, c1[j]);
-                    popc_acc(g2, c2[j]);
-                }
-            }
-        }
-        if (g + 1 < n_groups && !(diag & 2u)) commit((g + 1) & 1);
-    }
-
-    if (!lane_valid) return;
-    const uint64_t rc = binom3(c) + pi;
-#pragma unroll
-    for (int j = 0; j < kDB; ++j) {
-        const uint32_t d = d0 + j;
-        if (d < d1 && d > c) {
-            const uint64_t idx = (binom4(d) + rc - rank_lo) * 3;
-            uint32_t n0 = c0[j], n1 = c1[j], n2 = (MODE == MODE_BINARY_FULL) ? (m_trees - c0[j] - c1[j]) : c2[j];
-            uint32_t v0 = n0, v1 = n1, v2 = n2;
-            if (!overwrite) { v0 += (uint32_t)table[idx]; v1 += (uint32_t)table[idx + 1]; v2 += (uint32_t)table[idx + 2]; }
-            if (sizeof(CT) == 2 && ((v0 | v1 | v2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
-            table[idx] = (CT)v0;
-            table[idx + 1] = (CT)v1;
-            table[idx + 2] = (CT)v2;
-        }
-    }
 }
 
 // ======================================================================================
@@ -1278,37 +1059,6 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const v
     return hipGetLastError();
 }
 
-hipError_t launch_count_bitslice(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
-                                 uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
-                                 bool overwrite) {
-    if (g.total_tiles == 0) return hipSuccess;
-    const uint32_t npairs = (uint32_t)binom2(g.n);
-    dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
-    const char *de = getenv("QS_DIAG");
-    const uint32_t diag = de ? (uint32_t)atoi(de) : 0u;
-#define QS_BS(BB, M, CT)                                                                                            \
-    hipLaunchKernelGGL((count_bitslice_kernel<BB, M, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
-                       m_trees, g.n, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,      \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, diag)
-#define QS_BS_M(BB, CT)                                                                                             \
-    do {                                                                                                            \
-        if (mode == MODE_BINARY_FULL) QS_BS(BB, MODE_BINARY_FULL, CT);                                              \
-        else if (mode == MODE_GENERAL_FULL) QS_BS(BB, MODE_GENERAL_FULL, CT);                                       \
-        else QS_BS(BB, MODE_PARTIAL, CT);                                                                           \
-    } while (0)
-#define QS_BS_B(CT)                                                                                                 \
-    do {                                                                                                            \
-        if (depth_bits <= 4) QS_BS_M(4, CT);                                                                        \
-        else if (depth_bits == 5) QS_BS_M(5, CT);                                                                   \
-        else if (depth_bits == 6) QS_BS_M(6, CT);                                                                   \
-        else QS_BS_M(7, CT);                                                                                        \
-    } while (0)
-    if (count_bits == 32) QS_BS_B(uint32_t); else QS_BS_B(uint16_t);
-#undef QS_BS_B
-#undef QS_BS_M
-#undef QS_BS
-    return hipGetLastError();
-}
 
 // ======================================================================================
 // scatter count kernel (tree-major, atomics)

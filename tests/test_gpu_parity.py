@@ -64,15 +64,11 @@ CASES = [
 
 @pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES)
 @pytest.mark.parametrize("count_bits", [32, 16])
-@pytest.mark.parametrize("impl", ["bitslice", "bitslice1", "bitslice_bigpanel", "swar"])
+@pytest.mark.parametrize("impl", ["bitslice", "bitslice_bigpanel", "swar"])
 def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, rooted, seed, variant, count_bits, impl):
-    """All gather implementations: bit-sliced (default; binary_full batches take the kernel with two a-columns
-    per lane, "bitslice1" forces the one-column kernel, "bitslice_bigpanel" the panel builder meant for
-    n > ~256) and the byte-SWAR one (fallback for deep trees)."""
-    if impl == "bitslice1":
-        monkeypatch.setenv("QS_BITSLICE_TILE", "1")
-        impl = "bitslice"
-    elif impl == "bitslice_bigpanel":
+    """Both gather implementations: bit-sliced (default: count_bitslice3_kernel; "bitslice_bigpanel" forces the
+    panel builder meant for n > ~256) and the byte-SWAR one (fallback for deep trees)."""
+    if impl == "bitslice_bigpanel":
         monkeypatch.setenv("QS_PANEL_KERNEL", "big")
         impl = "bitslice"
     monkeypatch.setenv("QS_GATHER_IMPL", impl)
@@ -101,14 +97,12 @@ def test_scatter_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, va
 
 
 @pytest.mark.parametrize("n", [4, 5, 6, 7, 9, 15, 17])
-@pytest.mark.parametrize("impl", ["bitslice", "bitslice1", "swar", "scatter"])
+@pytest.mark.parametrize("impl", ["bitslice", "swar", "scatter"])
 def test_tiny_and_odd_taxon_counts(eng, monkeypatch, n, impl):
     """Edge geometry: fewer taxa than one tile, n not a multiple of the tile or d-block size, m = 1."""
     algo = eng.QS_ALGO_GATHER
     if impl == "scatter":
         algo = eng.QS_ALGO_SCATTER
-    elif impl == "bitslice1":
-        monkeypatch.setenv("QS_BITSLICE_TILE", "1")
     elif impl == "swar":
         monkeypatch.setenv("QS_GATHER_IMPL", "swar")
     for m, kw in ((1, {}), (33, {}), (21, dict(collapse=0.3)), (19, dict(dropout=0.3))):
