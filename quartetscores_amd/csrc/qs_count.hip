@@ -787,7 +787,8 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
                                                                         const uint32_t *__restrict__ dprefix,
                                                                         const uint32_t *__restrict__ cprefix,
                                                                         CT *__restrict__ table,
-                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite) {
+                                                                        uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
+                                                                        uint32_t xcd_remap) {
     constexpr bool BIN = MODE == MODE_BINARY_FULL, PART = MODE == MODE_PARTIAL;
     constexpr int NB = B + 1;
     constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
@@ -804,7 +805,16 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     uint4 *buf0 = stage_all[wave][0], *buf1 = stage_all[wave][1];
 
     // ---- tile decode (wave-uniform): d-block k counts down from the top of the shard ----
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    // Workgroups with the same blockIdx % 8 share an XCD (observed dispatch rule, used for speed only). With
+    // xcd_remap every XCD walks its own contiguous eighth of the tile list, so its 4 MB L2 holds the panel rows of
+    // one (d-block, c) neighbourhood instead of all eight: +4 % at 512 taxa, +1.5 % at 256, -2 % at 128 (there the
+    // whole panel fits every L2), so the launcher sets it from 200 taxa on.
+    uint32_t lb = blockIdx.x;
+    if (xcd_remap) {
+        const uint32_t nb = gridDim.x, q8 = nb / 8, r8 = nb % 8, xcd = lb % 8, y = lb / 8;
+        lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + y; // bijective on [0, nb)
+    }
+    const uint32_t tile = lb * kWavesPerBlock + wave;
     if (tile >= total_tiles) return;
     const uint32_t k = upper_bound_le(dprefix, 0, n_dblk, tile);
     const uint32_t local = tile - dprefix[k];
@@ -1029,7 +1039,7 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const v
 #define QS_BS3(BB, MM, CT)                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 1u : 0u)
 #define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
         if (depth_bits <= 4) QS_BS3(4, MM, CT);                                                                     \

@@ -195,6 +195,35 @@ def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     assert (T2.astype(np.uint64) == oracle_counts(ref_nw, trees2).counts()).all()
 
 
+@pytest.mark.parametrize("n,bits", [(20, 5), (40, 6), (80, 7)])
+@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial"])
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, kind, count_bits):
+    """All (depth bits B, mode) instances of count_bitslice3_kernel: a caterpillar that is not re-rooted forces
+    depth n-2; 40 trees span two 32-tree groups; both panel builders. Partial batches carry at most 6 depth bits
+    in the bit-sliced kernel (7 fall back to the byte-SWAR one)."""
+    ref_nw = synth.reference_tree(n, 200 + n)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    kw = {"binary_full": {}, "general_full": {"collapse": 0.25}, "partial": {"dropout": 0.15, "collapse": 0.1}}[kind]
+    trees = [cat + ";"] * 2 + synth.tree_set(n, 38, 300 + n, **kw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
+    assert (1 << (bits - 1)) <= int(batch.adj_depth.max()) < (1 << bits)
+    want = oracle_counts(ref_nw, trees).counts()
+    for builder in ("small", "big"):
+        monkeypatch.setenv("QS_PANEL_KERNEL", builder)
+        ctx, T = gpu_table(eng, ref, batch, count_bits)
+        v = ctx.last_count_variant()
+        assert kind in v
+        if kind == "partial" and bits == 7:
+            assert "depth_u" in v
+        else:
+            assert f"bitslice_b{bits}" in v
+        assert (T.astype(np.uint64) == want).all(), (builder, v)
+
+
 def test_very_deep_trees_fall_back_to_swar_u16(eng):
     n = 150
     ref_nw = synth.reference_tree(n, 19)
