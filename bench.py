@@ -349,7 +349,7 @@ def main():
     except Exception:
         pass
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0 would stall the other ranks' exit)
         try:
             from oracle_api import Oracle
             ncpu = os.cpu_count() or 1
