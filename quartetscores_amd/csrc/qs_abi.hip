@@ -45,6 +45,8 @@ struct qs_ctx {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
     bool ev_valid = false;
+    double *dev_logk = nullptr, *dev_invk = nullptr; // tables of the device QIC (qs_score.hip), tbl_n entries each
+    uint32_t tbl_n = 0;
     // scoring view (qs_score_set_view): tuples [view_rank_lo, view_rank_lo + view_n) in caller-owned device memory
     const void *view_table = nullptr;
     uint32_t view_bits = 0;
@@ -155,6 +157,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->dprefix) (void)hipFree(c->dprefix);
     if (c->cprefix) (void)hipFree(c->cprefix);
     if (c->dprefix3) (void)hipFree(c->dprefix3);
+    if (c->dev_logk) (void)hipFree(c->dev_logk);
+    if (c->dev_invk) (void)hipFree(c->dev_invk);
     if (c->dprefix1t) (void)hipFree(c->dprefix1t);
     if (c->cprefix3) (void)hipFree(c->cprefix3);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
@@ -594,7 +598,27 @@ struct DevPtr { // RAII for a hipMalloc'ed pointer
     ~DevPtr() { if (p) (void)hipFree(p); }
 };
 
+// log(k) and 1/k for the integer arguments of the device QIC: every count and every tuple sum is at most the
+// number of trees counted. Unknown (uploaded / attached tables, reduce-scattered shards): 65536 entries, larger
+// values take the kernel's slow path.
+static int ensure_score_tables(qs_ctx *c) {
+    const uint64_t want64 = std::min<uint64_t>(std::max<uint64_t>(c->trees_counted + 1, 65536), 1ull << 20);
+    const uint32_t want = (uint32_t)want64;
+    if (c->tbl_n >= want) return QS_OK;
+    if (c->dev_logk) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dev_logk); (void)hipFree(c->dev_invk); c->dev_logk = c->dev_invk = nullptr; c->tbl_n = 0; }
+    std::vector<double> lk(want), ik(want);
+    lk[0] = 0.0; ik[0] = 0.0;
+    for (uint32_t k = 1; k < want; ++k) { lk[k] = std::log((double)k); ik[k] = 1.0 / (double)k; }
+    QS_HIP(c, hipMalloc(&c->dev_logk, (size_t)want * 8));
+    QS_HIP(c, hipMalloc(&c->dev_invk, (size_t)want * 8));
+    QS_HIP(c, hipMemcpy(c->dev_logk, lk.data(), (size_t)want * 8, hipMemcpyHostToDevice));
+    QS_HIP(c, hipMemcpy(c->dev_invk, ik.data(), (size_t)want * 8, hipMemcpyHostToDevice));
+    c->tbl_n = want;
+    return QS_OK;
+}
+
 static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t *lca_dev, ScoreDevice &sd) {
+    sd.logk = c->dev_logk; sd.invk = c->dev_invk; sd.tbl_n = c->tbl_n;
     sd.ref_lca = lca_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
     if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }
@@ -634,6 +658,7 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
     QS_HIP(c, hipMemsetAsync(sums_dev, 0, np * 3 * 8, c->stream));
     QS_HIP(c, hipMemsetAsync(min_dev, 0x7F, np * 8, c->stream));
+    { int rc_t = ensure_score_tables(c); if (rc_t != QS_OK) return rc_t; }
     ScoreDevice sd;
     fill_score_device(c, R, (const uint32_t *)lca.p, sd);
     sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
@@ -655,6 +680,7 @@ extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *
     QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
     QS_HIP(c, hipMemsetAsync(cand_dev, 0xFF, np * kCand * 8, c->stream));
     QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
+    { int rc_t = ensure_score_tables(c); if (rc_t != QS_OK) return rc_t; }
     ScoreDevice sd;
     fill_score_device(c, R, (const uint32_t *)lca.p, sd);
     sd.pair_min = (long long *)min_dev; sd.pair_cand = (unsigned long long *)cand_dev;
@@ -766,6 +792,7 @@ extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64
     QS_HIP(c, hipMalloc(&dt, nq));
     hipError_t e = hipMalloc(&dq, nq * 24);
     if (e != hipSuccess) { (void)hipFree(dt); return fail(c, QS_ERR_OOM, "qs_raw_qic: hipMalloc"); }
+    { int rc_t = ensure_score_tables(c); if (rc_t != QS_OK) return rc_t; }
     ScoreDevice sd;
     fill_score_device(c, R, (const uint32_t *)lca.p, sd);
     sd.frame = 1; // printRawQICScores uses the multifurcating loop's argument order

@@ -77,6 +77,8 @@ struct ScoreDevice {
     long long *pair_min;           // n_inner*n_inner (f64_to_sortable of the device QIC)
     unsigned long long *pair_cand; // n_inner*n_inner*kCand
     uint32_t *flags;               // [0] candidate overflow
+    const double *logk, *invk;     // log(k) (0 at k = 0) and 1/k for k < tbl_n: integer arguments of the device QIC
+    uint32_t tbl_n;
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
                                    //    order of the multifurcating / raw-QIC loops (QSC:551-558, 661-668)
 };

@@ -27,16 +27,45 @@
 
 namespace qs {
 
-// QuartetScoreComputer.hpp:135-159 (device evaluation; only used to ORDER candidates)
-__device__ __forceinline__ double dev_log_score(uint32_t q1, uint32_t q2, uint32_t q3) {
+// QuartetScoreComputer.hpp:135-159 (device evaluation; only used to ORDER candidates -- the host re-evaluates the
+// near-minimal ones with libm). With s = q1+q2+q3:  sum_i (q_i/s) log(q_i/s) = (sum_i q_i log q_i) / s - log s,
+// and every argument is a small integer (<= number of trees), so log k and 1/k come from tables built on the host:
+// 4 lookups + a handful of f64 ops instead of 3 divisions + 3 logs. Values beyond the tables take the slow path.
+__device__ __forceinline__ double dev_logk(const ScoreDevice &sd, uint32_t k) {
+    return k < sd.tbl_n ? sd.logk[k] : log((double)k);
+}
+__device__ __forceinline__ double dev_log_score(const ScoreDevice &sd, uint32_t q1, uint32_t q2, uint32_t q3) {
     if ((q1 | q2 | q3) == 0) return 0.0;
-    const double sum = (double)((uint64_t)q1 + q2 + q3);
+    const uint64_t s64 = (uint64_t)q1 + q2 + q3;
     const double inv_log3 = 0.91023922662683739361;
-    double qic = 1.0;
-    if (q1) { double p = (double)q1 / sum; qic += p * log(p) * inv_log3; }
-    if (q2) { double p = (double)q2 / sum; qic += p * log(p) * inv_log3; }
-    if (q3) { double p = (double)q3 / sum; qic += p * log(p) * inv_log3; }
+    double acc = 0.0; // sum q_i log q_i (0 log 0 = 0: logk[0] is stored as 0)
+    acc += (double)q1 * dev_logk(sd, q1);
+    acc += (double)q2 * dev_logk(sd, q2);
+    acc += (double)q3 * dev_logk(sd, q3);
+    double inv_s, log_s;
+    if (s64 < sd.tbl_n) { inv_s = sd.invk[s64]; log_s = sd.logk[s64]; }
+    else { inv_s = 1.0 / (double)s64; log_s = log((double)s64); }
+    const double qic = 1.0 + (acc * inv_s - log_s) * inv_log3;
     return (q1 < q2 || q1 < q3) ? -qic : qic;
+}
+
+// Ranks are walked in blocks of consecutive values: the block's first rank is un-ranked once (f64 sqrt / cbrt,
+// ~300 instructions), every other rank of the block from it: rank = C(d,4) + C(c,3) + (C(b,2) + a), so adding `off`
+// to the pair rank and carrying into c (and d) is enough; unrank2 is a float sqrt and two corrections.
+struct Ids4 { uint32_t a, b, c, d; };
+__device__ __forceinline__ Ids4 decode_near(const Ids4 &base, uint32_t off) {
+    Ids4 r;
+    uint32_t c = base.c, d = base.d;
+    uint64_t pr = binom2(base.b) + base.a + off;
+    for (;;) {
+        const uint64_t lim = binom2(c);
+        if (pr < lim) break;
+        pr -= lim;
+        if (++c == d) { ++d; c = 2; }
+    }
+    unrank2((uint32_t)pr, r.a, r.b);
+    r.c = c; r.d = d;
+    return r;
 }
 
 struct QuartetRef {
@@ -47,10 +76,9 @@ struct QuartetRef {
 };
 
 template <typename CT>
-__device__ __forceinline__ QuartetRef classify(const ScoreDevice &sd, uint64_t local_rank) {
+__device__ __forceinline__ QuartetRef classify(const ScoreDevice &sd, uint64_t local_rank, const Ids4 &ids) {
     QuartetRef r;
-    uint32_t a, b, c, d;
-    unrank4(local_rank + sd.rank_lo, a, b, c, d);
+    const uint32_t a = ids.a, b = ids.b, c = ids.c, d = ids.d;
     const uint32_t e01 = sd.ref_lca[(size_t)b * sd.n + a];
     const uint32_t e12 = sd.ref_lca[(size_t)c * sd.n + b];
     const uint32_t e23 = sd.ref_lca[(size_t)d * sd.n + c];
@@ -114,14 +142,16 @@ __global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
     }
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
+    Ids4 base_ids;
+    unrank4(base + sd.rank_lo, base_ids.a, base_ids.b, base_ids.c, base_ids.d);
     for (int it = 0; it < kP1Iters; ++it) {
         const uint64_t r = base + (uint64_t)it * 256 + tid;
         QuartetRef q;
         q.resolved = false; q.key = kKeyEmpty; q.q1 = q.q2 = q.q3 = 0;
-        if (r < sd.n_tuples) q = classify<CT>(sd, r);
+        if (r < sd.n_tuples) q = classify<CT>(sd, r, decode_near(base_ids, (uint32_t)it * 256 + tid));
         const uint32_t key = q.resolved ? q.key : kKeyEmpty;
         unsigned long long s1 = q.q1, s2 = q.q2, s3 = q.q3;
-        long long mn = q.resolved ? f64_to_sortable(dev_log_score(q.q1, q.q2, q.q3)) : kSortableMax;
+        long long mn = q.resolved ? f64_to_sortable(dev_log_score(sd, q.q1, q.q2, q.q3)) : kSortableMax;
         // runs of equal keys inside the wave
         const uint32_t prev = __shfl_up(key, 1, 64);
         const bool head = (lane == 0) || (prev != key);
@@ -172,39 +202,51 @@ __device__ __forceinline__ uint32_t gcd_u32(uint32_t x, uint32_t y) {
 
 template <typename CT>
 __global__ __launch_bounds__(256) void score_pass2_kernel(ScoreDevice sd, double tol) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= sd.n_tuples) return;
-    const QuartetRef q = classify<CT>(sd, r);
-    if (!q.resolved) return;
-    const double sc = dev_log_score(q.q1, q.q2, q.q3);
-    const double mn = sortable_to_f64(sd.pair_min[q.key]);
-    if (!(sc <= mn + tol)) return;
-    uint32_t g = gcd_u32(gcd_u32(q.q1, q.q2), q.q3);
-    if (g == 0) g = 1;
-    const uint32_t a = q.q1 / g, b = q.q2 / g, c = q.q3 / g;
-    if ((a | b | c) >> 21) { atomicOr(&sd.flags[0], 2u); return; }
-    const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
-    unsigned long long *slots = sd.pair_cand + (size_t)q.key * kCand;
-    // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
-    for (int s = 0; s < kCand; ++s) {
-        unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == packed) return;
-        if (cur == kCandEmpty) {
-            unsigned long long old = atomicCAS(&slots[s], kCandEmpty, packed);
-            if (old == kCandEmpty || old == packed) return;
+    const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
+    Ids4 base_ids;
+    unrank4(base + sd.rank_lo, base_ids.a, base_ids.b, base_ids.c, base_ids.d);
+    for (int it = 0; it < kP1Iters; ++it) {
+        const uint64_t r = base + (uint64_t)it * 256 + threadIdx.x;
+        if (r >= sd.n_tuples) return;
+        const QuartetRef q = classify<CT>(sd, r, decode_near(base_ids, (uint32_t)it * 256 + threadIdx.x));
+        if (!q.resolved) continue;
+        const double sc = dev_log_score(sd, q.q1, q.q2, q.q3);
+        const double mn = sortable_to_f64(sd.pair_min[q.key]);
+        if (!(sc <= mn + tol)) continue;
+        uint32_t g = gcd_u32(gcd_u32(q.q1, q.q2), q.q3);
+        if (g == 0) g = 1;
+        const uint32_t a = q.q1 / g, b = q.q2 / g, c = q.q3 / g;
+        if ((a | b | c) >> 21) { atomicOr(&sd.flags[0], 2u); continue; }
+        const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
+        unsigned long long *slots = sd.pair_cand + (size_t)q.key * kCand;
+        // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
+        bool placed = false;
+        for (int s = 0; s < kCand && !placed; ++s) {
+            unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == packed) placed = true;
+            else if (cur == kCandEmpty) {
+                unsigned long long old = atomicCAS(&slots[s], kCandEmpty, packed);
+                if (old == kCandEmpty || old == packed) placed = true;
+            }
         }
+        if (!placed) atomicOr(&sd.flags[0], 1u);
     }
-    atomicOr(&sd.flags[0], 1u);
 }
 
 template <typename CT>
 __global__ __launch_bounds__(256) void raw_qic_kernel(ScoreDevice sd, uint64_t r0, uint64_t nq, uint8_t *__restrict__ topo,
                                                       unsigned long long *__restrict__ qout) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    const QuartetRef q = classify<CT>(sd, r0 + i);
-    topo[i] = q.topo;
-    qout[3 * i] = q.q1; qout[3 * i + 1] = q.q2; qout[3 * i + 2] = q.q3;
+    const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
+    if (base >= nq) return;
+    Ids4 base_ids;
+    unrank4(r0 + base + sd.rank_lo, base_ids.a, base_ids.b, base_ids.c, base_ids.d);
+    for (int it = 0; it < kP1Iters; ++it) {
+        const uint64_t i = base + (uint64_t)it * 256 + threadIdx.x;
+        if (i >= nq) return;
+        const QuartetRef q = classify<CT>(sd, r0 + i, decode_near(base_ids, (uint32_t)it * 256 + threadIdx.x));
+        topo[i] = q.topo;
+        qout[3 * i] = q.q1; qout[3 * i + 1] = q.q2; qout[3 * i + 2] = q.q3;
+    }
 }
 
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
@@ -218,7 +260,8 @@ hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
 
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) {
     if (sd.n_tuples == 0) return hipSuccess;
-    dim3 block(256), grid((unsigned)((sd.n_tuples + 255) / 256));
+    const uint64_t per_block = 256ull * kP1Iters;
+    dim3 block(256), grid((unsigned)((sd.n_tuples + per_block - 1) / per_block));
     if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass2_kernel<uint32_t>, grid, block, 0, s, sd, tol);
     else hipLaunchKernelGGL(score_pass2_kernel<uint16_t>, grid, block, 0, s, sd, tol);
     return hipGetLastError();
@@ -227,7 +270,8 @@ hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) 
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
                           unsigned long long *q_dev) {
     if (nq == 0) return hipSuccess;
-    dim3 block(256), grid((unsigned)((nq + 255) / 256));
+    const uint64_t per_block = 256ull * kP1Iters;
+    dim3 block(256), grid((unsigned)((nq + per_block - 1) / per_block));
     if (sd.count_bits == 32) hipLaunchKernelGGL(raw_qic_kernel<uint32_t>, grid, block, 0, s, sd, r0, nq, topo_dev, q_dev);
     else hipLaunchKernelGGL(raw_qic_kernel<uint16_t>, grid, block, 0, s, sd, r0, nq, topo_dev, q_dev);
     return hipGetLastError();

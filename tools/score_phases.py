@@ -1,0 +1,26 @@
+import time, numpy as np, torch, sys
+sys.path.insert(0, '/root/repo')
+from quartetscores_amd import engine, flatten, synth, _lib
+for n, m in ((128, 1000), (256, 2000)):
+    ref_nw = synth.reference_tree(n, 2000)
+    trees = synth.tree_set(n, m, 2001)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = engine.Context(n, 32)
+    ctx.table_alloc()
+    ctx.count_trees(batch)
+    def t(f, reps=5):
+        torch.cuda.synchronize(); best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        return best * 1e3, r
+    ms_all, _ = t(lambda: ctx.score(ref))
+    P = ctx.score_pair_slots(ref)
+    sums = torch.empty(3 * P, dtype=torch.int64, device="cuda"); mins = torch.empty(P, dtype=torch.int64, device="cuda")
+    cand = torch.empty(8 * P, dtype=torch.int64, device="cuda")
+    ms1, _ = t(lambda: ctx.score_pass1(ref, sums, mins))
+    ms2, _ = t(lambda: ctx.score_pass2(ref, mins, cand))
+    sh, ch = sums.cpu().numpy(), cand.cpu().numpy()[None, :]
+    ms3, _ = t(lambda: ctx.score_finish(ref, sh, ch))
+    msd, _ = t(lambda: (sums.cpu(), cand.cpu()))
+    print(f"n={n}: qs_score {ms_all:.3f} ms | pass1 call {ms1:.3f} pass2 call {ms2:.3f} d2h {msd:.3f} finish {ms3:.3f}  P={P}")
