@@ -131,6 +131,36 @@ __device__ __forceinline__ void p1_global_add(const ScoreDevice &sd, uint32_t ke
     atomicMin(&sd.pair_min[key], mn);
 }
 
+// lane l <- lane l - k of the same 16-lane row (DPP row_shr:k, CTRL = 0x110 + k); lanes without a source get `old`
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_shr(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_shr64(unsigned long long v) {
+    const uint32_t lo = dpp_shr<CTRL>(0u, (uint32_t)v), hi = dpp_shr<CTRL>(0u, (uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ void seg_step(uint32_t run, unsigned long long &s1, unsigned long long &s2, unsigned long long &s3,
+                                         long long &mn) {
+    const uint32_t orun = dpp_shr<CTRL>(0xFFFFFFFFu, run);
+    const unsigned long long o1 = dpp_shr64<CTRL>(s1), o2 = dpp_shr64<CTRL>(s2), o3 = dpp_shr64<CTRL>(s3);
+    const long long om = (long long)dpp_shr64<CTRL>((unsigned long long)mn);
+    if (orun == run) { s1 += o1; s2 += o2; s3 += o3; mn = om < mn ? om : mn; }
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int SRC>
+__device__ __forceinline__ void seg_carry(uint32_t lane, uint32_t run, unsigned long long &s1, unsigned long long &s2,
+                                          unsigned long long &s3, long long &mn) {
+    const uint32_t crun = (uint32_t)__builtin_amdgcn_readlane((int)run, SRC);
+    const unsigned long long c1 = readlane64(s1, SRC), c2 = readlane64(s2, SRC), c3 = readlane64(s3, SRC);
+    const long long cm = (long long)readlane64((unsigned long long)mn, SRC);
+    if (lane > (uint32_t)SRC && lane <= (uint32_t)SRC + 16 && run == crun) { s1 += c1; s2 += c2; s3 += c3; mn = cm < mn ? cm : mn; }
+}
+
 template <typename CT>
 __global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
     __shared__ P1Lds lds;
@@ -157,13 +187,16 @@ __global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
         const bool head = (lane == 0) || (prev != key);
         const unsigned long long heads = __ballot(head);
         const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t orun = __shfl_up(run, off, 64);
-            const unsigned long long o1 = __shfl_up(s1, off, 64), o2 = __shfl_up(s2, off, 64), o3 = __shfl_up(s3, off, 64);
-            const long long om = __shfl_up(mn, off, 64);
-            if ((int)lane >= off && orun == run) { s1 += o1; s2 += o2; s3 += o3; mn = om < mn ? om : mn; }
-        }
+        // segmented inclusive scan over the runs: inside each row of 16 lanes with DPP row shifts (VALU, no LDS
+        // traffic; the ds_bpermute version of this scan was what bounded the kernel), then the last lane of each
+        // row is carried into the lanes of the next row that continue its run (3 readlane steps)
+        seg_step<0x111>(run, s1, s2, s3, mn);
+        seg_step<0x112>(run, s1, s2, s3, mn);
+        seg_step<0x114>(run, s1, s2, s3, mn);
+        seg_step<0x118>(run, s1, s2, s3, mn);
+        seg_carry<15>(lane, run, s1, s2, s3, mn);
+        seg_carry<31>(lane, run, s1, s2, s3, mn);
+        seg_carry<47>(lane, run, s1, s2, s3, mn);
         const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
         if (tail && key != kKeyEmpty) {
             uint32_t slot = (key * 2654435761u) >> 22; // 10 bits
