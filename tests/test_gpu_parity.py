@@ -671,3 +671,24 @@ def test_count_trees_reduce_scatter_single_rank(eng):
         got = distributed.score_sharded(ctx, ref)
         for a, b in zip(got[:3], want[:3]):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_config1_fixture_on_the_gpu(eng):
+    """BASELINE configs[0] against the committed fixture (tests/golden/config1.json): table hash in canonical
+    taxon order and every internal edge's LQ/QP/EQP-IC as hex doubles."""
+    import hashlib
+    import json
+    import os
+    from helpers import remap_table
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1.json")))
+    n, m = fx["n"], fx["m"]
+    trees = synth.tree_set(n, m, fx["eval_seed"])
+    assert synth.reference_tree(n, fx["ref_seed"]) == fx["ref"] and trees[0] == fx["first_tree"] and trees[-1] == fx["last_tree"]
+    qsc = eng.QuartetScoreComputer(fx["ref"], trees, device=0)
+    names = list(qsc.ref.names)
+    perm = [names.index(f"t{i}") for i in range(n)]
+    table = remap_table(qsc.quartetCounterLookup.table(), perm).astype("<u4")
+    assert hashlib.sha256(np.ascontiguousarray(table).tobytes()).hexdigest() == fx["table_sha256"]
+    got = {",".join(sorted(k, key=lambda s: int(s[1:]))): [float(x).hex() for x in v]
+           for k, v in qsc.scores_by_bipartition().items()}
+    assert got == fx["scores_lq_qp_eqp_hex"]

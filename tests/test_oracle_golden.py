@@ -207,3 +207,18 @@ def test_log_score_known_values():
 
 def test_canonical_split_helper():
     assert canonical_split(["a", "b", "c", "d"], [1, 1, 0, 0]) == frozenset(["c", "d"])
+
+
+def test_config1_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/config1.json (BASELINE configs[0], frozen by make_config1_fixture.py): the oracle of today and
+    the tree generator of today still give the committed table hash and the committed scores, bit for bit."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_config1_fixture", os.path.join(here, "make_config1_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.build()
+    want = json.load(open(os.path.join(here, "config1.json")))
+    assert got == want
