@@ -46,12 +46,13 @@ def parse_args():
     ap.add_argument("--no-score", action="store_true")
     ap.add_argument("--distinct-trees", type=int, default=0,
                     help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
+    ap.add_argument("--nni", action="store_true", help="evaluation trees = reference tree + Poisson(n/8) random NNIs (concentrated counts)")
     ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees)")
     ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees)")
     ap.add_argument("--reduce", choices=["scatter", "all"], default="scatter",
                     help="N>1: reduce-scatter (each rank keeps and scores a shard of the reduced table) or all-reduce")
-    ap.add_argument("--wire", choices=["auto", "u16", "u32"], default="auto",
-                    help="N>1: cell width on the wire of the table all-reduce (auto = u16 while world x trees < 65536)")
+    ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto",
+                    help="N>1: format of the table on the wire (auto: while world x trees < 65536, u16x2 for binary full trees, else u16)")
     ap.add_argument("--table-shards", type=int, default=1,
                     help="table-sharded mode (configs[4]): split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=0, help="which shard this single-GPU run owns")
@@ -90,7 +91,11 @@ def main():
     # seeded inputs: seed = 1000 * config + tree set id; rank r counts tree set r
     ref_nw = synth.reference_tree(n, 2000)
     distinct = min(args.distinct_trees or m, m)
-    trees = synth.tree_set(n, distinct, 2001 + rank, collapse=args.collapse, dropout=args.dropout)
+    if args.nni:   # SURVEY 8(d), second distribution: the reference tree + Poisson(n/8) random NNIs -> concentrated counts
+        assert not (args.collapse or args.dropout), "--nni trees are binary and full"
+        trees = synth.nni_tree_set(ref_nw, distinct, 2001 + rank)
+    else:
+        trees = synth.tree_set(n, distinct, 2001 + rank, collapse=args.collapse, dropout=args.dropout)
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     if distinct < m:  # tile the flattened trees (needs every tree to hold all n taxa -> fixed stride)
@@ -120,19 +125,29 @@ def main():
     # QuartetScores.cpp:115-147) the u32 table is packed to u16 cells first (qs_table_pack16): half the bytes again.
     from quartetscores_amd import distributed
     tables = [table]
-    wire16 = (use_dist and args.count_bits == 32 and args.algo == "gather"
-              and (args.wire == "u16" or (args.wire == "auto" and world * m < 65536)))
+    binary_full_trees = not (args.collapse or args.dropout)
+    wire_fmt = None                       # None: the table's own cells travel; "u16" / "u16x2": packed first
+    if use_dist and args.count_bits == 32 and args.algo == "gather":
+        small = world * m < 65536
+        if args.wire == "u16x2" or (args.wire == "auto" and small and binary_full_trees):
+            wire_fmt = "u16x2"            # one word n0 | n1 << 16 per tuple (n2 = world * m - n0 - n1)
+        elif args.wire == "u16" or (args.wire == "auto" and small):
+            wire_fmt = "u16"
+    wire16 = wire_fmt is not None
+    if wire16:
+        assert world * m < 65536, "--wire u16 / u16x2 need world x trees < 65536"
+    assert wire_fmt != "u16x2" or binary_full_trees, "--wire u16x2 needs binary trees that hold all taxa"
     reduce_mode = args.reduce if use_dist else None
     bits_wire = 16 if wire16 else args.count_bits
+    layout_wire = wire_fmt or args.count_bits
     chunk_words = 0
     if reduce_mode == "scatter":
-        _, chunk_words = distributed.scatter_layout(ctx.table_tuples, world, bits_wire)
+        _, chunk_words = distributed.scatter_layout(ctx.table_tuples, world, layout_wire)
         send_words = world * chunk_words
         recv = [torch.zeros(chunk_words, dtype=torch.int32, device=dev) for _ in range(2)]
     else:
-        send_words = distributed.table_words(ctx.table_tuples, bits_wire)
+        send_words = ctx.table_tuples if wire_fmt == "u16x2" else distributed.table_words(ctx.table_tuples, bits_wire)
     if wire16:
-        assert world * m < 65536, "--wire u16 needs world x trees < 65536"
         wire = [torch.zeros(send_words, dtype=torch.int32, device=dev) for _ in range(2)]
     elif use_dist:
         table = torch.zeros(max(n_words, send_words), dtype=torch.int32, device=dev)  # padded to world chunks
@@ -162,7 +177,7 @@ def main():
         ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
         if use_dist:
             if wire16:
-                ctx.table_pack16(wire[i])
+                (ctx.table_pack16x2 if wire_fmt == "u16x2" else ctx.table_pack16)(wire[i])
                 src = wire[i]
             else:
                 src = tables[i]
@@ -213,17 +228,29 @@ def main():
     drain()
     # gate on the REDUCED table of the last timed step: every tuple sums to world x m (binary, full trees)
     reduced_ok = None
-    if use_dist and args.steps > 0 and not (args.collapse or args.dropout):
+    shard16 = None
+    if use_dist and args.steps > 0:
         if reduce_mode == "scatter":
-            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, bits_wire)
+            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
             red, n_red = recv[last_buf[0]], own_n
         else:
             red, n_red = (wire if wire16 else tables)[last_buf[0]], nq
-        cells = red[: n_red * 3] if bits_wire == 32 else (red.view(torch.int16)[: n_red * 3].to(torch.int32) & 0xFFFF)
-        ok = torch.tensor([int((cells.view(n_red, 3).sum(dim=1) == world * m).all().item())], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank's shard must pass
-        reduced_ok = bool(ok.item())
-        del cells
+        if wire_fmt == "u16x2":        # restore the third cell of the reduced tuples (a u16 table again)
+            shard16 = torch.zeros(distributed.table_words(max(n_red, 1), 16), dtype=torch.int32, device=dev)
+            ctx.unpack16x2(red, n_red, world * m, shard16)
+            ctx.sync()                 # raises if a reduced tuple exceeds world x m
+            w_ = red[:n_red]
+            ok_local = bool((((w_ & 0xFFFF) + ((w_ >> 16) & 0xFFFF)) <= world * m).all().item())
+        elif binary_full_trees:
+            cells = red[: n_red * 3] if bits_wire == 32 else (red.view(torch.int16)[: n_red * 3].to(torch.int32) & 0xFFFF)
+            ok_local = bool((cells.view(n_red, 3).sum(dim=1) == world * m).all().item())
+            del cells
+        else:
+            ok_local = None
+        if ok_local is not None:
+            ok = torch.tensor([int(ok_local)], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank's shard must pass
+            reduced_ok = bool(ok.item())
     if len(tables) > 1:                  # measurements below run on one table without collectives
         ctx.table_attach(table)
         tables[:] = [table]
@@ -268,8 +295,8 @@ def main():
         s0 = time.perf_counter()
         if reduce_mode == "scatter" and args.steps > 0:
             # every rank scores the shard it received (view), accumulators combined with small collectives
-            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, bits_wire)
-            ctx.score_set_view(recv[last_buf[0]], bits_wire, own_lo, own_n)
+            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
+            ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
             distributed.score_sharded(ctx, ref)
             ctx.score_set_view(None, 0, 0, 0)
         else:
@@ -300,11 +327,11 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"configs[1]: {n} taxa, {m} random eval trees per GPU, uint{args.count_bits} C(n,4)x3 table "
-                        f"({nq} quartets), seeds 2000/2001+rank",
+                        f"({nq} quartets), seeds 2000/2001+rank" + (", NNI-perturbed copies of the reference tree" if args.nni else ""),
             "distinct_trees": distinct,
             "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + (((" + pack to u16 cells" if wire16 else "") + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if use_dist_saved else ""),
+            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((({"u16": " + pack to u16 cells", "u16x2": " + pack to one word n0|n1<<16 per tuple (binary full trees: n2 = trees - n0 - n1)", None: ""}[wire_fmt]) + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if use_dist_saved else ""),
             "collective": reduce_mode,
             "collective_input_bytes_per_rank": send_words * 4 if use_dist_saved else None,
             "parity_reduced_tuple_sums_ok": reduced_ok,

@@ -154,6 +154,15 @@ int qs_table_upload(qs_ctx *ctx, const void *host_src, uint64_t bytes);
  * context can attach and score. A cell >= 65536 raises QS_ERR_OVERFLOW at the next qs_sync. Asynchronous. */
 int qs_table_pack16(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
 
+/* Two-cell wire format for batches in which every tree resolves every quartet (binary evaluation trees holding all
+ * taxa: n0 + n1 + n2 = number of trees): a tuple travels as ONE 32-bit word n0 | n1 << 16 (a third less than
+ * qs_table_pack16). qs_table_pack16x2 writes table_tuples words; after the collective qs_unpack16x2 turns n_tuples
+ * reduced words back into a count_bits = 16 table ([tuple][3] u16, n2 = total_trees - n0 - n1) in caller-owned
+ * memory. A tuple that does not sum to the number of trees raises QS_ERR_STATE at the next qs_sync (use the
+ * three-cell format then), a count >= 65536 QS_ERR_OVERFLOW. Asynchronous. */
+int qs_table_pack16x2(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+int qs_unpack16x2(qs_ctx *ctx, const void *src_device, uint64_t n_tuples, uint32_t total_trees, void *dst_device);
+
 /* ---- counting (QuartetCounterLookup::countQuartets) ------------------------------------ */
 
 /* Opaque device-resident copy of a batch. */

@@ -19,7 +19,7 @@ QS_SCORE_CAND_SLOTS = 8
 # every symbol include/quartetscores_hip.h declares
 EXPORTS = [
     "qs_create", "qs_destroy", "qs_last_error", "qs_version", "qs_table_tuples", "qs_table_bytes", "qs_table_alloc",
-    "qs_table_attach", "qs_table_pack16", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
+    "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
 ]
@@ -77,6 +77,10 @@ def load():
     L.qs_table_attach.argtypes = [vp, vp, u64]
     L.qs_table_pack16.restype = i32
     L.qs_table_pack16.argtypes = [vp, vp, u64]
+    L.qs_table_pack16x2.restype = i32
+    L.qs_table_pack16x2.argtypes = [vp, vp, u64]
+    L.qs_unpack16x2.restype = i32
+    L.qs_unpack16x2.argtypes = [vp, vp, u64, u32, vp]
     L.qs_table_device_ptr.restype = vp
     L.qs_table_device_ptr.argtypes = [vp]
     L.qs_table_clear.restype = i32

@@ -41,7 +41,7 @@ struct qs_ctx {
     // workspace
     void *panel = nullptr;
     size_t panel_bytes = 0;
-    uint32_t *dev_flags = nullptr; // [0] counter overflow, [1] score flags
+    uint32_t *dev_flags = nullptr; // [0] counter overflow, [1] score flags, [3] two-cell wire format: tuple sum mismatch
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool last_timed = false;
     bool ev_valid = false;
@@ -232,6 +232,24 @@ extern "C" int qs_table_pack16(qs_ctx *c, void *dst_device, uint64_t dst_bytes) 
     if (dst_bytes < need) return fail(c, QS_ERR_ARG, "qs_table_pack16: destination smaller than " + std::to_string(need) + " bytes");
     QS_HIP(c, hipSetDevice(c->device));
     QS_HIP(c, launch_pack16(c->stream, c->table, dst_device, cells, c->dev_flags));
+    return QS_OK;
+}
+
+extern "C" int qs_table_pack16x2(qs_ctx *c, void *dst_device, uint64_t dst_bytes) {
+    if (!c || !c->table || !dst_device) return fail(c, QS_ERR_STATE, "qs_table_pack16x2: no table / NULL destination");
+    if (c->count_bits != 32) return fail(c, QS_ERR_ARG, "qs_table_pack16x2: needs a 32-bit table");
+    if (c->trees_counted > 0xFFFFull) return fail(c, QS_ERR_OVERFLOW, "qs_table_pack16x2: more than 65535 trees counted");
+    if (dst_bytes < c->n_tuples * 4) return fail(c, QS_ERR_ARG, "qs_table_pack16x2: destination smaller than " + std::to_string(c->n_tuples * 4) + " bytes");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, launch_pack16x2(c->stream, c->table, dst_device, c->n_tuples, (uint32_t)c->trees_counted, c->dev_flags, c->dev_flags + 3));
+    return QS_OK;
+}
+
+extern "C" int qs_unpack16x2(qs_ctx *c, const void *src_device, uint64_t n_tuples, uint32_t total_trees, void *dst_device) {
+    if (!c || !src_device || !dst_device) return fail(c, QS_ERR_ARG, "qs_unpack16x2: NULL argument");
+    if (total_trees > 0xFFFFu) return fail(c, QS_ERR_OVERFLOW, "qs_unpack16x2: more than 65535 trees");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, launch_unpack16x2(c->stream, src_device, dst_device, n_tuples, total_trees, c->dev_flags + 3));
     return QS_OK;
 }
 
@@ -441,6 +459,10 @@ extern "C" int qs_sync(qs_ctx *c) {
     if (fl[0]) {
         (void)hipMemset(c->dev_flags, 0, 4);
         return fail(c, QS_ERR_OVERFLOW, "count table overflow: a counter exceeded count_bits");
+    }
+    if (fl[3]) {
+        (void)hipMemset(c->dev_flags + 3, 0, 4);
+        return fail(c, QS_ERR_STATE, "two-cell wire format: a tuple does not sum to the number of trees (the batch was not binary with all taxa)");
     }
     return QS_OK;
 }

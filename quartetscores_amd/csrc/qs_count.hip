@@ -1169,6 +1169,42 @@ __global__ __launch_bounds__(256) void pack16_kernel(const uint32_t *__restrict_
     dst[i] = (lo & 0xFFFFu) | (hi << 16);
 }
 
+// Two-cell wire format for batches in which every tree resolves every quartet (binary trees holding all taxa):
+// n0 + n1 + n2 = number of trees, so a tuple travels as ONE word n0 | n1 << 16 and n2 is restored after the
+// collective from the total number of trees. flags[0]: a count does not fit 16 bits; flags[1]: a tuple does not sum
+// to `trees` (the batch was not binary/full).
+__global__ __launch_bounds__(256) void pack16x2_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                       uint64_t n_tuples, uint32_t trees, uint32_t *__restrict__ overflow_flag,
+                                                       uint32_t *__restrict__ shape_flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tuples) return;
+    const uint32_t n0 = src[3 * i], n1 = src[3 * i + 1], n2 = src[3 * i + 2];
+    if ((n0 | n1) > 0xFFFFu) atomicOr(overflow_flag, 1u);
+    if (n0 + n1 + n2 != trees) atomicOr(shape_flag, 1u);
+    dst[i] = (n0 & 0xFFFFu) | (n1 << 16);
+}
+__global__ __launch_bounds__(256) void unpack16x2_kernel(const uint32_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                         uint64_t n_tuples, uint32_t trees, uint32_t *__restrict__ shape_flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tuples) return;
+    const uint32_t w = src[i], n0 = w & 0xFFFFu, n1 = w >> 16;
+    if (n0 + n1 > trees) atomicOr(shape_flag, 1u);
+    dst[3 * i] = (uint16_t)n0; dst[3 * i + 1] = (uint16_t)n1; dst[3 * i + 2] = (uint16_t)(trees - n0 - n1);
+}
+hipError_t launch_pack16x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees,
+                           uint32_t *overflow_flag, uint32_t *shape_flag) {
+    if (n_tuples == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_tuples + 255) / 256));
+    hipLaunchKernelGGL(pack16x2_kernel, grid, block, 0, s, (const uint32_t *)table_u32, (uint32_t *)dst, n_tuples, trees, overflow_flag, shape_flag);
+    return hipGetLastError();
+}
+hipError_t launch_unpack16x2(hipStream_t s, const void *src, void *dst_u16, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag) {
+    if (n_tuples == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_tuples + 255) / 256));
+    hipLaunchKernelGGL(unpack16x2_kernel, grid, block, 0, s, (const uint32_t *)src, (uint16_t *)dst_u16, n_tuples, trees, shape_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack16(hipStream_t s, const void *table_u32, void *dst, uint64_t n_cells, uint32_t *overflow_flag) {
     const uint64_t n_words = (n_cells + 1) / 2;
     if (n_words == 0) return hipSuccess;

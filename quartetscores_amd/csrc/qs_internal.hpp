@@ -60,6 +60,9 @@ uint32_t bitslice3_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of co
 hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
                                 uint64_t rank_lo, void *table, int count_bits);
 hipError_t launch_pack16(hipStream_t s, const void *table_u32, void *dst, uint64_t n_cells, uint32_t *overflow_flag);
+hipError_t launch_pack16x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees,
+                           uint32_t *overflow_flag, uint32_t *shape_flag);
+hipError_t launch_unpack16x2(hipStream_t s, const void *src, void *dst_u16, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
 hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,
                          int count_bits, uint64_t nq, const uint16_t *abcd_dev, uint64_t *out_dev);
 size_t gather_lds_bytes(uint32_t d_hi);

@@ -30,18 +30,24 @@ def table_words(n_tuples: int, count_bits: int) -> int:
     return (n_tuples * 3 * (count_bits // 8) + 3) // 4
 
 
-def scatter_layout(n_tuples: int, world: int, count_bits: int) -> Tuple[int, int]:
+def _wire_words_per_2_tuples(wire) -> int:
+    """int32 words that two tuples occupy on the wire: u32 cells 6, u16 cells 3, two-cell u16 format 2."""
+    return {32: 6, "u32": 6, 16: 3, "u16": 3, "u16x2": 2}[wire]
+
+
+def scatter_layout(n_tuples: int, world: int, wire) -> Tuple[int, int]:
     """Reduce-scatter layout of the [rank][3] table: rank r ends with tuples [r * T, min((r + 1) * T, n_tuples)).
-    Returns (T, words): T tuples per rank (even, so a u16 chunk is a whole number of 32-bit words) and the int32
+    `wire` = 32 | 16 (cell width of the three-cell formats) or "u16x2" (one word n0 | n1 << 16 per tuple).
+    Returns (T, words): T tuples per rank (even, so every chunk is a whole number of 32-bit words) and the int32
     words per chunk; the send buffer is world * words long (zero padded behind the table)."""
     t = -(-n_tuples // world)
     t += t & 1
-    return t, t * 3 * (count_bits // 8) // 4
+    return t, t // 2 * _wire_words_per_2_tuples(wire)
 
 
-def scatter_owned(n_tuples: int, world: int, rank: int, count_bits: int) -> Tuple[int, int]:
+def scatter_owned(n_tuples: int, world: int, rank: int, wire) -> Tuple[int, int]:
     """(first tuple rank, number of tuples) that `rank` owns after reduce_scatter_table."""
-    t, _ = scatter_layout(n_tuples, world, count_bits)
+    t, _ = scatter_layout(n_tuples, world, wire)
     lo = min(rank * t, n_tuples)
     return lo, min(lo + t, n_tuples) - lo
 
@@ -142,24 +148,30 @@ def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, devic
 def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str = "auto", group=None):
     """Tree-sharded counting that ends with the table SHARDED over the ranks (reduce-scatter instead of
     all-reduce). Returns (ctx, shard, bits, rank_lo, n_owned): `shard` holds tuples [rank_lo, rank_lo + n_owned)
-    with `bits`-bit cells; ctx has that range set as its scoring view, so score_sharded(ctx, ref) gives the scores."""
+    with `bits`-bit cells; ctx has that range set as its scoring view, so score_sharded(ctx, ref) gives the scores.
+
+    wire: "u32" | "u16" (three cells per tuple; u16 needs fewer than 65536 trees in total, "auto" picks it then) |
+    "u16x2" (one word per tuple; only for batches of binary trees that hold all taxa -- anything else is reported
+    as an error by the library, use "u16" then)."""
     import torch
     import torch.distributed as dist
     from . import engine
-    if wire not in ("auto", "u16", "u32"):
-        raise ValueError("wire must be auto, u16 or u32")
-    if wire == "u16" and batch.n_trees >= (1 << 16):
+    if wire not in ("auto", "u16x2", "u16", "u32"):
+        raise ValueError("wire must be auto, u16x2, u16 or u32")
+    if wire in ("u16", "u16x2") and batch.n_trees >= (1 << 16):
         raise ValueError("a u16 wire format needs fewer than 65536 trees in total")
-    bits = 16 if (wire == "u16" or (wire == "auto" and batch.n_trees < (1 << 16))) else 32
+    if wire == "auto":
+        wire = "u16" if batch.n_trees < (1 << 16) else "u32"
+    bits = 32 if wire == "u32" else 16
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     multi = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
     stream = torch.cuda.current_stream(dev)
     ctx = engine.Context(ref.n_taxa, 32, device=dev.index or 0, stream=stream.cuda_stream)
-    t_chunk, words = scatter_layout(ctx.table_tuples, world, bits)
+    t_chunk, words = scatter_layout(ctx.table_tuples, world, wire)
     send = torch.zeros(world * words, dtype=torch.int32, device=dev)
-    if bits == 32:
+    if wire == "u32":
         ctx.table_attach(send)                     # counted in place, padded to world chunks
     else:
         table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
@@ -167,14 +179,20 @@ def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str
     lo, hi = shard_range(batch.n_trees, world, rank)
     if hi > lo:
         ctx.count_trees(batch.slice(lo, hi), algo)
-    if bits == 16:
+    if wire == "u16":
         ctx.table_pack16(send)
+    elif wire == "u16x2":
+        ctx.table_pack16x2(send)
     recv = torch.zeros(words, dtype=torch.int32, device=dev)
     reduce_scatter_table(send, recv, group)
-    rank_lo, n_owned = scatter_owned(ctx.table_tuples, world, rank, bits)
-    ctx.score_set_view(recv, bits, rank_lo, n_owned)
-    torch.cuda.synchronize(dev)
-    return ctx, recv, bits, rank_lo, n_owned
+    rank_lo, n_owned = scatter_owned(ctx.table_tuples, world, rank, wire)
+    shard = recv
+    if wire == "u16x2":                            # restore the third cell: n2 = total trees - n0 - n1
+        shard = torch.zeros(table_words(max(n_owned, 1), 16), dtype=torch.int32, device=dev)
+        ctx.unpack16x2(recv, n_owned, batch.n_trees, shard)
+    ctx.sync()                                     # raises if a tuple did not fit the wire format
+    ctx.score_set_view(shard, bits, rank_lo, n_owned)
+    return ctx, shard, bits, rank_lo, n_owned
 
 
 def score_sharded(ctx, ref, flags: int = 0, group=None, device=None):

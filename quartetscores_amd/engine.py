@@ -86,6 +86,16 @@ class Context:
         """u32 table -> u16 table in `tensor` (torch CUDA tensor, >= ceil(cells/2)*4 bytes); asynchronous."""
         self._chk(self.L.qs_table_pack16(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
 
+    def table_pack16x2(self, tensor):
+        """u32 table -> one word n0 | n1 << 16 per tuple (batches of binary trees holding all taxa); asynchronous."""
+        self._chk(self.L.qs_table_pack16x2(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
+
+    def unpack16x2(self, src, n_tuples: int, total_trees: int, dst):
+        """n_tuples reduced words -> [tuple][3] u16 cells in `dst` (n2 = total_trees - n0 - n1); asynchronous."""
+        if src.numel() * src.element_size() < n_tuples * 4 or dst.numel() * dst.element_size() < n_tuples * 6:
+            raise ValueError("unpack16x2: buffer too small")
+        self._chk(self.L.qs_unpack16x2(self.h, C.c_void_p(src.data_ptr()), n_tuples, total_trees, C.c_void_p(dst.data_ptr())))
+
     def table_clear(self):
         self._chk(self.L.qs_table_clear(self.h))
 

@@ -665,9 +665,9 @@ def test_count_trees_reduce_scatter_single_rank(eng):
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     plain, _ = distributed.count_trees_multi_gpu(ref, batch, wire="u32")
     want = plain.score(ref)
-    for wire in ("u16", "u32"):
+    for wire in ("u16x2", "u16", "u32"):
         ctx, shard, bits, r_lo, n_own = distributed.count_trees_reduce_scatter(ref, batch, wire=wire)
-        assert (bits, r_lo, n_own) == (16 if wire == "u16" else 32, 0, ranks.n_quartets(n))
+        assert (bits, r_lo, n_own) == (32 if wire == "u32" else 16, 0, ranks.n_quartets(n))
         got = distributed.score_sharded(ctx, ref)
         for a, b in zip(got[:3], want[:3]):
             assert np.array_equal(a, b, equal_nan=True)
@@ -692,3 +692,37 @@ def test_config1_fixture_on_the_gpu(eng):
     got = {",".join(sorted(k, key=lambda s: int(s[1:]))): [float(x).hex() for x in v]
            for k, v in qsc.scores_by_bipartition().items()}
     assert got == fx["scores_lq_qp_eqp_hex"]
+
+
+def test_two_cell_wire_format(eng):
+    """qs_table_pack16x2 / qs_unpack16x2: one word per tuple for batches of binary trees holding all taxa; the words
+    of several ranks add without carries; the unpacked table equals the three-cell one; anything else is refused."""
+    import torch
+    n, m = 21, 77
+    ref_nw, trees = make_case(n, m, 95)
+    ref = flatten.flatten_reference(ref_nw)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    ctx.count_trees(flatten.flatten_eval_trees(trees, ref.name_to_id))
+    want = ctx.table_download()
+    nq = want.shape[0]
+    words = torch.full((nq,), -1, dtype=torch.int32, device="cuda")
+    ctx.table_pack16x2(words)
+    ctx.sync()
+    w = words.cpu().numpy().view(np.uint32)
+    assert np.array_equal(w & 0xFFFF, want[:, 0]) and np.array_equal(w >> 16, want[:, 1])
+    out = torch.zeros((nq * 3 + 1) // 2, dtype=torch.int32, device="cuda")
+    ctx.unpack16x2(words * 3, nq, 3 * m, out)          # "three ranks" with the same trees
+    ctx.sync()
+    got = out.cpu().numpy().view(np.uint16)[: nq * 3].reshape(nq, 3)
+    assert np.array_equal(got.astype(np.uint32), want * 3)
+    # a batch with an unresolved quartet does not fit the format
+    ctx2 = eng.Context(n, 32)
+    ctx2.table_alloc()
+    ctx2.count_trees(flatten.flatten_eval_trees(synth.tree_set(n, 30, 96, collapse=0.3), ref.name_to_id))
+    ctx2.table_pack16x2(words)
+    with pytest.raises(eng.QSError) as ei:
+        ctx2.sync()
+    assert ei.value.code == -4 and "two-cell" in str(ei.value)
+    with pytest.raises(eng.QSError):
+        ctx.table_pack16x2(words[:-1])
