@@ -12,13 +12,16 @@
 //  reduced once to its "pair-depth panel": for every taxon pair {x,y} the depth of their
 //  lowest common ancestor (build_panel kernel, O(n^2) per tree). By the four-point
 //  condition a tree displays ab|cd  iff  M[ab]+M[cd] > M[ac]+M[bd] (= M[ad]+M[bc]); all
-//  three sums equal means the tree does not resolve the quartet. Panels are stored 16 trees
-//  per 16-byte element ([tree-chunk][pair] of uint4), so one lane compares 4 (u8) or 2 (u16)
-//  trees per 32-bit integer instruction (SWAR: the sums are kept below 128 / 32768 so that
-//  "(S1 | H) - S2" never borrows across fields) and v_bcnt accumulates the hits. Counters
-//  live in registers for the whole launch and each table cell is written exactly once, with
-//  plain coalesced stores: no atomics, and HBM traffic is one pass over the table instead of
-//  m passes.
+//  three sums equal means the tree does not resolve the quartet. Counters live in registers
+//  for the whole launch and each table cell is written exactly once, with plain coalesced
+//  stores: no atomics, and HBM traffic is one pass over the table instead of m passes.
+//  Two implementations of the comparison:
+//    * bit-sliced (count_bitslice3_kernel, default): the panel holds the depths of 32 trees as
+//      bit planes; a (B+1)-bit magnitude comparison of 32 trees costs 2(B+1) v_bitop3_b32;
+//    * byte-SWAR (count_gather_kernel; depths beyond 7 bits, and the independent cross-check
+//      of bench.py): 16 (u8) or 8 (u16) trees per 16-byte panel element, 4 or 2 trees per
+//      32-bit integer instruction (the sums are kept below 128 / 32768 so that "(S1 | H) - S2"
+//      never borrows across fields), v_bcnt accumulates the hits.
 //
 //  SCATTER.  The tree-major formulation of BASELINE.json's north_star: one wavefront per
 //  (tree, inner node), the tree's tour staged in LDS, lanes enumerating the third clade while
