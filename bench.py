@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)   # 0.2 ms each; short runs measure a cold, down-clocked GPU (20 steps: 0.233 ms, 1000: 0.192)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--taxa", type=int, default=128)
     ap.add_argument("--trees", type=int, default=1000)
     ap.add_argument("--algo", choices=["gather", "scatter"], default="gather")
