@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)   # 0.2 ms each; short runs measure a cold, down-clocked GPU (20 steps: 0.233 ms, 1000: 0.192)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed pre-conditioning before the warm-up steps (GPU clock ramp); 0 = off")
     ap.add_argument("--taxa", type=int, default=128)
     ap.add_argument("--trees", type=int, default=1000)
     ap.add_argument("--algo", choices=["gather", "scatter"], default="gather")
@@ -200,6 +201,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Untimed pre-conditioning, then the W warm-up steps the contract asks for: a 0.2 ms step is far shorter than the
+    # GPU's clock ramp, so a run of 20 steps from idle measures 0.233 ms per step where 1000 steps measure 0.192 ms.
+    if args.prewarm_ms > 0:
+        torch.cuda.synchronize(dev)
+        t_pre = time.perf_counter()
+        step()
+        drain()
+        torch.cuda.synchronize(dev)
+        one_ms = max((time.perf_counter() - t_pre) * 1e3, 1e-3)
+        n_pre = int(min(1024, max(0, args.prewarm_ms / one_ms - 1)))
+        if use_dist:      # the same number of steps (= collectives) on every rank
+            npt = torch.tensor([n_pre], device=dev)
+            dist.all_reduce(npt, op=dist.ReduceOp.MAX)
+            n_pre = int(npt.item())
+        for _ in range(n_pre):
+            step()
+        drain()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     ctx.sync()
@@ -339,6 +358,7 @@ def main():
             "parity_bitslice_equals_swar_impl": impl_match,
             "panel_kernel_ms": panel_ms,
             "count_kernel_ms": count_ms,
+            "prewarm_ms": args.prewarm_ms,
             "count_kernel_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
             "score_phase_ms": score_ms,
