@@ -370,7 +370,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": (("count_bitslice3_kernel" if "x2/" in variant else "count_bitslice_kernel") if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
+            "kernel": ("count_bitslice3_kernel" if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
             "algorithmic_bytes_per_launch": m * nq * bytes_per_unit,
             "avg_launch_ms": count_ms,
             "note": "achieved = algorithmic RMW bytes of the reference formulation (8 B per tree x quartet) / kernel time; "
