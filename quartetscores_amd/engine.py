@@ -13,7 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import Iterable, List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Tuple, Union
 
 import numpy as np
 

@@ -1,6 +1,11 @@
-import time, numpy as np, torch, sys
-sys.path.insert(0, '/root/repo')
-from quartetscores_amd import engine, flatten, synth, _lib
+"""Wall time of the phases of qs_score (pass 1, pass 2, copies, host finalisation) at 128 and 256 taxa; run on a GPU box."""
+import sys
+import time
+
+import torch
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quartetscores_amd import engine, flatten, synth
 for n, m in ((128, 1000), (256, 2000)):
     ref_nw = synth.reference_tree(n, 2000)
     trees = synth.tree_set(n, m, 2001)
