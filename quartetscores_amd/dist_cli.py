@@ -1,0 +1,110 @@
+"""Multi-GPU command-line driver: the reference's CLI surface (-r -e -o [-v], QuartetScores.cpp:48-79) on N GPUs of
+one node, one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        -m quartetscores_amd.dist_cli -r ref.nwk -e eval.nwk -o out.nwk [-v] [--exact-qp] [--wire auto|u16x2|u16|u32]
+
+Every rank parses the evaluation file, flattens and counts its own contiguous share of the trees
+(distributed.shard_range), the tables are combined with one RCCL reduce-scatter, every rank scores the shard it
+received and the per-node-pair accumulators are combined with small collectives (distributed.score_sharded); rank 0
+writes the annotated Newick file in the format of the single-GPU CLI (quartetscores_amd/bin/QuartetScores).
+Works unchanged with one process (no launcher). There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+
+
+def _annotate(ref, lq, qp, eqp, bif):
+    """Newick text with "qp-ic:X;lq-ic:Y;eqp-ic:Z" comments per edge, parts omitted when +inf; the qp-ic guard tests
+    the LQ value like the reference (quartet_newick_writer.hpp:164-187, quirk Q6). %f = std::to_string(double)."""
+    from . import newick
+    index = {id(nd): i for i, nd in enumerate(ref.nodes)}
+
+    def comment(nd):
+        v = index[id(nd)]
+        if v == 0:
+            return None
+        parts = []
+        if bif and lq[v] != math.inf:
+            parts.append("qp-ic:%f" % qp[v])
+        if lq[v] != math.inf:
+            parts.append("lq-ic:%f" % lq[v])
+        if bif and eqp[v] != math.inf:
+            parts.append("eqp-ic:%f" % eqp[v])
+        return ";".join(parts) if parts else None
+    return newick.write(ref.nodes[0], comment)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="quartetscores_amd.dist_cli", description=__doc__.split("\n\n")[0])
+    ap.add_argument("-r", "--ref", required=True)
+    ap.add_argument("-e", "--eval", required=True)
+    ap.add_argument("-o", "--output", required=True)
+    ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--exact-qp", action="store_true", help="64-bit QP sums instead of the reference's 32-bit wrap")
+    ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto")
+    args = ap.parse_args(argv)
+    t_begin = time.perf_counter()
+
+    import torch
+    import torch.distributed as dist
+    from . import _lib, distributed, flatten, newick
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.path.exists(args.output):
+        if rank == 0:
+            print("ERROR: The specified output file already exists.")
+        return 1
+    if not torch.cuda.is_available():
+        print("ERROR: no HIP device (quartetscores_amd has no CPU fallback)", file=sys.stderr)
+        return 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    say = print if rank == 0 else (lambda *a, **k: None)
+    try:
+        ref = flatten.flatten_reference(open(args.ref).read())
+        trees = list(newick.parse_trees(open(args.eval).read()))
+        m = len(trees)
+        say(f"There are {m} evaluation trees.")
+        say(f"The reference tree has {ref.n_taxa} taxa.")
+        lo, hi = distributed.shard_range(m, world, rank)
+        local = flatten.flatten_eval_trees(trees[lo:hi], ref.name_to_id)
+        t0 = time.perf_counter()
+        ctx, shard, bits, rank_lo, n_owned = distributed.reduce_scatter_counts(ref, local, m, device=dev, wire=args.wire)
+        if args.verbose:
+            print(f"[rank {rank}] trees [{lo},{hi}) counted ({ctx.last_count_variant() if hi > lo else 'none'}); owns tuples "
+                  f"[{rank_lo},{rank_lo + n_owned}) as u{bits}")
+        say("Finished counting quartets.")
+        say(f"It took: {int((time.perf_counter() - t0) * 1e6)} microseconds.")
+        t0 = time.perf_counter()
+        flags = _lib.QS_SCORE_QP_EXACT64 if args.exact_qp else _lib.QS_SCORE_QP_WRAP32
+        lq, qp, eqp, bif = distributed.score_sharded(ctx, ref, flags, device=dev)
+        say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
+        say("Finished computing scores.")
+        say(f"It took: {int((time.perf_counter() - t0) * 1e6)} microseconds.")
+        if rank == 0:
+            with open(args.output, "w") as f:
+                f.write(_annotate(ref, lq, qp, eqp, bif) + "\n")
+    except Exception as e:  # same exit behaviour as the single-GPU CLI: message + status 1
+        print(f"ERROR: {e}", file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        return 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    say(f"Elapsed time: {int((time.perf_counter() - t_begin) * 1e6)} microseconds.")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -147,8 +147,21 @@ def count_trees_multi_gpu(ref, batch, count_bits: int = 32, algo: int = 0, devic
 
 def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str = "auto", group=None):
     """Tree-sharded counting that ends with the table SHARDED over the ranks (reduce-scatter instead of
-    all-reduce). Returns (ctx, shard, bits, rank_lo, n_owned): `shard` holds tuples [rank_lo, rank_lo + n_owned)
-    with `bits`-bit cells; ctx has that range set as its scoring view, so score_sharded(ctx, ref) gives the scores.
+    all-reduce): every rank holds the whole `batch` and counts its own slice of it.
+    Returns (ctx, shard, bits, rank_lo, n_owned), see reduce_scatter_counts."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    lo, hi = shard_range(batch.n_trees, world, rank)
+    return reduce_scatter_counts(ref, batch.slice(lo, hi), batch.n_trees, algo, device, wire, group)
+
+
+def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, device=None, wire: str = "auto", group=None):
+    """Count THIS rank's trees (`local_batch`; total_trees = trees over all ranks), reduce-scatter the table.
+    Returns (ctx, shard, bits, rank_lo, n_owned): `shard` holds tuples [rank_lo, rank_lo + n_owned) of the reduced
+    table with `bits`-bit cells; ctx has that range set as its scoring view, so score_sharded(ctx, ref) gives the
+    scores.
 
     wire: "u32" | "u16" (three cells per tuple; u16 needs fewer than 65536 trees in total, "auto" picks it then) |
     "u16x2" (one word per tuple; only for batches of binary trees that hold all taxa -- anything else is reported
@@ -158,10 +171,10 @@ def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str
     from . import engine
     if wire not in ("auto", "u16x2", "u16", "u32"):
         raise ValueError("wire must be auto, u16x2, u16 or u32")
-    if wire in ("u16", "u16x2") and batch.n_trees >= (1 << 16):
+    if wire in ("u16", "u16x2") and total_trees >= (1 << 16):
         raise ValueError("a u16 wire format needs fewer than 65536 trees in total")
     if wire == "auto":
-        wire = "u16" if batch.n_trees < (1 << 16) else "u32"
+        wire = "u16" if total_trees < (1 << 16) else "u32"
     bits = 32 if wire == "u32" else 16
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     multi = dist.is_available() and dist.is_initialized()
@@ -176,9 +189,8 @@ def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str
     else:
         table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
         ctx.table_attach(table)
-    lo, hi = shard_range(batch.n_trees, world, rank)
-    if hi > lo:
-        ctx.count_trees(batch.slice(lo, hi), algo)
+    if local_batch.n_trees:
+        ctx.count_trees(local_batch, algo)
     if wire == "u16":
         ctx.table_pack16(send)
     elif wire == "u16x2":
@@ -189,7 +201,7 @@ def count_trees_reduce_scatter(ref, batch, algo: int = 0, device=None, wire: str
     shard = recv
     if wire == "u16x2":                            # restore the third cell: n2 = total trees - n0 - n1
         shard = torch.zeros(table_words(max(n_owned, 1), 16), dtype=torch.int32, device=dev)
-        ctx.unpack16x2(recv, n_owned, batch.n_trees, shard)
+        ctx.unpack16x2(recv, n_owned, total_trees, shard)
     ctx.sync()                                     # raises if a tuple did not fit the wire format
     ctx.score_set_view(shard, bits, rank_lo, n_owned)
     return ctx, shard, bits, rank_lo, n_owned

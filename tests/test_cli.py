@@ -129,3 +129,26 @@ def test_cli_end_to_end_matches_oracle(d1_files, tmp_path, golden):
     bad.write_text(golden["D6"]["bad_tree"] + "\n")
     p = run("-r", r, "-e", str(bad), "-o", str(tmp_path / "o4.nwk"))
     assert p.returncode == 1 and "unknown taxon" in p.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_driver_single_process_matches_the_cli(d1_files, tmp_path):
+    """quartetscores_amd.dist_cli (tree-sharded count + reduce-scatter + sharded scoring; here one process, no
+    launcher) writes the same annotated tree as the single-GPU C++ CLI, for every wire format."""
+    import sys
+    r, e = d1_files
+    ref_out = tmp_path / "cli.nwk"
+    p = run("-r", r, "-e", e, "-o", str(ref_out))
+    assert p.returncode == 0, p.stderr
+    want = ref_out.read_text()
+    for wire in ("auto", "u16x2", "u16", "u32"):
+        out = tmp_path / f"dist_{wire}.nwk"
+        q = subprocess.run([sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", r, "-e", e, "-o", str(out), "-v", "--wire", wire],
+                           capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert q.returncode == 0, q.stderr
+        assert "There are 20 evaluation trees." in q.stdout and "Finished computing scores." in q.stdout
+        assert out.read_text() == want, wire
+    # existing output file -> refused like the CLI
+    q = subprocess.run([sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", r, "-e", e, "-o", str(ref_out)],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert q.returncode == 1 and "already exists" in q.stdout
