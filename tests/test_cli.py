@@ -86,6 +86,37 @@ def test_cli_fails_loudly_without_gpu(d1_files, tmp_path):
     assert not (tmp_path / "o.nwk").exists()
 
 
+def test_multi_gpu_driver_fails_loudly_without_gpu(d1_files, tmp_path):
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r, e = d1_files
+    q = subprocess.run([sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", r, "-e", e, "-o", str(tmp_path / "o.nwk")],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert q.returncode == 1 and "no CPU fallback" in q.stderr
+    assert not (tmp_path / "o.nwk").exists()
+
+
+def test_multi_gpu_driver_annotation_format():
+    """The comment layout of dist_cli equals the C++ CLI's (QuartetScores.cpp in csrc/host): parts omitted at +inf,
+    the qp-ic guard on the LQ value, std::to_string's %f."""
+    import math
+    from quartetscores_amd import dist_cli, flatten
+    ref = flatten.flatten_reference("((a,b)x,(c,d),e);")
+    n = ref.n_nodes
+    lq = [math.inf] * n; qp = [math.inf] * n; eqp = [math.inf] * n
+    inner = [i for i, nd in enumerate(ref.nodes) if nd.children and i != 0]
+    lq[inner[0]], qp[inner[0]], eqp[inner[0]] = 0.5, 0.25, -0.125
+    lq[inner[1]] = 1.0   # qp/eqp left at +inf: eqp omitted, qp printed because the guard looks at lq
+    text = dist_cli._annotate(ref, lq, qp, eqp, True)
+    assert "[qp-ic:0.250000;lq-ic:0.500000;eqp-ic:-0.125000]" in text
+    assert "[qp-ic:inf;lq-ic:1.000000]" in text
+    assert text.count("[") == 2
+    text2 = dist_cli._annotate(ref, lq, qp, eqp, False)   # multifurcating reference: LQ-IC only
+    assert "[lq-ic:0.500000]" in text2 and "qp-ic" not in text2
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end_matches_oracle(d1_files, tmp_path, golden):
     r, e = d1_files
