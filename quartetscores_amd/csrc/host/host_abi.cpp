@@ -1,0 +1,77 @@
+// host_abi.cpp -- the C++ host's Newick ingest (newick.hpp, flatten.hpp, ingest.hpp) behind a small C interface, so
+// that the Python multi-GPU driver (quartetscores_amd/dist_cli.py) reads evaluation files at native speed: every
+// rank cuts the file into tree spans once and parses + flattens only its own share with a pool of threads.
+// Plain g++ (no HIP); builds quartetscores_amd/lib/libquartetscores_host.so. Host plumbing, not the drop-in
+// boundary (that is include/quartetscores_hip.h).
+#include "ingest.hpp"
+
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+
+using namespace qsh;
+
+namespace {
+thread_local std::string g_err;
+std::string read_file(const char *path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(std::string("cannot read ") + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+} // namespace
+
+struct qsh_batch { BatchFlat b; };
+
+extern "C" {
+
+const char *qsh_last_error(void) { return g_err.c_str(); }
+
+// Flattens the trees [tree_lo, min(tree_hi, m)) of eval_path against the taxa of the reference tree in ref_path.
+// *n_trees_total = m (trees in the file). 0 on success, 1 on error (qsh_last_error()).
+int qsh_ingest(const char *ref_path, const char *eval_path, uint64_t tree_lo, uint64_t tree_hi, unsigned threads,
+               qsh_batch **out, uint64_t *n_trees_total) {
+    try {
+        if (!ref_path || !eval_path || !out) throw std::runtime_error("qsh_ingest: NULL argument");
+        const std::string refText = read_file(ref_path);
+        NewickReader rr(refText);
+        Tree ref;
+        if (!rr.next(ref)) throw std::runtime_error("empty reference tree file");
+        const RefFlat rf = flatten_reference(ref);
+        const std::string text = read_file(eval_path);
+        const auto spans = split_trees(text);
+        if (n_trees_total) *n_trees_total = spans.size();
+        const size_t lo = std::min<size_t>(tree_lo, spans.size()), hi = std::max(lo, std::min<size_t>(tree_hi, spans.size()));
+        if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+        qsh_batch *b = new qsh_batch();
+        try {
+            b->b = flatten_parallel(text, spans, lo, hi, rf.name_to_id, threads);
+        } catch (...) { delete b; throw; }
+        *out = b;
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
+uint32_t qsh_batch_n_trees(const qsh_batch *b) { return b ? b->b.n_trees : 0; }
+// which: 0 leaf_off (u32), 1 leaf_ids (u16), 2 adj_depth (u16), 3 node_off (u32), 4 rng_off (u32), 5 ranges (u16)
+const void *qsh_batch_array(const qsh_batch *b, int which, uint64_t *n_elems) {
+    if (!b) return nullptr;
+    const BatchFlat &f = b->b;
+    switch (which) {
+        case 0: if (n_elems) *n_elems = f.leaf_off.size(); return f.leaf_off.data();
+        case 1: if (n_elems) *n_elems = f.leaf_ids.size(); return f.leaf_ids.data();
+        case 2: if (n_elems) *n_elems = f.adj_depth.size(); return f.adj_depth.data();
+        case 3: if (n_elems) *n_elems = f.node_off.size(); return f.node_off.data();
+        case 4: if (n_elems) *n_elems = f.rng_off.size(); return f.rng_off.data();
+        case 5: if (n_elems) *n_elems = f.ranges.size(); return f.ranges.data();
+        default: return nullptr;
+    }
+}
+void qsh_batch_free(qsh_batch *b) { delete b; }
+
+} // extern "C"

@@ -46,6 +46,7 @@ def main(argv=None):
     ap.add_argument("-e", "--eval", required=True)
     ap.add_argument("-o", "--output", required=True)
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("-t", "--threads", type=int, default=0, help="host threads per rank for parsing the evaluation trees (0 = all)")
     ap.add_argument("--exact-qp", action="store_true", help="64-bit QP sums instead of the reference's 32-bit wrap")
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto")
     args = ap.parse_args(argv)
@@ -53,7 +54,7 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
-    from . import _lib, distributed, flatten, newick
+    from . import _lib, distributed, flatten, native_ingest, newick
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -72,12 +73,20 @@ def main(argv=None):
     say = print if rank == 0 else (lambda *a, **k: None)
     try:
         ref = flatten.flatten_reference(open(args.ref).read())
-        trees = list(newick.parse_trees(open(args.eval).read()))
-        m = len(trees)
+        if native_ingest.available():
+            # the C++ host's multi-threaded ingest: one scan for the tree spans (= m), then only this rank's share is
+            # parsed and flattened (the reference parses the whole file twice on one thread, QuartetScores.cpp:23-32)
+            _, m = native_ingest.ingest(args.ref, args.eval, 0, 0, args.threads)
+            lo, hi = distributed.shard_range(m, world, rank)
+            local, _ = native_ingest.ingest(args.ref, args.eval, lo, hi, args.threads)
+        else:
+            say("note: libquartetscores_host.so not built; using the (slow) Python Newick parser")
+            trees = list(newick.parse_trees(open(args.eval).read()))
+            m = len(trees)
+            lo, hi = distributed.shard_range(m, world, rank)
+            local = flatten.flatten_eval_trees(trees[lo:hi], ref.name_to_id)
         say(f"There are {m} evaluation trees.")
         say(f"The reference tree has {ref.n_taxa} taxa.")
-        lo, hi = distributed.shard_range(m, world, rank)
-        local = flatten.flatten_eval_trees(trees[lo:hi], ref.name_to_id)
         t0 = time.perf_counter()
         ctx, shard, bits, rank_lo, n_owned = distributed.reduce_scatter_counts(ref, local, m, device=dev, wire=args.wire)
         if args.verbose:

@@ -76,6 +76,36 @@ def test_cpp_host_flattening_matches_python_host(tmp_path):
     assert p.returncode == 1 and "unknown taxon 'zzz'" in p.stderr and "tree 70" in p.stderr
 
 
+def test_native_ingest_binding_matches_python_host(tmp_path):
+    """quartetscores_amd.native_ingest (libquartetscores_host.so = the C++ host's ingest behind a C interface) gives
+    the Python flattening's arrays, for any tree range and thread count; errors carry the tree index."""
+    import numpy as np
+    from quartetscores_amd import flatten, native_ingest, synth
+    assert native_ingest.available(), "build the host first (__graft_entry__.build())"
+    n = 19
+    ref_nw = synth.reference_tree(n, 15)
+    trees = synth.tree_set(n, 130, 16) + synth.tree_set(n, 50, 17, collapse=0.3, dropout=0.2) + synth.tree_set(n, 20, 18, rooted=True)
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_text("\n".join(trees) + "\n")
+    ref = flatten.flatten_reference(ref_nw)
+    want = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    for lo, hi, th in ((0, native_ingest.ALL, 1), (0, len(trees), 5), (37, 141, 3), (199, 200, 2), (200, 500, 2), (10, 10, 1)):
+        got, total = native_ingest.ingest(str(r), str(e), lo, hi, th)
+        assert total == len(trees)
+        exp = want.slice(min(lo, len(trees)), min(hi, len(trees)))
+        assert got.n_trees == exp.n_trees
+        for f in ("leaf_off", "leaf_ids", "adj_depth", "node_off", "rng_off", "ranges"):
+            assert np.array_equal(getattr(got, f), getattr(exp, f)), (f, lo, hi, th)
+    bad = tmp_path / "bad.nwk"
+    bad.write_text("\n".join(trees[:70]) + "\n((t0,t1),(t2,zzz),(t3,t4));\n")
+    with pytest.raises(native_ingest.IngestError) as ei:
+        native_ingest.ingest(str(r), str(bad), 0, native_ingest.ALL, 4)
+    assert "zzz" in str(ei.value) and "tree 70" in str(ei.value)
+    with pytest.raises(native_ingest.IngestError):
+        native_ingest.ingest(str(r), str(tmp_path / "missing.nwk"))
+
+
 def test_cli_fails_loudly_without_gpu(d1_files, tmp_path):
     import torch
     if torch.cuda.is_available():
