@@ -1,0 +1,234 @@
+// fast_ingest.hpp -- allocation-free parse + flatten of ONE evaluation tree (the inner loop of the ingest).
+//
+// newick.hpp's Tree keeps a vector of children and two strings per node: ~1500 heap allocations for a 256-taxon
+// tree, which is what bounded flatten_parallel (134 us per tree on one thread, and no scaling from 2 to 4 threads:
+// the allocator). Here a tree is parsed straight into a parent array + label spans inside reusable scratch
+// buffers, the adjacency is a CSR built from the parent array, and the traversal of flatten.hpp's flatten_append
+// runs on it unchanged in meaning: same neighbour order ([parent, children...]), same re-rooting at the centre,
+// same depth-first leaf order, same arrays -- tests/test_cli.py compares them with the Python host's.
+#pragma once
+
+#include "flatten.hpp"
+#include "newick.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace qsh {
+
+struct FlatScratch {
+    std::vector<int32_t> parent;
+    std::vector<uint32_t> lab_b, lab_e;   // label = text[lab_b, lab_e) (empty span = none); quoted labels: see qidx
+    std::vector<int32_t> qidx;            // -1, or index into `quoted` (labels that needed unescaping)
+    std::vector<std::string> quoted;
+    std::vector<uint32_t> adj_off, nchild, fill;
+    std::vector<int32_t> adj, dist, prev, order, dfs_par, ipar;
+    std::vector<uint32_t> start, end, depth;
+    struct Frame { int32_t x, par; uint32_t k; };
+    std::vector<Frame> st;
+    std::vector<uint16_t> tmp;
+    std::string key;
+};
+
+namespace detail {
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+
+// Newick text [b, e) -> s.parent / label spans. Same dialect and errors as NewickReader::parse_one.
+inline void parse_flat(const std::string &text, size_t b, size_t e, FlatScratch &s) {
+    s.parent.clear(); s.lab_b.clear(); s.lab_e.clear(); s.qidx.clear(); s.quoted.clear();
+    size_t i = b;
+    auto skip = [&]() {
+        while (i < e) {
+            const char c = text[i];
+            if (is_ws(c)) ++i;
+            else if (c == '[') {
+                const size_t j = text.find(']', i);
+                if (j == std::string::npos || j >= e) throw NewickError("unterminated comment");
+                i = j + 1;
+            } else break;
+        }
+    };
+    auto add = [&](int32_t par) {
+        s.parent.push_back(par); s.lab_b.push_back(0); s.lab_e.push_back(0); s.qidx.push_back(-1);
+        return (int32_t)s.parent.size() - 1;
+    };
+    auto label = [&](int32_t node) {
+        skip();
+        if (i < e && text[i] == '\'') {
+            ++i;
+            std::string out;
+            while (i < e) {
+                if (text[i] == '\'') {
+                    if (i + 1 < e && text[i + 1] == '\'') { out.push_back('\''); i += 2; continue; }
+                    ++i;
+                    break;
+                }
+                out.push_back(text[i++]);
+            }
+            s.qidx[node] = (int32_t)s.quoted.size();
+            s.quoted.push_back(std::move(out));
+            return;
+        }
+        const size_t j0 = i;
+        while (i < e) {
+            const char c = text[i];
+            if (c == '(' || c == ')' || c == ',' || c == ':' || c == ';' || c == '[' || is_ws(c)) break;
+            ++i;
+        }
+        s.lab_b[node] = (uint32_t)j0; s.lab_e[node] = (uint32_t)i;
+    };
+    int32_t cur = add(-1);
+    skip();
+    if (i < e && text[i] != '(') label(cur);
+    while (i < e) {
+        skip();
+        if (i >= e) break;
+        const char c = text[i];
+        if (c == '(') {
+            cur = add(cur);
+            ++i; skip();
+            if (i < e && text[i] != '(' && text[i] != ',' && text[i] != ')') label(cur);
+        } else if (c == ',') {
+            if (s.parent[cur] < 0) throw NewickError("',' outside parentheses");
+            cur = add(s.parent[cur]);
+            ++i; skip();
+            if (i < e && text[i] != '(' && text[i] != ',' && text[i] != ')') label(cur);
+        } else if (c == ')') {
+            if (s.parent[cur] < 0) throw NewickError("unbalanced ')'");
+            cur = s.parent[cur];
+            ++i; skip();
+            if (i < e && text[i] != '(' && text[i] != ')' && text[i] != ',' && text[i] != ':' && text[i] != ';') label(cur);
+        } else if (c == ':') {
+            ++i; skip();
+            while (i < e && text[i] != '(' && text[i] != ')' && text[i] != ',' && text[i] != ';' && text[i] != '[' && !is_ws(text[i])) ++i;
+        } else if (c == ';') {
+            ++i;
+            break;
+        } else {
+            throw NewickError("unexpected character '" + std::string(1, c) + "' at offset " + std::to_string(i - b));
+        }
+    }
+    if (cur != 0) throw NewickError("unbalanced '('");
+}
+
+} // namespace detail
+
+// Parse text[b, e) and append the tree to `batch`; same result as NewickReader + flatten_append.
+inline void parse_flatten_append(const std::string &text, size_t b, size_t e, const std::unordered_map<std::string, uint32_t> &name_to_id,
+                                 BatchFlat &batch, FlatScratch &s, bool recentre = true) {
+    detail::parse_flat(text, b, e, s);
+    const size_t N = s.parent.size();
+    // CSR adjacency, neighbour order = [parent, children in input order]
+    s.nchild.assign(N, 0);
+    for (size_t v = 1; v < N; ++v) s.nchild[s.parent[v]]++;
+    s.adj_off.assign(N + 1, 0);
+    for (size_t v = 0; v < N; ++v) s.adj_off[v + 1] = s.adj_off[v] + s.nchild[v] + (s.parent[v] >= 0 ? 1u : 0u);
+    s.adj.resize(s.adj_off[N]);
+    s.fill.assign(N, 0);
+    for (size_t v = 0; v < N; ++v)
+        if (s.parent[v] >= 0) { s.adj[s.adj_off[v]] = s.parent[v]; s.fill[v] = 1; }
+    for (size_t v = 1; v < N; ++v) { const int32_t p = s.parent[v]; s.adj[s.adj_off[p] + s.fill[p]++] = (int32_t)v; }
+    auto deg = [&](int32_t x) { return s.adj_off[x + 1] - s.adj_off[x]; };
+    auto nb = [&](int32_t x, uint32_t k) { return s.adj[s.adj_off[x] + k]; };
+
+    int32_t r = 0;
+    if (recentre && N > 2) { // middle of a longest path (two BFS passes), as detail::centre
+        s.dist.resize(N); s.prev.resize(N);
+        auto bfs = [&](int32_t src) {
+            std::fill(s.dist.begin(), s.dist.end(), -1);
+            s.order.clear();
+            s.dist[src] = 0; s.prev[src] = -1;
+            s.order.push_back(src);
+            for (size_t k = 0; k < s.order.size(); ++k) {
+                const int32_t x = s.order[k];
+                for (uint32_t q = 0; q < deg(x); ++q) {
+                    const int32_t y = nb(x, q);
+                    if (s.dist[y] < 0) { s.dist[y] = s.dist[x] + 1; s.prev[y] = x; s.order.push_back(y); }
+                }
+            }
+            return s.order.back();
+        };
+        const int32_t u = bfs(0);
+        const int32_t v = bfs(u);
+        int32_t len = s.dist[v], x = v;        // path v .. u has len + 1 nodes; centre = element (len + 1) / 2 from v
+        for (int32_t step = 0; step < (len + 1) / 2; ++step) x = s.prev[x];
+        r = x;
+        if (deg(r) == 1) r = nb(r, 0);
+    }
+    s.start.assign(N, 0); s.end.assign(N, 0); s.depth.assign(N, 0);
+    s.dfs_par.assign(N, -1); s.ipar.assign(N, -1);
+    // children of x in the tree rooted at r: the neighbours after its parent, cyclically
+    auto nkids = [&](int32_t x) { return deg(x) - (s.ipar[x] >= 0 ? 1u : 0u); };
+    auto kid = [&](int32_t x, uint32_t k) {
+        if (s.ipar[x] < 0) return nb(x, k);
+        uint32_t q = (uint32_t)s.ipar[x] + 1 + k;   // < 2 * deg
+        const uint32_t dg = deg(x);
+        if (q >= dg) q -= dg;
+        return nb(x, q);
+    };
+    s.st.clear();
+    s.st.push_back({r, -1, 0});
+    uint32_t L = 0, cur_min = 0;
+    const size_t ids0 = batch.leaf_ids.size();
+    while (!s.st.empty()) {
+        FlatScratch::Frame &f = s.st.back();   // edited in place; re-read nothing from it after a push_back
+        const int32_t x = f.x;
+        if (f.k == 0) {
+            s.start[x] = L;
+            s.dfs_par[x] = f.par;
+            if (f.par >= 0) {
+                uint32_t q = 0;
+                while (nb(x, q) != f.par) ++q;
+                s.ipar[x] = (int32_t)q;
+            }
+            if (nkids(x) == 0) {
+                if (s.qidx[x] >= 0) s.key = s.quoted[s.qidx[x]];
+                else s.key.assign(text, s.lab_b[x], s.lab_e[x] - s.lab_b[x]);
+                const auto it = name_to_id.find(s.key);
+                if (it == name_to_id.end()) throw UnknownTaxon("unknown taxon '" + s.key + "' in evaluation tree " + std::to_string(batch.n_trees));
+                if (L > 0) batch.adj_depth.push_back((uint16_t)std::min<uint32_t>(cur_min, 0xFFFFu));
+                cur_min = 1u << 30;
+                batch.leaf_ids.push_back((uint16_t)it->second);
+                ++L;
+                s.end[x] = L;
+                s.st.pop_back();
+                continue;
+            }
+        }
+        if (f.k < nkids(x)) {
+            const uint32_t k = f.k++;
+            cur_min = std::min(cur_min, s.depth[x]);
+            const int32_t c = kid(x, k);
+            s.depth[c] = s.depth[x] + 1;
+            s.st.push_back({c, x, 0});
+        } else {
+            s.end[x] = L;
+            s.st.pop_back();
+        }
+    }
+    if (L > 0) batch.adj_depth.push_back(0);
+    s.tmp.assign(batch.leaf_ids.begin() + ids0, batch.leaf_ids.end());
+    std::sort(s.tmp.begin(), s.tmp.end());
+    if (std::adjacent_find(s.tmp.begin(), s.tmp.end()) != s.tmp.end())
+        throw std::runtime_error("duplicate taxon in evaluation tree " + std::to_string(batch.n_trees));
+    batch.leaf_off.push_back((uint32_t)batch.leaf_ids.size());
+    for (size_t x = 0; x < N && L > 0; ++x) {
+        const uint32_t nk = nkids((int32_t)x);
+        const size_t nlinks = nk + ((int32_t)x != r ? 1 : 0);
+        if (nk == 0 || nlinks < 3) continue;
+        if ((int32_t)x != r) { batch.ranges.push_back((uint16_t)(s.end[x] % L)); batch.ranges.push_back((uint16_t)(s.start[x] % L)); }
+        for (uint32_t k = 0; k < nk; ++k) {
+            const int32_t c = kid((int32_t)x, k);
+            batch.ranges.push_back((uint16_t)(s.start[c] % L)); batch.ranges.push_back((uint16_t)(s.end[c] % L));
+        }
+        batch.rng_off.push_back((uint32_t)(batch.ranges.size() / 2));
+    }
+    batch.node_off.push_back((uint32_t)(batch.rng_off.size() - 1));
+    ++batch.n_trees;
+}
+
+} // namespace qsh

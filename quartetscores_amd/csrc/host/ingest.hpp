@@ -7,6 +7,7 @@
 // (qs_count_batch is asynchronous). SURVEY.md 8(f) rank 1.
 #pragma once
 
+#include "fast_ingest.hpp"
 #include "flatten.hpp"
 #include "newick.hpp"
 
@@ -66,20 +67,16 @@ inline BatchFlat flatten_parallel(const std::string &text, const std::vector<std
     auto work = [&](unsigned w) {
         try {
             const size_t lo = i0 + count * w / threads, hi = i0 + count * (w + 1) / threads;
-            Tree t;
+            FlatScratch scratch; // parse + flatten without per-node allocations (fast_ingest.hpp)
+            BatchFlat b;         // worker-local (the vector headers of adjacent parts[] share cache lines)
             for (size_t i = lo; i < hi; ++i) {
-                const std::string one = text.substr(spans[i].first, spans[i].second - spans[i].first);
-                NewickReader rd(one);
-                if (!rd.next(t)) throw NewickError("empty tree at byte " + std::to_string(spans[i].first));
-                BatchFlat &b = parts[w];
-                const uint32_t before = b.n_trees;
                 try {
-                    flatten_append(t, name_to_id, b);
+                    parse_flatten_append(text, spans[i].first, spans[i].second, name_to_id, b, scratch);
                 } catch (const UnknownTaxon &e) { // report the tree's index in the file, not in the part
-                    (void)before;
                     throw UnknownTaxon(std::string(e.what()) + " (tree " + std::to_string(i) + " of the file)");
                 }
             }
+            parts[w] = std::move(b);
         } catch (...) { errors[w] = std::current_exception(); }
     };
     if (threads == 1) work(0);
