@@ -4,7 +4,7 @@ set -u
 N=${1:-256}; M=${2:-20000}
 D=$(mktemp -d)
 python3 - "$N" "$M" "$D" <<'PY'
-import sys
+import subprocess, sys, time
 sys.path.insert(0, ".")
 from quartetscores_amd import synth
 n, m, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
@@ -13,13 +13,21 @@ base = synth.tree_set(n, min(m, 2000), 4001)
 with open(d + "/eval.nwk", "w") as f:
     for i in range(m):
         f.write(base[i % len(base)] + "\n")
+import os
+print("eval file bytes:", os.path.getsize(d + "/eval.nwk"))
+
+def timed(label, cmd, out):
+    if os.path.exists(out):
+        os.remove(out)
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    lines = [l for l in p.stdout.split("\n") if "took" in l or "Elapsed" in l]
+    print(f"{label}: {dt:.3f} s wall, rc {p.returncode} | " + " ".join(lines))
+
+for t in ("1", "8", "64", "0"):
+    timed(f"QuartetScores -t {t}", ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out.nwk", "-t", t], d + "/out.nwk")
+timed("dist_cli, 1 process", [sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out2.nwk"], d + "/out2.nwk")
+print("outputs identical:", open(d + "/out.nwk").read() == open(d + "/out2.nwk").read())
 PY
-ls -la $D/eval.nwk | awk '{print "eval file bytes:", $5}'
-for t in 1 8 64; do
-  rm -f $D/out.nwk
-  /usr/bin/time -f "QuartetScores -t $t: %e s wall" quartetscores_amd/bin/QuartetScores -r $D/ref.nwk -e $D/eval.nwk -o $D/out.nwk -t $t | grep -E "Elapsed|took" | tr '\n' ' '; echo
-done
-rm -f $D/out2.nwk
-/usr/bin/time -f "dist_cli (1 process): %e s wall" python -m quartetscores_amd.dist_cli -r $D/ref.nwk -e $D/eval.nwk -o $D/out2.nwk | grep -E "Elapsed|took" | tr '\n' ' '; echo
-cmp $D/out.nwk $D/out2.nwk && echo "outputs identical"
 rm -rf $D
