@@ -389,6 +389,16 @@ def main():
             kname = out["roofline"]["kernel"]
             fk = [v for k_, v in pmc["FETCH_SIZE"].items() if kname in k_]
             wk = [v for k_, v in pmc["WRITE_SIZE"].items() if kname in k_]
+            vi = [v for k_, v in pmc.get("SQ_INSTS_VALU", {}).items() if kname in k_]
+            if vi and "bitslice" in variant:
+                # the kernel's real bound: VALU issue. Time the launch would take if the 1024 SIMDs issued its VALU
+                # instructions at the rate tools/valu_rates.hip measures for this mix at 4 waves/SIMD
+                # (85 % v_bitop3-class at 3.13 cycles, 15 % v_bcnt at 5.6 cycles, of a 2.4 GHz clock)
+                ns_per_inst = (0.85 * 3.13 + 0.15 * 5.6) / 2.4
+                bound_ms = vi[0]["avg_per_dispatch"] / 1024.0 * ns_per_inst * 1e-6
+                out["roofline"]["valu_issue"] = {"wave_insts_per_launch": vi[0]["avg_per_dispatch"], "bound_ms": bound_ms,
+                                                 "frac": bound_ms / count_ms,
+                                                 "source": "profiles/r01_final_pmc_summary.json (SQ_INSTS_VALU) x profiles/r01_valu_rates_pass2.txt"}
             if fk and wk:
                 out["roofline"]["traffic"] = (2 * fk[0]["avg_per_dispatch"] + wk[0]["avg_per_dispatch"]) * 1024
                 out["roofline"]["traffic_source"] = ("profiles/r01_final_pmc_summary.json (tools/pmc_collect.sh: rocprofv3 --pmc, "
