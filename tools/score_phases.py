@@ -6,7 +6,8 @@ import torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quartetscores_amd import engine, flatten, synth
-for n, m in ((128, 1000), (256, 2000)):
+cases = [(int(a), 64) for a in sys.argv[1:]] or [(128, 1000), (256, 2000)]
+for n, m in cases:
     ref_nw = synth.reference_tree(n, 2000)
     trees = synth.tree_set(n, m, 2001)
     ref = flatten.flatten_reference(ref_nw)
