@@ -1046,12 +1046,16 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         if (full) run(F_{}, T_{}, T_{}); else run(F_{}, F_{}, T_{});
     }
 
-    const uint64_t rcb = binom3(c);
+    // rank of {a,b,c,d} = C(d,4) + C(c,3) + C(b,2) + a; along the d slots C(d+1,4) = C(d,4) + C(d,3) etc., so the
+    // 64-bit products and divisions are done once per wave instead of once per slot
+    uint64_t bd4 = binom4(d0), bd3 = binom3(d0), bd2 = binom2(d0);
+    const uint64_t rcb = binom3(c) - rank_lo;
 #pragma unroll
     for (int j = 0; j < kDB; ++j) {
         const uint32_t d = d0 + j;
+        const uint64_t base = bd4 + rcb;
+        bd4 += bd3; bd3 += bd2; bd2 += d;
         if (d < d1 && d > c) {
-            const uint64_t base = binom4(d) + rcb - rank_lo;
             if (v1) {
                 const uint64_t idx = (base + pi1) * 3;
                 uint32_t w0 = x0[j], w1 = x1[j], w2 = BIN ? m_trees - x0[j] - x1[j] : y0[j];
