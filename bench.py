@@ -383,7 +383,7 @@ def main():
     # rocprofv3 summary of THIS kernel variant on THIS default workload exists, report it (per launch;
     # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is, KB -> bytes)
     try:
-        if (n, m, args.count_bits, args.table_shards) == (128, 1000, 32, 1):
+        if (n, m, args.count_bits, args.table_shards) == (128, 1000, 32, 1) and ("binary_full" in variant or args.algo != "gather"):
             with open(os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")) as f:
                 pmc = json.load(f)["counters"]
             kname = out["roofline"]["kernel"]

@@ -207,25 +207,27 @@ __device__ __forceinline__ uint32_t upper_bound_le(const uint32_t *__restrict__ 
     return lo;
 }
 
-// The same search done by the whole wave: lane i loads arr[lo + 64 j + i] (coalesced, the chunks are independent
-// loads), a ballot per chunk gives the count of entries <= key; *value = arr[result], taken from the loaded chunk
-// with v_readlane. One memory latency instead of log2(hi - lo) dependent ones -- the tile decode of the count
-// kernel was 11 dependent scalar loads, ~4 us of a 44 us tile.
+// The same search done by the whole wave in at most two memory latencies (instead of log2(hi - lo) dependent scalar
+// loads): lane i first looks at arr[lo + i * stride] (stride = ceil(range / 64)), a ballot gives the segment that
+// holds the answer, then the lanes look at that segment's (at most 64) consecutive entries. *value = arr[result],
+// taken from the loaded registers with v_readlane. Ranges up to 4096 entries (n_taxa <= 4096).
 __device__ __forceinline__ uint32_t wave_search_le(const uint32_t *__restrict__ arr, uint32_t lo, uint32_t hi, uint32_t key,
                                                    uint32_t lane, uint32_t &value) {
-    uint32_t cnt = 0, val = 0;
-    for (uint32_t base = lo; base < hi; base += kWave) {
-        const uint32_t i = base + lane;
+    const uint32_t range = hi - lo, stride = (range + kWave - 1) / kWave;
+    uint32_t seg_lo = lo;
+    if (stride > 1) {
+        const uint32_t i = lo + lane * stride;
         const uint32_t v = i < hi ? arr[i] : 0xFFFFFFFFu;
-        const unsigned long long m = __ballot(v <= key);
-        if (m) { // wave-uniform; arr is non-decreasing, so the last chunk with a hit holds the answer
-            const int top = 63 - __builtin_clzll(m);
-            val = (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(top));
-            cnt += (uint32_t)__builtin_popcountll(m);
-        }
+        const unsigned long long m = __ballot(v <= key);      // lane 0 always hits (arr[lo] <= key)
+        seg_lo = lo + ((uint32_t)__builtin_popcountll(m) - 1) * stride;
     }
-    value = val;
-    return lo + cnt - 1;
+    const uint32_t seg_hi = min(seg_lo + (stride > 1 ? stride : (uint32_t)kWave), hi);
+    const uint32_t i = seg_lo + lane;
+    const uint32_t v = i < seg_hi ? arr[i] : 0xFFFFFFFFu;
+    const unsigned long long m = __ballot(v <= key);
+    const int top = 63 - __builtin_clzll(m);
+    value = (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(top));
+    return seg_lo + (uint32_t)top;
 }
 
 // Work item = one WAVEFRONT = (d-block of kDB largest ids, third id c, tile of (a,b) with a<b<c).
