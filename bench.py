@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-trees", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score", action="store_true")
+    ap.add_argument("--no-impl-check", action="store_true", help="skip the on-device comparison with the byte-SWAR implementation (slow at >= 1024 taxa; parameter sweeps)")
     ap.add_argument("--distinct-trees", type=int, default=0,
                     help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
     ap.add_argument("--nni", action="store_true", help="evaluation trees = reference tree + Poisson(n/8) random NNIs (concentrated counts)")
@@ -295,7 +296,7 @@ def main():
     # stronger gate (the tuple sums are trivially m in the binary_full variant): the table must equal the one
     # the independent byte-SWAR implementation of the same count produces, bit for bit, on the device
     impl_match = None
-    if args.algo == "gather" and "bitslice" in variant:
+    if args.algo == "gather" and "bitslice" in variant and not args.no_impl_check:
         mine = table.clone()
         os.environ["QS_GATHER_IMPL"] = "swar"
         step()

@@ -57,10 +57,13 @@ struct qs_ctx {
 
 static std::string g_create_err;
 // upper bound of the pair-depth panel of one sub-batch (QS_PANEL_SLICE_BYTES overrides it: tests)
-static size_t panel_slice_bytes() {
+// Panel bytes per sub-batch: QS_PANEL_SLICE_BYTES, else 96 MiB (Infinity-Cache resident) but at least 32 tree groups
+// (a tile's fixed cost -- decode, first staging, table read-modify-write -- needs that many 32-tree steps to
+// amortise; at 1024 taxa a group is 10 MB and 96 MiB would leave 7 steps per launch), capped at 384 MiB.
+static size_t panel_slice_bytes(size_t group_bytes) {
     const char *e = getenv("QS_PANEL_SLICE_BYTES");
     if (e && *e) { long long v = atoll(e); if (v > 0) return (size_t)v; }
-    return 96ull << 20;
+    return std::min<size_t>(std::max<size_t>(96ull << 20, 32 * group_bytes), 384ull << 20);
 }
 
 static int fail(qs_ctx *c, int code, const std::string &msg) {
@@ -385,6 +388,8 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         // 256 MiB Infinity Cache while every wave streams through it; the price is one read-modify-write of
         // the table per sub-batch. Measured at 512 taxa x 10000 trees (819 MB of panel, 34 GB table):
         // 0.72 s with 50 MB slices, 0.60 s with 100 MB, 0.64 s with 192 MB, 0.71 s with 400 MB, 0.80 s unsliced.
+        // At 1024 taxa (10 MB per tree group) the optimum moves up: one of 8 table shards 1.03 s at 96 MiB, 0.78 s at
+        // 160 MB, 0.73 s at 224 MB; see panel_slice_bytes.
         // Two things that did NOT help (profiles/r01_experiments.md): visiting the tree groups in rotated order so
         // that late tiles stay in phase with the resident ones (the panel still streams from HBM once per
         // round of tiles), and non-temporal table accesses.
@@ -403,7 +408,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             tpc = 16 / (bits / 8); elem_bytes = 16;
         }
         const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
-        uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes() / chunk_bytes);
+        uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes(use_bitslice ? chunk_bytes : 0) / chunk_bytes);
         const uint32_t n_chunks_total = (d.n_trees + tpc - 1) / tpc;
         chunks_per_slice = std::min(chunks_per_slice, n_chunks_total);
         const size_t need = (size_t)chunks_per_slice * chunk_bytes;
