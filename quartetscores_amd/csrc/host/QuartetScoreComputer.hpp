@@ -107,10 +107,12 @@ private:
         try {
             for (size_t i0 = 0; i0 < spans.size(); i0 += opt.batch_trees) {
                 const size_t i1 = std::min(spans.size(), i0 + opt.batch_trees);
-                BatchFlat b = flatten_parallel(text, spans, i0, i1, ref_.name_to_id, threads);
+                const bool want_ranges = (opt.algo & 0xFFu) == QS_ALGO_SCATTER; // the gather kernels do not read them
+                BatchFlat b = flatten_parallel(text, spans, i0, i1, ref_.name_to_id, threads, want_ranges);
                 qs_tree_batch hb;
                 hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data();
-                hb.adj_depth = b.adj_depth.data(); hb.node_off = b.node_off.data(); hb.rng_off = b.rng_off.data();
+                hb.adj_depth = b.adj_depth.data();
+                hb.node_off = want_ranges ? b.node_off.data() : nullptr; hb.rng_off = want_ranges ? b.rng_off.data() : nullptr;
                 hb.ranges = b.ranges.data();
                 qs_device_batch *db = nullptr;
                 if (qs_batch_upload(ctx_, &hb, &db) != QS_OK) fail();  // synchronous copy: `b` may go away

@@ -119,7 +119,7 @@ inline void parse_flat(const std::string &text, size_t b, size_t e, FlatScratch 
 
 // Parse text[b, e) and append the tree to `batch`; same result as NewickReader + flatten_append.
 inline void parse_flatten_append(const std::string &text, size_t b, size_t e, const std::unordered_map<std::string, uint32_t> &name_to_id,
-                                 BatchFlat &batch, FlatScratch &s, bool recentre = true) {
+                                 BatchFlat &batch, FlatScratch &s, bool recentre = true, bool want_ranges = true) {
     detail::parse_flat(text, b, e, s);
     const size_t N = s.parent.size();
     // CSR adjacency, neighbour order = [parent, children in input order]
@@ -216,7 +216,8 @@ inline void parse_flatten_append(const std::string &text, size_t b, size_t e, co
     if (std::adjacent_find(s.tmp.begin(), s.tmp.end()) != s.tmp.end())
         throw std::runtime_error("duplicate taxon in evaluation tree " + std::to_string(batch.n_trees));
     batch.leaf_off.push_back((uint32_t)batch.leaf_ids.size());
-    for (size_t x = 0; x < N && L > 0; ++x) {
+    // leaf ranges of the links of the inner nodes: only the scatter kernel reads them
+    for (size_t x = 0; want_ranges && x < N && L > 0; ++x) {
         const uint32_t nk = nkids((int32_t)x);
         const size_t nlinks = nk + ((int32_t)x != r ? 1 : 0);
         if (nk == 0 || nlinks < 3) continue;

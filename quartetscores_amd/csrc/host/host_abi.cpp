@@ -31,8 +31,9 @@ const char *qsh_last_error(void) { return g_err.c_str(); }
 
 // Flattens the trees [tree_lo, min(tree_hi, m)) of eval_path against the taxa of the reference tree in ref_path.
 // *n_trees_total = m (trees in the file). 0 on success, 1 on error (qsh_last_error()).
+// want_ranges = 0 skips the per-link leaf ranges (only the scatter kernel reads them).
 int qsh_ingest(const char *ref_path, const char *eval_path, uint64_t tree_lo, uint64_t tree_hi, unsigned threads,
-               qsh_batch **out, uint64_t *n_trees_total) {
+               int want_ranges, qsh_batch **out, uint64_t *n_trees_total) {
     try {
         if (!ref_path || !eval_path || !out) throw std::runtime_error("qsh_ingest: NULL argument");
         const std::string refText = read_file(ref_path);
@@ -47,7 +48,7 @@ int qsh_ingest(const char *ref_path, const char *eval_path, uint64_t tree_lo, ui
         if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
         qsh_batch *b = new qsh_batch();
         try {
-            b->b = flatten_parallel(text, spans, lo, hi, rf.name_to_id, threads);
+            b->b = flatten_parallel(text, spans, lo, hi, rf.name_to_id, threads, want_ranges != 0);
         } catch (...) { delete b; throw; }
         *out = b;
         return 0;

@@ -12,6 +12,7 @@
 #include "newick.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <exception>
 #include <string>
 #include <thread>
@@ -23,23 +24,35 @@ namespace qsh {
 // [begin, end) byte spans of the trees in a Newick text: a tree ends at a ';' outside quotes and comments.
 inline std::vector<std::pair<size_t, size_t>> split_trees(const std::string &s) {
     std::vector<std::pair<size_t, size_t>> spans;
+    const char *base = s.data();
+    const size_t n = s.size();
     size_t start = 0;
-    bool in_quote = false, in_comment = false, content = false;
-    for (size_t i = 0; i < s.size(); ++i) {
-        const char ch = s[i];
-        if (in_comment) { if (ch == ']') in_comment = false; continue; }
-        if (in_quote) { if (ch == '\'') in_quote = false; continue; }
-        if (ch == '[') { in_comment = true; continue; }
-        if (ch == '\'') { in_quote = true; content = true; continue; }
-        if (ch == ';') {
-            if (content) spans.emplace_back(start, i + 1);
-            start = i + 1;
-            content = false;
+    while (start < n) {
+        // fast path: the next ';' ends the tree if no quote or comment opens before it (memchr scans)
+        const char *semi = static_cast<const char *>(memchr(base + start, ';', n - start));
+        const size_t stop = semi ? (size_t)(semi - base) : n;
+        if (!memchr(base + start, '\'', stop - start) && !memchr(base + start, '[', stop - start)) {
+            size_t i = start;
+            while (i < stop && (base[i] == ' ' || base[i] == '\t' || base[i] == '\n' || base[i] == '\r')) ++i;
+            if (i < stop) spans.emplace_back(start, semi ? stop + 1 : n);
+            start = stop + 1;
             continue;
         }
-        if (ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') content = true;
+        // slow path for this tree: a ';' inside quotes or comments does not end it
+        bool in_quote = false, in_comment = false, content = false, closed = false;
+        size_t i = start;
+        for (; i < n; ++i) {
+            const char ch = base[i];
+            if (in_comment) { if (ch == ']') in_comment = false; continue; }
+            if (in_quote) { if (ch == '\'') in_quote = false; continue; }
+            if (ch == '[') { in_comment = true; continue; }
+            if (ch == '\'') { in_quote = true; content = true; continue; }
+            if (ch == ';') { closed = true; break; }
+            if (ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') content = true;
+        }
+        if (content) spans.emplace_back(start, closed ? i + 1 : n); // the last tree may lack its ';'
+        start = i + 1;
     }
-    if (content) spans.emplace_back(start, s.size()); // last tree without ';'
     return spans;
 }
 
@@ -58,8 +71,11 @@ inline void append_batch(BatchFlat &dst, const BatchFlat &src) {
 
 // Parse + flatten the trees spans[i0..i1) with `threads` workers; the result keeps file order.
 // An unknown taxon / syntax error in any tree is rethrown on the caller's thread.
+// want_ranges = false skips the per-link leaf ranges (node_off / rng_off / ranges stay all-zero / empty): the gather
+// kernels read only leaf_ids and adj_depth.
 inline BatchFlat flatten_parallel(const std::string &text, const std::vector<std::pair<size_t, size_t>> &spans, size_t i0,
-                                  size_t i1, const std::unordered_map<std::string, uint32_t> &name_to_id, unsigned threads) {
+                                  size_t i1, const std::unordered_map<std::string, uint32_t> &name_to_id, unsigned threads,
+                                  bool want_ranges = true) {
     const size_t count = i1 - i0;
     threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, (count + 63) / 64));
     std::vector<BatchFlat> parts(threads);
@@ -71,7 +87,7 @@ inline BatchFlat flatten_parallel(const std::string &text, const std::vector<std
             BatchFlat b;         // worker-local (the vector headers of adjacent parts[] share cache lines)
             for (size_t i = lo; i < hi; ++i) {
                 try {
-                    parse_flatten_append(text, spans[i].first, spans[i].second, name_to_id, b, scratch);
+                    parse_flatten_append(text, spans[i].first, spans[i].second, name_to_id, b, scratch, true, want_ranges);
                 } catch (const UnknownTaxon &e) { // report the tree's index in the file, not in the part
                     throw UnknownTaxon(std::string(e.what()) + " (tree " + std::to_string(i) + " of the file)");
                 }

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace qs;
@@ -281,33 +282,53 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
         return fail(c, QS_ERR_ARG, "qs_batch_upload: leaf arrays missing");
     const uint32_t nt = hb->n_trees, n = c->n;
     // ---- validate (the reference dies on malformed input; we return a status) ----
+    // Trees are independent: large batches are checked by a few host threads, the first error in tree order wins.
+    struct Part { uint32_t max_depth = 0; bool all_full = true, all_binary = true; uint32_t err_tree = 0xFFFFFFFFu; std::string err; };
+    auto check = [&](uint32_t t0, uint32_t t1, Part &P) {
+        std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
+        std::vector<uint32_t> stack;
+        auto bad = [&](uint32_t t, const std::string &m) { P.err_tree = t; P.err = m; };
+        for (uint32_t t = t0; t < t1; ++t) {
+            if (hb->leaf_off[t + 1] < hb->leaf_off[t]) return bad(t, "qs_batch_upload: leaf_off not monotone");
+            const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
+            if (L > n) return bad(t, "qs_batch_upload: tree " + std::to_string(t) + " has more leaves than taxa");
+            if (L != n) P.all_full = false;
+            for (uint32_t i = 0; i < L; ++i) {
+                const uint32_t id = hb->leaf_ids[base + i];
+                if (id >= n) return bad(t, "qs_batch_upload: tree " + std::to_string(t) + ": taxon id out of range (unknown taxon)");
+                if (stamp[id] == t) return bad(t, "qs_batch_upload: tree " + std::to_string(t) + ": duplicate taxon");
+                stamp[id] = t;
+            }
+            // internal nodes from the adjacent-LCA depth sequence
+            stack.clear();
+            uint32_t nodes = 0, zeros = 0;
+            for (uint32_t i = 0; i + 1 < L; ++i) {
+                const uint32_t dd = hb->adj_depth[base + i];
+                P.max_depth = std::max(P.max_depth, dd);
+                if (dd == 0) ++zeros;
+                while (!stack.empty() && stack.back() > dd) stack.pop_back();
+                if (stack.empty() || stack.back() < dd) { stack.push_back(dd); ++nodes; }
+            }
+            const bool binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
+            if (!binary) P.all_binary = false;
+        }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned workers = nt >= 2048 ? std::min(8u, std::min(hw, nt / 1024)) : 1u;
+    std::vector<Part> parts(workers);
+    if (workers == 1) check(0, nt, parts[0]);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < workers; ++w)
+            pool.emplace_back([&, w] { check((uint32_t)((uint64_t)nt * w / workers), (uint32_t)((uint64_t)nt * (w + 1) / workers), parts[w]); });
+        for (auto &th : pool) th.join();
+    }
     uint32_t max_depth = 0;
     bool all_full = true, all_binary = true;
-    std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
-    std::vector<uint32_t> stack;
-    for (uint32_t t = 0; t < nt; ++t) {
-        if (hb->leaf_off[t + 1] < hb->leaf_off[t]) return fail(c, QS_ERR_ARG, "qs_batch_upload: leaf_off not monotone");
-        const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
-        if (L > n) return fail(c, QS_ERR_ARG, "qs_batch_upload: tree " + std::to_string(t) + " has more leaves than taxa");
-        if (L != n) all_full = false;
-        for (uint32_t i = 0; i < L; ++i) {
-            const uint32_t id = hb->leaf_ids[base + i];
-            if (id >= n) return fail(c, QS_ERR_ARG, "qs_batch_upload: tree " + std::to_string(t) + ": taxon id out of range (unknown taxon)");
-            if (stamp[id] == t) return fail(c, QS_ERR_ARG, "qs_batch_upload: tree " + std::to_string(t) + ": duplicate taxon");
-            stamp[id] = t;
-        }
-        // internal nodes from the adjacent-LCA depth sequence
-        stack.clear();
-        uint32_t nodes = 0, zeros = 0;
-        for (uint32_t i = 0; i + 1 < L; ++i) {
-            const uint32_t dd = hb->adj_depth[base + i];
-            max_depth = std::max(max_depth, dd);
-            if (dd == 0) ++zeros;
-            while (!stack.empty() && stack.back() > dd) stack.pop_back();
-            if (stack.empty() || stack.back() < dd) { stack.push_back(dd); ++nodes; }
-        }
-        const bool binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
-        if (!binary) all_binary = false;
+    for (const Part &P : parts) { // parts are in tree order: the first one with an error holds the earliest bad tree
+        if (P.err_tree != 0xFFFFFFFFu) return fail(c, QS_ERR_ARG, P.err);
+        max_depth = std::max(max_depth, P.max_depth);
+        all_full = all_full && P.all_full; all_binary = all_binary && P.all_binary;
     }
     qs_device_batch *b = new qs_device_batch();
     DeviceBatch &d = b->d;

@@ -76,9 +76,9 @@ def main(argv=None):
         if native_ingest.available():
             # the C++ host's multi-threaded ingest: one scan for the tree spans (= m), then only this rank's share is
             # parsed and flattened (the reference parses the whole file twice on one thread, QuartetScores.cpp:23-32)
-            _, m = native_ingest.ingest(args.ref, args.eval, 0, 0, args.threads)
+            _, m = native_ingest.ingest(args.ref, args.eval, 0, 0, args.threads, want_ranges=False)
             lo, hi = distributed.shard_range(m, world, rank)
-            local, _ = native_ingest.ingest(args.ref, args.eval, lo, hi, args.threads)
+            local, _ = native_ingest.ingest(args.ref, args.eval, lo, hi, args.threads, want_ranges=False)
         else:
             say("note: libquartetscores_host.so not built; using the (slow) Python Newick parser")
             trees = list(newick.parse_trees(open(args.eval).read()))

@@ -33,7 +33,7 @@ def _lib():
         L = C.CDLL(_path())
         L.qsh_last_error.restype = C.c_char_p
         L.qsh_ingest.restype = C.c_int
-        L.qsh_ingest.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.qsh_ingest.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.qsh_batch_n_trees.restype = C.c_uint32
         L.qsh_batch_n_trees.argtypes = [C.c_void_p]
         L.qsh_batch_array.restype = C.c_void_p
@@ -43,15 +43,18 @@ def _lib():
     return _LIB
 
 
-def ingest(ref_path: str, eval_path: str, tree_lo: int = 0, tree_hi: int = ALL, threads: int = 0) -> Tuple[flatten.TreeBatch, int]:
+def ingest(ref_path: str, eval_path: str, tree_lo: int = 0, tree_hi: int = ALL, threads: int = 0,
+           want_ranges: bool = True) -> Tuple[flatten.TreeBatch, int]:
     """Flatten trees [tree_lo, tree_hi) of `eval_path` against the taxa of the reference tree in `ref_path`.
-    Returns (TreeBatch, number of trees in the file). threads = 0: all hardware threads.
+    Returns (TreeBatch, number of trees in the file). threads = 0: all hardware threads. want_ranges=False skips the
+    per-link leaf ranges (node_off all zero, rng_off = [0], ranges empty): only the scatter kernel reads them.
     An unknown taxon or a syntax error raises IngestError (the reference dies with std::out_of_range,
     QuartetCounterLookup.hpp:218)."""
     L = _lib()
     h = C.c_void_p()
     total = C.c_uint64(0)
-    rc = L.qsh_ingest(ref_path.encode(), eval_path.encode(), tree_lo, min(tree_hi, ALL), threads, C.byref(h), C.byref(total))
+    rc = L.qsh_ingest(ref_path.encode(), eval_path.encode(), tree_lo, min(tree_hi, ALL), threads, 1 if want_ranges else 0,
+                      C.byref(h), C.byref(total))
     if rc != 0:
         raise IngestError(L.qsh_last_error().decode())
     try:

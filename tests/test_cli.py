@@ -97,6 +97,10 @@ def test_native_ingest_binding_matches_python_host(tmp_path):
         assert got.n_trees == exp.n_trees
         for f in ("leaf_off", "leaf_ids", "adj_depth", "node_off", "rng_off", "ranges"):
             assert np.array_equal(getattr(got, f), getattr(exp, f)), (f, lo, hi, th)
+    lean, _ = native_ingest.ingest(str(r), str(e), 5, 60, 2, want_ranges=False)   # what the gather path needs
+    exp = want.slice(5, 60)
+    assert np.array_equal(lean.leaf_ids, exp.leaf_ids) and np.array_equal(lean.adj_depth, exp.adj_depth)
+    assert lean.ranges.size == 0 and not lean.node_off.any()
     bad = tmp_path / "bad.nwk"
     bad.write_text("\n".join(trees[:70]) + "\n((t0,t1),(t2,zzz),(t3,t4));\n")
     with pytest.raises(native_ingest.IngestError) as ei:

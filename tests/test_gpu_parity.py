@@ -726,3 +726,25 @@ def test_two_cell_wire_format(eng):
     assert ei.value.code == -4 and "two-cell" in str(ei.value)
     with pytest.raises(eng.QSError):
         ctx.table_pack16x2(words[:-1])
+
+
+def test_large_batch_validation_runs_on_several_host_threads(eng):
+    """qs_batch_upload checks batches of >= 2048 trees with a pool of host threads: same table as many small
+    batches, and the error reported is the one of the FIRST bad tree in tree order."""
+    n, m = 9, 5000
+    ref_nw, trees = make_case(n, m, 97, collapse=0.1)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    _, T1 = gpu_table(eng, ref, batch)
+    _, T2 = gpu_table(eng, ref, batch, split=700)
+    assert np.array_equal(T1, T2)
+    assert (T1.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all()
+    bad = flatten.TreeBatch(batch.n_trees, batch.leaf_off.copy(), batch.leaf_ids.copy(), batch.adj_depth.copy(),
+                            batch.node_off.copy(), batch.rng_off.copy(), batch.ranges.copy())
+    for t in (4100, 2500):     # the later error is planted first
+        bad.leaf_ids[bad.leaf_off[t]] = n + 3
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    with pytest.raises(eng.QSError) as ei:
+        ctx.count_trees(bad)
+    assert "tree 2500" in str(ei.value)
