@@ -196,3 +196,22 @@ def test_qs_create_fails_loudly_without_gpu():
     rc = L.qs_create(C.byref(h), 8, 32, 0, 0, None, 0, 8)
     assert rc == _lib.QS_ERR_NO_DEVICE and not h.value
     assert b"no CPU fallback" in L.qs_last_error(None)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/quartetscores_hip.h is the drop-in boundary: it must compile as C99 (no C++, no torch types) and a C
+    program must link against the library with nothing but the header."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "quartetscores_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { qs_ctx *c = 0; int rc = qs_create(&c, 8, 32, 0, 0, 0, 0, 0);\n'
+                   '  printf("%s|%d|%s\\n", qs_version(), rc, qs_last_error(c)); if (c) qs_destroy(c); return 0; }\n')
+    exe = tmp_path / "use"
+    lib_dir = os.path.join(ROOT, "quartetscores_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", lib_dir, "-lquartetscores_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "quartetscores_amd" in p.stdout
+    import torch
+    if not torch.cuda.is_available():       # no device here: the C caller sees the loud failure too
+        assert "|-6|" in p.stdout and "no HIP device" in p.stdout
