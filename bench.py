@@ -205,6 +205,8 @@ def main():
     # Untimed pre-conditioning, then the W warm-up steps the contract asks for: a 0.2 ms step is far shorter than the
     # GPU's clock ramp, so a run of 20 steps from idle measures 0.233 ms per step where 1000 steps measure 0.192 ms.
     if args.prewarm_ms > 0:
+        step()                     # first step: lazy initialisation (code objects, RCCL communicator), not representative
+        drain()
         torch.cuda.synchronize(dev)
         t_pre = time.perf_counter()
         step()
