@@ -36,11 +36,25 @@ inline std::string slurp(const std::string &path) {
     return ss.str();
 }
 
-// Count the number of evaluation trees (QuartetScores.cpp:23-32). The reference parses the whole file
-// just to count; here it is one scan for top-level ';' (ingest.hpp).
-inline size_t countEvalTrees(const std::string &evalTreesPath) {
-    return split_trees(slurp(evalTreesPath)).size();
+// The evaluation file, read and cut into tree spans ONCE (the reference reads it twice: to count the trees,
+// QuartetScores.cpp:23-32, and to stream them). countEvalTrees() fills the cache, the counter consumes it.
+struct EvalFile {
+    std::string path, text;
+    std::vector<std::pair<size_t, size_t>> spans;
+};
+inline std::shared_ptr<const EvalFile> loadEvalFile(const std::string &evalTreesPath) {
+    static std::shared_ptr<const EvalFile> cache;
+    if (!cache || cache->path != evalTreesPath) {
+        auto f = std::make_shared<EvalFile>();
+        f->path = evalTreesPath;
+        f->text = slurp(evalTreesPath);
+        f->spans = split_trees(f->text);
+        cache = f;
+    }
+    return cache;
 }
+// Count the number of evaluation trees: one scan for top-level ';' (ingest.hpp).
+inline size_t countEvalTrees(const std::string &evalTreesPath) { return loadEvalFile(evalTreesPath)->spans.size(); }
 
 struct DeviceOptions {
     int device = 0;
@@ -58,11 +72,30 @@ public:
         : ref_(flatten_reference(refTree)), savemem_(savemem) {
         static_assert(sizeof(CINT) <= 4, "m >= 2^32 evaluation trees are not supported by the GPU table");
         const uint32_t bits = sizeof(CINT) <= 2 ? 16 : 32;
-        (void)m;
-        if (qs_create(&ctx_, (uint32_t)ref_.names.size(), bits, QS_FLAG_NONE, opt.device, nullptr, 0, 0) != QS_OK)
-            throw std::runtime_error(qs_last_error(nullptr));
-        if (qs_table_alloc(ctx_) != QS_OK) fail();
-        countQuartets(evalTreesPath, m, opt);
+        // HIP initialisation + table allocation (~0.1 s) run on a helper thread while this one reads the evaluation
+        // file and flattens the first batch
+        int rc_create = QS_OK, rc_alloc = QS_OK;
+        std::string create_err;
+        std::thread gpu_init([&] {
+            rc_create = qs_create(&ctx_, (uint32_t)ref_.names.size(), bits, QS_FLAG_NONE, opt.device, nullptr, 0, 0);
+            if (rc_create != QS_OK) { create_err = qs_last_error(nullptr); return; }
+            rc_alloc = qs_table_alloc(ctx_);
+        });
+        std::shared_ptr<const EvalFile> ef;
+        BatchFlat first;
+        std::exception_ptr host_err;
+        const bool counting = opt.load_table.empty();
+        try {
+            if (counting) {
+                ef = loadEvalFile(evalTreesPath);
+                first = flatten_batch(*ef, 0, opt);
+            }
+        } catch (...) { host_err = std::current_exception(); }
+        gpu_init.join();
+        if (rc_create != QS_OK) throw std::runtime_error(create_err);
+        if (rc_alloc != QS_OK) fail();
+        if (host_err) std::rethrow_exception(host_err);
+        countQuartets(ef, std::move(first), m, opt);
         std::cout << "lookup table size in bytes: " << qs_table_bytes(ctx_) << "\n"; // QCL:268-272
     }
     ~QuartetCounterLookup() { qs_destroy(ctx_); }
@@ -91,24 +124,30 @@ private:
     }
     // QuartetCounterLookup.hpp:196-238. One pass over the file: spans of trees are parsed + flattened by a
     // thread pool, batch by batch, while the GPU counts the previous batch (qs_count_batch is asynchronous).
-    void countQuartets(const std::string &evalTreesPath, size_t m, const DeviceOptions &opt) {
+    static unsigned threads_of(const DeviceOptions &opt) {
+        return opt.ingest_threads ? opt.ingest_threads : std::max(1u, std::thread::hardware_concurrency());
+    }
+    static bool wants_ranges(const DeviceOptions &opt) { return (opt.algo & 0xFFu) == QS_ALGO_SCATTER; } // the gather kernels do not read them
+    BatchFlat flatten_batch(const EvalFile &ef, size_t i0, const DeviceOptions &opt) const {
+        const size_t i1 = std::min(ef.spans.size(), i0 + opt.batch_trees);
+        return flatten_parallel(ef.text, ef.spans, i0, i1, ref_.name_to_id, threads_of(opt), wants_ranges(opt));
+    }
+    void countQuartets(const std::shared_ptr<const EvalFile> &ef, BatchFlat first, size_t m, const DeviceOptions &opt) {
         if (!opt.load_table.empty()) { // resume from a saved table instead of counting
             std::string bytes = slurp(opt.load_table);
             if (bytes.size() != qs_table_bytes(ctx_)) throw std::runtime_error("--load-table: size does not match this reference tree / counter width");
             if (qs_table_upload(ctx_, bytes.data(), bytes.size()) != QS_OK) fail();
             return;
         }
-        const std::string text = slurp(evalTreesPath);
-        const auto spans = split_trees(text);
-        unsigned threads = opt.ingest_threads ? opt.ingest_threads : std::max(1u, std::thread::hardware_concurrency());
+        const auto &spans = ef->spans;
+        const bool want_ranges = wants_ranges(opt);
         std::vector<qs_device_batch *> in_flight;
         unsigned progress = 1;
         const float onePercent = (float)m / 100;
         try {
             for (size_t i0 = 0; i0 < spans.size(); i0 += opt.batch_trees) {
                 const size_t i1 = std::min(spans.size(), i0 + opt.batch_trees);
-                const bool want_ranges = (opt.algo & 0xFFu) == QS_ALGO_SCATTER; // the gather kernels do not read them
-                BatchFlat b = flatten_parallel(text, spans, i0, i1, ref_.name_to_id, threads, want_ranges);
+                BatchFlat b = i0 == 0 ? std::move(first) : flatten_batch(*ef, i0, opt);
                 qs_tree_batch hb;
                 hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data();
                 hb.adj_depth = b.adj_depth.data();
