@@ -25,6 +25,8 @@
 #include "qs_common.hpp"
 #include "qs_internal.hpp"
 
+#include <algorithm>
+
 namespace qs {
 
 // QuartetScoreComputer.hpp:135-159 (device evaluation; only used to ORDER candidates -- the host re-evaluates the
@@ -113,7 +115,8 @@ __device__ __forceinline__ QuartetRef classify(const ScoreDevice &sd, uint64_t l
 // runs of equal keys with a segmented scan (shuffles), (2) the run tails add into a small
 // open-addressing hash table in LDS (ds atomics), (3) the table is flushed once with global
 // atomics. This cuts the global atomics from 4 per quartet to 4 per distinct pair per workgroup.
-constexpr int kP1Iters = 16;
+constexpr int kP1Iters = 16;      // passes of 256 ranks per workgroup (pass 2, raw QIC; lower bound for pass 1)
+constexpr int kP1ItersMax = 64;   // pass 1 on large tables: 4x fewer hash flushes (global atomics) per quartet
 constexpr int kP1Slots = 1024; // power of two
 constexpr uint32_t kKeyEmpty = 0xFFFFFFFFu;
 
@@ -162,7 +165,7 @@ __device__ __forceinline__ void seg_carry(uint32_t lane, uint32_t run, unsigned 
 }
 
 template <typename CT>
-__global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
+__global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd, int iters) {
     __shared__ P1Lds lds;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     for (uint32_t i = tid; i < kP1Slots; i += 256) {
@@ -171,10 +174,10 @@ __global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd) {
         lds.mn[i] = kSortableMax;
     }
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
+    const uint64_t base = (uint64_t)blockIdx.x * (256ull * iters);
     Ids4 base_ids;
     unrank4(base + sd.rank_lo, base_ids.a, base_ids.b, base_ids.c, base_ids.d);
-    for (int it = 0; it < kP1Iters; ++it) {
+    for (int it = 0; it < iters; ++it) {
         const uint64_t r = base + (uint64_t)it * 256 + tid;
         QuartetRef q;
         q.resolved = false; q.key = kKeyEmpty; q.q1 = q.q2 = q.q3 = 0;
@@ -284,10 +287,12 @@ __global__ __launch_bounds__(256) void raw_qic_kernel(ScoreDevice sd, uint64_t r
 
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
     if (sd.n_tuples == 0) return hipSuccess;
-    const uint64_t per_block = 256ull * kP1Iters;
+    // as many passes per workgroup as still leave >= 8192 workgroups (128 taxa: 16, from ~230 taxa on: 64)
+    const int iters = (int)std::min<uint64_t>(kP1ItersMax, std::max<uint64_t>(kP1Iters, sd.n_tuples / (256ull * 8192)));
+    const uint64_t per_block = 256ull * iters;
     dim3 block(256), grid((unsigned)((sd.n_tuples + per_block - 1) / per_block));
-    if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass1_kernel<uint32_t>, grid, block, 0, s, sd);
-    else hipLaunchKernelGGL(score_pass1_kernel<uint16_t>, grid, block, 0, s, sd);
+    if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass1_kernel<uint32_t>, grid, block, 0, s, sd, iters);
+    else hipLaunchKernelGGL(score_pass1_kernel<uint16_t>, grid, block, 0, s, sd, iters);
     return hipGetLastError();
 }
 
