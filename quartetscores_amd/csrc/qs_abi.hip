@@ -761,40 +761,75 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
         lqic[v] = inf;
         if (R.bifurcating) { qpic[v] = inf; eqpic[v] = inf; }
     }
-    for (uint32_t iu = 0; iu < R.n_inner; ++iu)
-        for (uint32_t iv = iu + 1; iv < R.n_inner; ++iv) {
-            const size_t key = (size_t)iu * R.n_inner + iv;
-            double lqmin = inf;
-            bool any = false;
-            for (uint32_t part = 0; part < n_cand_parts; ++part) {
-                const unsigned long long *cs = cand + ((size_t)part * np + key) * kCand;
-                for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
-                    const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
-                    const double v = host_log_score(q1, q2, q3);
-                    lqmin = std::min(lqmin, v);
-                    any = true;
+    // The O(#node pairs) finalisation runs on a few host threads for large references. Each thread folds a contiguous
+    // range of iu (pairs are visited in (iu, iv) order) into private vectors; merging the ranges in order reproduces
+    // the sequential result exactly, including which of two equal minima / which of two writers of a QP value wins.
+    struct Local { std::vector<double> lq, qp, eqp; std::vector<uint8_t> qp_set; };
+    auto fold = [&](uint32_t iu0, uint32_t iu1, Local &out) {
+        out.lq.assign(N, inf);
+        if (R.bifurcating) { out.qp.assign(N, inf); out.eqp.assign(N, inf); out.qp_set.assign(N, 0); }
+        for (uint32_t iu = iu0; iu < iu1; ++iu)
+            for (uint32_t iv = iu + 1; iv < R.n_inner; ++iv) {
+                const size_t key = (size_t)iu * R.n_inner + iv;
+                double lqmin = inf;
+                bool any = false;
+                for (uint32_t part = 0; part < n_cand_parts; ++part) {
+                    const unsigned long long *cs = cand + ((size_t)part * np + key) * kCand;
+                    for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
+                        const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
+                        const double v = host_log_score(q1, q2, q3);
+                        lqmin = std::min(lqmin, v);
+                        any = true;
+                    }
+                }
+                if (!any) continue; // pair owns no resolved quartet
+                uint64_t p1 = sums[key * 3], p2 = sums[key * 3 + 1], p3 = sums[key * 3 + 2];
+                if (!(flags & QS_SCORE_QP_EXACT64)) { p1 &= 0xFFFFFFFFull; p2 &= 0xFFFFFFFFull; p3 &= 0xFFFFFFFFull; } // QSC:382
+                const double qp = host_log_score(p1, p2, p3);
+                // walk the path u..v (edges are indexed by their child node)
+                uint32_t x = R.inner_node[iu], y = R.inner_node[iv];
+                uint32_t path_edges = 0, last_edge_a = 0, last_edge_b = 0;
+                while (x != y) {
+                    uint32_t e;
+                    if (R.depth[x] >= R.depth[y]) { e = x; x = (uint32_t)R.parent[x]; }
+                    else { e = y; y = (uint32_t)R.parent[y]; }
+                    out.lq[e] = std::min(out.lq[e], lqmin);
+                    if (R.bifurcating) out.eqp[e] = std::min(out.eqp[e], qp);
+                    if (path_edges == 0) last_edge_a = e; else last_edge_b = e;
+                    ++path_edges;
+                }
+                if (R.bifurcating) {
+                    const bool through_deg2_root = path_edges == 2 && x == R.root && R.nchild[R.root] == 2;
+                    if (path_edges == 1) { out.qp[last_edge_a] = qp; out.qp_set[last_edge_a] = 1; }
+                    else if (through_deg2_root) { out.qp[last_edge_a] = qp; out.qp[last_edge_b] = qp; out.qp_set[last_edge_a] = out.qp_set[last_edge_b] = 1; }
                 }
             }
-            if (!any) continue; // pair owns no resolved quartet
-            uint64_t p1 = sums[key * 3], p2 = sums[key * 3 + 1], p3 = sums[key * 3 + 2];
-            if (!(flags & QS_SCORE_QP_EXACT64)) { p1 &= 0xFFFFFFFFull; p2 &= 0xFFFFFFFFull; p3 &= 0xFFFFFFFFull; } // QSC:382
-            const double qp = host_log_score(p1, p2, p3);
-            // walk the path u..v (edges are indexed by their child node)
-            uint32_t x = R.inner_node[iu], y = R.inner_node[iv];
-            uint32_t path_edges = 0, last_edge_a = 0, last_edge_b = 0;
-            while (x != y) {
-                uint32_t e;
-                if (R.depth[x] >= R.depth[y]) { e = x; x = (uint32_t)R.parent[x]; }
-                else { e = y; y = (uint32_t)R.parent[y]; }
-                lqic[e] = std::min(lqic[e], lqmin);
-                if (R.bifurcating) eqpic[e] = std::min(eqpic[e], qp);
-                if (path_edges == 0) last_edge_a = e; else last_edge_b = e;
-                ++path_edges;
-            }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned workers = R.n_inner >= 128 ? std::min(8u, hw) : 1u;
+    std::vector<Local> parts(workers);
+    if (workers == 1) fold(0, R.n_inner, parts[0]);
+    else {
+        // ranges of iu with about the same number of pairs (row iu has n_inner - 1 - iu of them)
+        std::vector<uint32_t> cut(workers + 1, R.n_inner);
+        const uint64_t total = (uint64_t)R.n_inner * (R.n_inner - 1) / 2;
+        uint64_t acc = 0;
+        uint32_t w = 1;
+        cut[0] = 0;
+        for (uint32_t iu = 0; iu < R.n_inner && w < workers; ++iu) {
+            acc += R.n_inner - 1 - iu;
+            while (w < workers && acc >= total * w / workers) cut[w++] = iu + 1;
+        }
+        std::vector<std::thread> pool;
+        for (unsigned k = 0; k < workers; ++k) pool.emplace_back([&, k] { fold(cut[k], cut[k + 1], parts[k]); });
+        for (auto &th : pool) th.join();
+    }
+    for (const Local &L : parts) // in range order
+        for (uint32_t v = 0; v < N; ++v) {
+            lqic[v] = std::min(lqic[v], L.lq[v]);
             if (R.bifurcating) {
-                const bool through_deg2_root = path_edges == 2 && x == R.root && R.nchild[R.root] == 2;
-                if (path_edges == 1) qpic[last_edge_a] = qp;
-                else if (through_deg2_root) { qpic[last_edge_a] = qp; qpic[last_edge_b] = qp; }
+                eqpic[v] = std::min(eqpic[v], L.eqp[v]);
+                if (L.qp_set[v]) qpic[v] = L.qp[v];
             }
         }
     return QS_OK;
