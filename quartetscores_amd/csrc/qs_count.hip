@@ -750,13 +750,16 @@ __device__ __forceinline__ uint32_t gt_planes(const Planes &l, const Planes &r) 
 }
 
 // ======================================================================================
-// count_bitslice3_kernel: the binary_full fast path (every tree holds all taxa and is binary)
+// count_bitslice3_kernel: the bit-sliced count of every batch whose depths fit 7 bits (6 with missing taxa)
 // ======================================================================================
-// Same arithmetic as count_bitslice_kernel, two topologies counted (the third is m minus the other two), and TWO
-// a-columns per lane: the tile is 16 a x 8 b, lane (ia, ib) owns a1 = 8*A1+ia, a2 = 8*A2+ia and b = 8*Bk+ib
-// (A1 < A2 < Bk are 8-blocks of ids below c; A2 is absent in the last tile of an odd Bk). The staged R element of
-// (b,d) is read from LDS once and compared against both L(a1,b,c) and L(a2,b,c). Diagonal tiles keep the packing
-// of count_bitslice_kernel (two diagonal blocks per wave, one a per lane).
+// Wave = (d-block of 8, c, tile of (a,b)); lane = (a,b); the arithmetic of the section above.
+//   binary_full instance (every tree binary and holding all taxa): two topologies are counted (the third is m minus
+//   the other two) and a lane owns TWO a-columns: the tile is 16 a x 8 b, lane (ia, ib) owns a1 = 8*A1+ia,
+//   a2 = 8*A2+ia and b = 8*Bk+ib (A1 < A2 < Bk are 8-blocks of ids below c; A2 is absent in the last tile of an
+//   odd Bk). The staged R element of (b,d) is read from LDS once and compared against both L(a1,b,c) and L(a2,b,c).
+//   general_full / partial instances: one a-column, tile 8 a x 8 b, three topologies counted, R staged for all 16
+//   columns (the lane also reads R of (a,d)); partial batches carry a presence word per element.
+//   Diagonal tiles (a and b from the same block) pack two diagonal blocks per wave, one a per lane.
 // The step over 32 trees is built around what the ISA of its predecessor showed (60 % of the instructions were not
 // comparison chains; profiles/r01_experiments.md):
 //   * the panel is COMPACT: per tree group uint4 lo[npairs] (planes 0..3) followed by the B-4 upper planes per
