@@ -550,6 +550,19 @@ def test_config2_full_size_properties(eng):
     assert (eqp[internal] <= qp[internal]).all()                       # EQP-IC is a min that includes the edge's own pair
 
 
+@pytest.mark.parametrize("kw", [{}, {"collapse": 0.15, "dropout": 0.1}])
+def test_scores_above_128_inner_nodes_take_the_threaded_finalisation(eng, kw):
+    """From 128 inner nodes on (n >= 130) qs_score_finish folds the node pairs on several host threads and the
+    large-table variant of pass 1 is close: scores must still equal the oracle's, bit for bit."""
+    n, m = 134, 8        # 132 inner nodes; the oracle's compact table costs ~m * n^4 / 12 increments
+    ref_nw, trees = make_case(n, m, 131, **kw)
+    o = Oracle(ref_nw)
+    o.count("\n".join(trees), savemem=True, cint_bits=16)      # compact oracle table (the n^4 one would be 1 GB)
+    o.score(nthreads=8)
+    qsc = eng.QuartetScoreComputer(ref_nw, trees)
+    assert assert_scores_equal(qsc.scores_by_bipartition(), o.scores_by_bipartition()) == 0
+
+
 def test_pack16_wire_format(eng):
     """qs_table_pack16: the u32 table as u16 cells is a valid count_bits=16 table (same counts, same scores);
     packed words add without carries (what the multi-GPU all-reduce relies on); a cell >= 2^16 is reported."""
