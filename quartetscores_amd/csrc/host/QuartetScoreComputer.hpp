@@ -281,6 +281,39 @@ public:
         }
         outfile.close();
     }
+    // Binary sidecar of the -q dump: no text formatting, 9 bytes per quartet instead of ~35.
+    //   char magic[8] = "QSQIC01"; u32 n_taxa; u32 reserved; u64 n_quartets;
+    //   n_taxa x { u32 length; bytes }            taxon names in lookup-id order
+    //   u8  topo[n_quartets]                      per rank (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0 of the sorted lookup ids):
+    //                                             0 = s0 s1 | s2 s3, 2 = s0 s3 | s1 s2, 255 = not resolved in the reference
+    //   f64 qic[n_quartets]                       raw QIC of the reference topology (NaN where topo = 255)
+    void printRawQICBinary(Tree const &refTree, const std::string &path) {
+        std::ofstream out(path, std::ios::binary);
+        if (!out) throw std::runtime_error("cannot write " + path);
+        const RefFlat &rf = quartetCounterLookup->reference();
+        qs_ctx *ctx = quartetCounterLookup->context();
+        qs_ref_tree rt;
+        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
+        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
+        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 22;
+        const char magic[8] = {'Q', 'S', 'Q', 'I', 'C', '0', '1', 0};
+        const uint32_t n32 = rt.n_taxa, zero = 0;
+        out.write(magic, 8); out.write((const char *)&n32, 4); out.write((const char *)&zero, 4); out.write((const char *)&total, 8);
+        for (const std::string &nm : rf.names) { const uint32_t len = (uint32_t)nm.size(); out.write((const char *)&len, 4); out.write(nm.data(), len); }
+        const std::streamoff topo_at = out.tellp(), qic_at = topo_at + (std::streamoff)total;
+        std::vector<uint8_t> topo(chunk);
+        std::vector<uint64_t> q(chunk * 3);
+        std::vector<double> qic(chunk);
+        for (uint64_t r = 0; r < total; r += chunk) {
+            const uint64_t nq = std::min(chunk, total - r);
+            if (qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+            for (uint64_t i = 0; i < nq; ++i)
+                qic[i] = topo[i] == 255 ? std::numeric_limits<double>::quiet_NaN() : log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+            out.seekp(topo_at + (std::streamoff)r); out.write((const char *)topo.data(), (std::streamsize)nq);
+            out.seekp(qic_at + (std::streamoff)(r * 8)); out.write((const char *)qic.data(), (std::streamsize)(nq * 8));
+        }
+        if (!out) throw std::runtime_error("error writing " + path);
+    }
     unsigned raw_threads = 0; // threads that format the -q file (0 = hardware concurrency)
 
     // rank -> sorted ids (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0)

@@ -2,7 +2,7 @@
 // (QuartetScores.cpp:48-79: -r -e -o required, -q -t -v -s optional) and stdout protocol.
 //
 //   QuartetScores -r ref.nwk -e eval.nwk -o out.nwk [-q raw.txt] [-t N] [-v] [-s]
-//                 [--device N] [--algo gather|scatter] [--exact-qp]
+//                 [--device N] [--algo gather|scatter] [--exact-qp] [--qic-binary raw.bin]
 //
 // -t sets the number of host threads that parse + flatten the evaluation trees (the reference's OpenMP
 // threads counted quartets; here that happens on the GPU). -s/--savemem is accepted and has no effect: the
@@ -22,7 +22,7 @@ using namespace qsh;
 namespace {
 
 struct Args {
-    std::string ref, eval, out, raw;
+    std::string ref, eval, out, raw, raw_bin;
     size_t threads = 0;
     bool verbose = false, savemem = false;
     DeviceOptions dev;
@@ -41,7 +41,8 @@ void usage(std::ostream &os) {
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
           "   --save-table F write the count table to F after counting\n"
-          "   --load-table F read the count table from F instead of counting (-e is still needed for m)\n";
+          "   --load-table F read the count table from F instead of counting (-e is still needed for m)\n"
+          "   --qic-binary F raw per-quartet QIC as a binary file (topology byte + double per quartet, in rank order)\n";
 }
 
 // returns 0 ok, 1 error (message printed like the reference prints TCLAP::ArgException), 2 exit quietly
@@ -69,6 +70,7 @@ int parse(int argc, char **argv, Args &a) {
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
         else if (f == "--save-table") { if (!(v = need(i, "--save-table"))) return 1; a.dev.save_table = v; }
+        else if (f == "--qic-binary") { if (!(v = need(i, "--qic-binary"))) return 1; a.raw_bin = v; }
         else if (f == "--load-table") { if (!(v = need(i, "--load-table"))) return 1; a.dev.load_table = v; }
         else if (f == "--version") { std::cout << argv[0] << "  version: 1.0.1 (" << qs_version() << ")" << std::endl; return 2; }
         else if (f == "-h" || f == "--help") { usage(std::cout); return 2; }
@@ -88,6 +90,7 @@ void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double>
     eqpic = qsc.getEQPICScores();
     qsc.raw_threads = a.dev.ingest_threads;
     if (!a.raw.empty()) qsc.printRawQICScores(referenceTree, a.raw);
+    if (!a.raw_bin.empty()) qsc.printRawQICBinary(referenceTree, a.raw_bin);
 }
 
 } // namespace

@@ -182,6 +182,30 @@ def test_cli_end_to_end_matches_oracle(d1_files, tmp_path, golden):
             d[frozenset([frozenset(l.split(",")), frozenset(rr.split(","))])] = val
         return d
     assert canon(str(raw)) == canon(str(ora_raw)) and len(canon(str(raw))) == 70
+    # binary sidecar of the raw QIC dump: same quartets, same topologies, QIC equal to the printed %g value
+    import struct
+    import numpy as np
+    rawb = tmp_path / "raw.bin"
+    p = run("-r", r, "-e", e, "-o", str(tmp_path / "ob.nwk"), "--qic-binary", str(rawb))
+    assert p.returncode == 0, p.stderr
+    blob = rawb.read_bytes()
+    assert blob[:8] == b"QSQIC01\0"
+    n_taxa, _, nq = struct.unpack_from("<IIQ", blob, 8)
+    assert (n_taxa, nq) == (8, 70)
+    off, names = 24, []
+    for _ in range(n_taxa):
+        (ln,) = struct.unpack_from("<I", blob, off)
+        names.append(blob[off + 4:off + 4 + ln].decode()); off += 4 + ln
+    topo = np.frombuffer(blob, dtype=np.uint8, count=nq, offset=off)
+    qic = np.frombuffer(blob[off + nq:off + nq + 8 * nq], dtype="<f8")
+    text_vals = canon(str(raw))
+    from itertools import combinations
+    quads = sorted(combinations(range(n_taxa), 4), key=lambda q: (q[3], q[2], q[1], q[0]))
+    assert len(quads) == nq and set(topo.tolist()) <= {0, 2}
+    for rk, (s0, s1, s2, s3) in enumerate(quads):
+        A, B, C_, D = names[s0], names[s1], names[s2], names[s3]
+        key = frozenset([frozenset([A, B]), frozenset([C_, D])]) if topo[rk] == 0 else frozenset([frozenset([A, D]), frozenset([B, C_])])
+        assert key in text_vals and "%g" % qic[rk] == text_vals[key]
     # table persistence: save after counting, reload instead of counting -> the same annotated tree
     tab = tmp_path / "table.bin"
     out2, out3 = tmp_path / "o2.nwk", tmp_path / "o3.nwk"
