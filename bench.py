@@ -176,9 +176,16 @@ def main():
             ctx.table_attach(tables[i])
         if args.algo != "gather":
             ctx.table_clear()
-        ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
+        if use_dist and wire_fmt == "u16x2" and not timed:
+            # counted straight into the wire words: no table write, no pack pass (QS_COUNT_WIRE16X2)
+            ctx.wire_attach(wire[i])
+            ctx.count_batch(hb, step_algo | engine.QS_COUNT_WIRE16X2)
+        else:
+            ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
         if use_dist:
-            if wire16:
+            if wire_fmt == "u16x2" and not timed:
+                src = wire[i]
+            elif wire16:
                 (ctx.table_pack16x2 if wire_fmt == "u16x2" else ctx.table_pack16)(wire[i])
                 src = wire[i]
             else:
@@ -353,7 +360,7 @@ def main():
             "distinct_trees": distinct,
             "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((({"u16": " + pack to u16 cells", "u16x2": " + pack to one word n0|n1<<16 per tuple (binary full trees: n2 = trees - n0 - n1)", None: ""}[wire_fmt]) + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if use_dist_saved else ""),
+            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((({"u16": " + pack to u16 cells", "u16x2": ", counted straight into one word n0|n1<<16 per tuple (binary full trees: n2 = trees - n0 - n1; no table write, no pack pass)", None: ""}[wire_fmt]) + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if use_dist_saved else ""),
             "collective": reduce_mode,
             "collective_input_bytes_per_rank": send_words * 4 if use_dist_saved else None,
             "parity_reduced_tuple_sums_ok": reduced_ok,

@@ -76,6 +76,11 @@ enum {
 /* OR-ed into `algo`: bracket the kernels of this call with HIP events for qs_last_count_ms (costs ~5 % of a
  * 0.25 ms batch, so it is off unless asked for) */
 #define QS_COUNT_TIMED 0x200u
+/* OR-ed into `algo`: count into the wire buffer given to qs_wire_attach instead of the table -- one 32-bit word
+ * n0 | n1 << 16 per tuple, the two-cell format of qs_table_pack16x2, without the table write and the pack pass.
+ * Only for batches of binary trees that hold all taxa (anything else: QS_ERR_STATE), gather algorithm, fewer than
+ * 65536 trees accumulated. QS_COUNT_OVERWRITE applies to the wire buffer. */
+#define QS_COUNT_WIRE16X2 0x400u
 
 /* qs_score flags */
 #define QS_SCORE_QP_WRAP32 0u   /* reference-compatible: QP sums kept mod 2^32 (QuartetScoreComputer.hpp:382) */
@@ -161,6 +166,8 @@ int qs_table_pack16(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
  * memory. A tuple that does not sum to the number of trees raises QS_ERR_STATE at the next qs_sync (use the
  * three-cell format then), a count >= 65536 QS_ERR_OVERFLOW. Asynchronous. */
 int qs_table_pack16x2(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+/* destination of QS_COUNT_WIRE16X2 (table_tuples 32-bit words in caller-owned device memory); NULL detaches */
+int qs_wire_attach(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
 int qs_unpack16x2(qs_ctx *ctx, const void *src_device, uint64_t n_tuples, uint32_t total_trees, void *dst_device);
 
 /* ---- counting (QuartetCounterLookup::countQuartets) ------------------------------------ */

@@ -13,13 +13,14 @@ QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEV
 QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER = 0, 1, 2
 QS_COUNT_OVERWRITE = 0x100
 QS_COUNT_TIMED = 0x200
+QS_COUNT_WIRE16X2 = 0x400
 QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
 QS_SCORE_CAND_SLOTS = 8
 
 # every symbol include/quartetscores_hip.h declares
 EXPORTS = [
     "qs_create", "qs_destroy", "qs_last_error", "qs_version", "qs_table_tuples", "qs_table_bytes", "qs_table_alloc",
-    "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
+    "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_wire_attach", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
 ]
@@ -79,6 +80,8 @@ def load():
     L.qs_table_pack16.argtypes = [vp, vp, u64]
     L.qs_table_pack16x2.restype = i32
     L.qs_table_pack16x2.argtypes = [vp, vp, u64]
+    L.qs_wire_attach.restype = i32
+    L.qs_wire_attach.argtypes = [vp, vp, u64]
     L.qs_unpack16x2.restype = i32
     L.qs_unpack16x2.argtypes = [vp, vp, u64, u32, vp]
     L.qs_table_device_ptr.restype = vp

@@ -32,6 +32,8 @@ struct qs_ctx {
     void *table = nullptr;
     bool table_owned = false;
     uint64_t trees_counted = 0;
+    uint32_t *wire_out = nullptr;   // qs_wire_attach: destination of QS_COUNT_WIRE16X2 (one word per tuple)
+    uint64_t wire_trees = 0;        // trees accumulated in it
     // geometry
     uint32_t *dprefix = nullptr, *cprefix = nullptr;
     uint32_t n_dblk = 0, total_tiles = 0;
@@ -239,6 +241,15 @@ extern "C" int qs_table_pack16(qs_ctx *c, void *dst_device, uint64_t dst_bytes) 
     return QS_OK;
 }
 
+extern "C" int qs_wire_attach(qs_ctx *c, void *dst_device, uint64_t dst_bytes) {
+    if (!c) return QS_ERR_ARG;
+    if (!dst_device) { c->wire_out = nullptr; c->wire_trees = 0; return QS_OK; }
+    if (dst_bytes < c->n_tuples * 4) return fail(c, QS_ERR_ARG, "qs_wire_attach: destination smaller than " + std::to_string(c->n_tuples * 4) + " bytes");
+    c->wire_out = (uint32_t *)dst_device;
+    c->wire_trees = 0;
+    return QS_OK;
+}
+
 extern "C" int qs_table_pack16x2(qs_ctx *c, void *dst_device, uint64_t dst_bytes) {
     if (!c || !c->table || !dst_device) return fail(c, QS_ERR_STATE, "qs_table_pack16x2: no table / NULL destination");
     if (c->count_bits != 32) return fail(c, QS_ERR_ARG, "qs_table_pack16x2: needs a 32-bit table");
@@ -367,8 +378,58 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     return QS_OK;
 }
 
+// QS_COUNT_WIRE16X2: count a binary_full batch straight into the attached wire buffer (one word per tuple)
+static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) {
+    const DeviceBatch &d = b->d;
+    if (!c->wire_out) return fail(c, QS_ERR_STATE, "QS_COUNT_WIRE16X2: no wire buffer (qs_wire_attach first)");
+    const bool overwrite = (algo & QS_COUNT_OVERWRITE) != 0;
+    const uint32_t base_algo = algo & 0xFFu;
+    if (base_algo != QS_ALGO_AUTO && base_algo != QS_ALGO_GATHER) return fail(c, QS_ERR_ARG, "QS_COUNT_WIRE16X2 needs the gather algorithm");
+    if (algo & QS_COUNT_TIMED) return fail(c, QS_ERR_ARG, "QS_COUNT_WIRE16X2 cannot be combined with QS_COUNT_TIMED");
+    QS_HIP(c, hipSetDevice(c->device));
+    if (d.n_trees == 0) {
+        if (overwrite) { QS_HIP(c, hipMemsetAsync(c->wire_out, 0, c->n_tuples * 4, c->stream)); c->wire_trees = 0; }
+        return QS_OK;
+    }
+    if (!(d.all_full && d.all_binary))
+        return fail(c, QS_ERR_STATE, "QS_COUNT_WIRE16X2: the batch is not made of binary trees that hold all taxa (count into the table and use qs_table_pack16)");
+    if ((overwrite ? 0 : c->wire_trees) + d.n_trees > 0xFFFFull)
+        return fail(c, QS_ERR_OVERFLOW, "QS_COUNT_WIRE16X2: more than 65535 trees do not fit 16-bit cells");
+    uint32_t depth_bits = 1;
+    while ((1u << depth_bits) <= d.max_depth) ++depth_bits;
+    if (depth_bits > 7) return fail(c, QS_ERR_UNSUPPORTED, "QS_COUNT_WIRE16X2: tree depth needs more than 7 bits; count into the table instead");
+    CountGeometry g;
+    g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo; g.n_dblk = c->n_dblk;
+    g.total_tiles = c->total_tiles3; g.dprefix = c->dprefix3; g.cprefix = c->cprefix3;
+    const uint32_t compact_nw = std::max(depth_bits, 4u);
+    const size_t chunk_bytes = (size_t)binom2(c->n) * compact_nw * 4;
+    const uint32_t n_chunks_total = (d.n_trees + 31) / 32;
+    const uint32_t chunks_per_slice = std::min<uint32_t>((uint32_t)std::max<size_t>(1, panel_slice_bytes(chunk_bytes) / chunk_bytes), n_chunks_total);
+    const size_t need = (size_t)chunks_per_slice * chunk_bytes;
+    if (need > c->panel_bytes) {
+        if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
+        if (hipMalloc(&c->panel, need) != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
+        c->panel_bytes = need;
+    }
+    for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
+        const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
+        const uint32_t t0 = ch0 * 32, nt = std::min(nch * 32, d.n_trees - t0);
+        DeviceBatch sub = d;
+        sub.leaf_off = d.leaf_off + t0;
+        sub.n_trees = nt;
+        QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, false, c->panel, nch, compact_nw));
+        QS_HIP(c, launch_count_bitslice3(c->stream, g, c->panel, (int)depth_bits, MODE_BINARY_FULL, nch, nt, nullptr, 32, c->dev_flags,
+                                         overwrite && ch0 == 0, c->wire_out));
+    }
+    c->variant = std::string("gather/binary_full/bitslice_b") + std::to_string(std::max(depth_bits, 4u)) + "x2/wire_u16x2";
+    c->wire_trees = (overwrite ? 0 : c->wire_trees) + d.n_trees;
+    c->last_timed = false;
+    return QS_OK;
+}
+
 extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo) {
     if (!c || !b) return fail(c, QS_ERR_ARG, "qs_count_batch: NULL argument");
+    if (algo & QS_COUNT_WIRE16X2) return count_batch_wire(c, b, algo);
     if (!c->table) return fail(c, QS_ERR_STATE, "qs_count_batch: no table (qs_table_alloc / qs_table_attach first)");
     const DeviceBatch &d = b->d;
     QS_HIP(c, hipSetDevice(c->device));
@@ -452,7 +513,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 CountGeometry g3 = g;
                 if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
                 else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
-                QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+                QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0, nullptr));
             }
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
         }

@@ -832,7 +832,7 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
                                                                         const uint32_t *__restrict__ cprefix,
                                                                         CT *__restrict__ table,
                                                                         uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
-                                                                        uint32_t xcd_remap) {
+                                                                        uint32_t xcd_remap, uint32_t *__restrict__ wire) {
     constexpr bool BIN = MODE == MODE_BINARY_FULL, PART = MODE == MODE_PARTIAL;
     constexpr int NB = B + 1;
     constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
@@ -1055,6 +1055,30 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     // 64-bit products and divisions are done once per wave instead of once per slot
     uint64_t bd4 = binom4(d0), bd3 = binom3(d0), bd2 = binom2(d0);
     const uint64_t rcb = binom3(c) - rank_lo;
+    if (BIN && wire) {
+        // Wire output (qs_count_batch with QS_COUNT_WIRE16X2; binary_full batches only): instead of the [rank][3]
+        // table the kernel writes ONE word n0 | n1 << 16 per tuple -- the two-cell format the multi-GPU collective
+        // moves (n2 = trees - n0 - n1 is restored by qs_unpack16x2). No table write, no pack kernel.
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            const uint32_t d = d0 + j;
+            const uint64_t base = bd4 + rcb;
+            bd4 += bd3; bd3 += bd2; bd2 += d;
+            if (d < d1 && d > c) {
+                if (v1) {
+                    uint32_t w = x0[j] | (x1[j] << 16);
+                    if (!overwrite) w += wire[base + pi1];      // carry-free: the host keeps the totals below 2^16
+                    wire[base + pi1] = w;
+                }
+                if (v2) {
+                    uint32_t w = y0[j] | (y1[j] << 16);
+                    if (!overwrite) w += wire[base + pi2];
+                    wire[base + pi2] = w;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < kDB; ++j) {
         const uint32_t d = d0 + j;
@@ -1081,14 +1105,14 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
 
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
-                                  bool overwrite) {
+                                  bool overwrite, uint32_t *wire) {
     if (g.total_tiles == 0 || n_groups == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
 #define QS_BS3(BB, MM, CT)                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 1u : 0u)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 1u : 0u, wire)
 #define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
         if (depth_bits <= 4) QS_BS3(4, MM, CT);                                                                     \

@@ -55,7 +55,7 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
                                  uint32_t compact_nw); // words per panel element: planes (>= 4) [+ presence word]
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
-                                  bool overwrite);
+                                  bool overwrite, uint32_t *wire); // wire != NULL (binary_full only): one word n0 | n1 << 16 per tuple instead of the table
 uint32_t bitslice3_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of count_bitslice3_kernel
 hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
                                 uint64_t rank_lo, void *table, int count_bits);

@@ -184,17 +184,27 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
     ctx = engine.Context(ref.n_taxa, 32, device=dev.index or 0, stream=stream.cuda_stream)
     t_chunk, words = scatter_layout(ctx.table_tuples, world, wire)
     send = torch.zeros(world * words, dtype=torch.int32, device=dev)
-    if wire == "u32":
-        ctx.table_attach(send)                     # counted in place, padded to world chunks
+    if wire == "u16x2":
+        # counted straight into the wire words (QS_COUNT_WIRE16X2): no table, no pack pass; the library refuses
+        # batches that are not binary with all taxa
+        ctx.wire_attach(send)
+        if local_batch.n_trees:
+            hb = ctx.batch_upload(local_batch, with_nodes=False)
+            try:
+                ctx.count_batch(hb, engine.QS_ALGO_GATHER | engine.QS_COUNT_WIRE16X2)
+                ctx.sync()
+            finally:
+                ctx.batch_free(hb)
     else:
-        table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
-        ctx.table_attach(table)
-    if local_batch.n_trees:
-        ctx.count_trees(local_batch, algo)
-    if wire == "u16":
-        ctx.table_pack16(send)
-    elif wire == "u16x2":
-        ctx.table_pack16x2(send)
+        if wire == "u32":
+            ctx.table_attach(send)                 # counted in place, padded to world chunks
+        else:
+            table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
+            ctx.table_attach(table)
+        if local_batch.n_trees:
+            ctx.count_trees(local_batch, algo)
+        if wire == "u16":
+            ctx.table_pack16(send)
     recv = torch.zeros(words, dtype=torch.int32, device=dev)
     reduce_scatter_table(send, recv, group)
     rank_lo, n_owned = scatter_owned(ctx.table_tuples, world, rank, wire)

@@ -18,7 +18,7 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 
 from . import _lib, flatten, newick
-from ._lib import (QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_COUNT_OVERWRITE, QS_COUNT_TIMED, QS_SCORE_QP_EXACT64,  # noqa: F401
+from ._lib import (QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_COUNT_OVERWRITE, QS_COUNT_TIMED, QS_COUNT_WIRE16X2, QS_SCORE_QP_EXACT64,  # noqa: F401
                    QS_SCORE_QP_WRAP32)
 
 
@@ -85,6 +85,14 @@ class Context:
     def table_pack16(self, tensor):
         """u32 table -> u16 table in `tensor` (torch CUDA tensor, >= ceil(cells/2)*4 bytes); asynchronous."""
         self._chk(self.L.qs_table_pack16(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
+
+    def wire_attach(self, tensor):
+        """Destination of count_batch(..., QS_COUNT_WIRE16X2): table_tuples int32 words (torch CUDA tensor; None detaches)."""
+        if tensor is None:
+            self._chk(self.L.qs_wire_attach(self.h, None, 0))
+        else:
+            self._chk(self.L.qs_wire_attach(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
+        self._wire = tensor
 
     def table_pack16x2(self, tensor):
         """u32 table -> one word n0 | n1 << 16 per tuple (batches of binary trees holding all taxa); asynchronous."""

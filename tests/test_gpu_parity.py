@@ -761,3 +761,54 @@ def test_large_batch_validation_runs_on_several_host_threads(eng):
     with pytest.raises(eng.QSError) as ei:
         ctx.count_trees(bad)
     assert "tree 2500" in str(ei.value)
+
+
+def test_counting_straight_into_the_wire_format(eng, monkeypatch):
+    """QS_COUNT_WIRE16X2: the count kernel writes one word n0 | n1 << 16 per tuple into the attached buffer: equal to
+    qs_table_pack16x2 of the table the normal path builds, also over several panel slices, accumulated over two
+    calls, and with overwrite; refused for batches that are not binary with all taxa."""
+    import torch
+    n, m = 37, 150
+    ref_nw, trees = make_case(n, m, 141)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    ctx.count_trees(batch)
+    nq = ctx.table_tuples
+    want = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    ctx.table_pack16x2(want)
+    ctx.sync()
+    W = eng.QS_ALGO_GATHER | eng.QS_COUNT_WIRE16X2
+
+    def wire_count(parts, overwrite_first=False, slice_bytes=None):
+        if slice_bytes:
+            monkeypatch.setenv("QS_PANEL_SLICE_BYTES", str(slice_bytes))
+        c2 = eng.Context(n, 32)                      # no table at all
+        words = torch.full((nq,), 0x7F7F7F7F, dtype=torch.int32, device="cuda") if overwrite_first else torch.zeros(nq, dtype=torch.int32, device="cuda")
+        c2.wire_attach(words)
+        for k, (lo, hi) in enumerate(parts):
+            hb = c2.batch_upload(batch.slice(lo, hi), with_nodes=False)
+            c2.count_batch(hb, W | (eng.QS_COUNT_OVERWRITE if (overwrite_first and k == 0) else 0))
+            c2.sync()
+            c2.batch_free(hb)
+        if slice_bytes:
+            monkeypatch.delenv("QS_PANEL_SLICE_BYTES")
+        assert "wire_u16x2" in c2.last_count_variant()
+        return words
+
+    assert torch.equal(wire_count([(0, m)]), want)
+    assert torch.equal(wire_count([(0, 64), (64, m)]), want)                       # accumulation over calls
+    assert torch.equal(wire_count([(0, m)], overwrite_first=True), want)           # stale contents discarded
+    assert torch.equal(wire_count([(0, m)], slice_bytes=40000), want)              # several panel slices per call
+    # refused: multifurcating trees; missing wire buffer
+    c3 = eng.Context(n, 32)
+    c3.wire_attach(torch.zeros(nq, dtype=torch.int32, device="cuda"))
+    hb = c3.batch_upload(flatten.flatten_eval_trees(synth.tree_set(n, 20, 142, collapse=0.3), ref.name_to_id), with_nodes=False)
+    with pytest.raises(eng.QSError) as ei:
+        c3.count_batch(hb, W)
+    assert ei.value.code == -4
+    c3.wire_attach(None)
+    hb2 = c3.batch_upload(batch.slice(0, 10), with_nodes=False)
+    with pytest.raises(eng.QSError):
+        c3.count_batch(hb2, W)
