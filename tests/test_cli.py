@@ -110,6 +110,53 @@ def test_native_ingest_binding_matches_python_host(tmp_path):
         native_ingest.ingest(str(r), str(tmp_path / "missing.nwk"))
 
 
+def test_native_ingest_on_decorated_newick(tmp_path):
+    """Randomly decorated input (branch lengths, comments -- also with ';' and quotes inside --, quoted labels, blank
+    lines, line breaks inside a tree, a last tree without ';'): the allocation-free C++ parser, its memchr tree
+    splitter and the Python host agree on every array."""
+    import random
+    import re
+    import numpy as np
+    from quartetscores_amd import flatten, native_ingest, synth
+    rng = random.Random(4242)
+    n = 17
+    ref_nw = synth.reference_tree(n, 25)
+    ref = flatten.flatten_reference(ref_nw)
+    plain = synth.tree_set(n, 120, 26, collapse=0.2, dropout=0.15) + synth.tree_set(n, 30, 27, rooted=True)
+
+    def decorate(t):
+        out = []
+        for tok in re.split(r"([(),;])", t):
+            if re.fullmatch(r"t\d+", tok or ""):
+                if rng.random() < 0.3:
+                    tok = "'" + tok + "'"
+                if rng.random() < 0.5:
+                    tok += ":%g" % rng.uniform(0, 2)
+                if rng.random() < 0.2:
+                    tok += rng.choice(["[c]", "[x;y]", "[it's]", "[&&NHX:S=a]"])
+            elif tok == ")" and rng.random() < 0.3:
+                tok = ")" + rng.choice(["", "n1", "'inner node'"]) + (":%g" % rng.uniform(0, 1) if rng.random() < 0.5 else "")
+            elif tok == "," and rng.random() < 0.1:
+                tok = ",\n  "
+            out.append(tok or "")
+        return "".join(out)
+
+    trees = [decorate(t) for t in plain]
+    text = "\n\n".join(trees)
+    text = text.rstrip()
+    assert text.endswith(";")
+    text = text[:-1] + "\n"          # the last tree lacks its ';'
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_text(text)
+    want = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    for th in (1, 4):
+        got, total = native_ingest.ingest(str(r), str(e), 0, native_ingest.ALL, th)
+        assert total == len(trees) == got.n_trees
+        for f in ("leaf_off", "leaf_ids", "adj_depth", "node_off", "rng_off", "ranges"):
+            assert np.array_equal(getattr(got, f), getattr(want, f)), f
+
+
 def test_cli_fails_loudly_without_gpu(d1_files, tmp_path):
     import torch
     if torch.cuda.is_available():
