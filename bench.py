@@ -1,27 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- quartets counted per second on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (N = 1): BASELINE.json configs[1] = 128 taxa, 1000 random evaluation trees, uint32
-C(128,4)x3 count table (~1.07e7 quartets), seeded synthetic trees (quartetscores_amd/synth.py).
-A step = one pass of the hot path over the batch of 1000 trees that is already resident in
-HBM: clear the table, build the pair-depth panel, run the count kernel; for N > 1 every rank
-counts its own 1000 trees (weak scaling: trees shard across GPUs) and the step ends with the
-RCCL all-reduce of the count table (BASELINE.json north_star). Exactly K steps are timed
-between barrier + torch.cuda.synchronize() on both sides; value = quartets counted by all
-ranks / max-over-ranks time.
+Workloads (BASELINE.json `configs`; seeded synthetic trees from csrc/host/synth.hpp):
+    --config 1   configs[1]: 128 taxa x 1 000 trees, u32 table (128 MB)
+    --config 2   configs[2]: 512 taxa x 10 000 trees, u32 table (34 GB)            <- default at N = 1
+    --config 3   configs[3]: 256 taxa x 100 000 trees SPLIT over the N ranks, u32 table per rank (2.1 GB) + one RCCL
+                 collective on the table per step                                   <- default at N > 1 (strong scaling)
+    --config 4   configs[4]: 1024 taxa x 5 000 trees, u16 table sharded by the largest taxon id over max(N, 8) shards;
+                 every rank counts all trees into its shard(s), no table collective
+    --taxa/--trees/--count-bits override the sizes (the workload label then says "custom").
 
-roofline: the dominant kernel is the count kernel. achieved = algorithmic bytes per launch
-(8 B per (tree, quartet) = one read + one write of a u32 counter) / its
-average launch duration measured with HIP events on the launch stream (qs_last_count_ms).
-cpu_baseline: the oracle (CPU restatement of the reference, kind "port") timed on this host
-on a bounded prefix of the same trees; reported, never the target.
+A step = one pass of the hot path over the rank's batch of trees, which is already resident in HBM: build the
+pair-depth panel and run the count kernel slice by slice (first slice stores, the others accumulate), then for N > 1
+the collective on the table. Exactly K steps are timed between barrier + torch.cuda.synchronize() on both sides;
+value = quartet-tree units counted by all ranks / max-over-ranks time.
+
+roofline: the dominant kernel is the count kernel. The gather formulation keeps every counter in a
+register and writes each table cell once per panel slice, so it is bound by VALU issue, not by HBM:
+    achieved = ALGORITHMIC vector lane-operations per launch (the minimal compare chain of the bit-sliced four-point
+               test, (2(B+1)+2)/32 per tree x quartet for binary trees with B depth bits) / the kernel's average
+               launch duration, measured live with HIP events on the launch stream (qs_last_count_ms);
+    peak     = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles
+               per SIMD = the 157.3 TFLOP/s fp32 vector peak / 2 flops).
+`issued` (instructions really issued, from rocprofv3 SQ_INSTS_VALU) and `traffic` (HBM bytes from FETCH_SIZE /
+WRITE_SIZE) come from the PMC summary under profiles/ ONLY when that summary was collected for this workload, this
+kernel variant and this kernel source (sha256 of qs_count.hip); otherwise they are null. `hbm_algorithmic_ratio` is
+SURVEY.md 8(d)'s figure: the RMW bytes of the reference formulation (2 x sizeof(counter) per unit) / kernel time /
+8 TB/s -- a speed-up over a perfect scatter implementation, not a fraction.
+cpu_baseline: the oracle (CPU restatement of the reference, kind "port") timed in a child process on this host on a
+bounded sample of the same trees at -t 1 and at the best thread count; reported, never the target.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,40 +45,189 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 T lane-ops/s: one wave64 VALU op per 2 cycles per SIMD-32
+
+CONFIGS = {
+    1: dict(taxa=128, trees=1000, bits=32, shards=1, split=False),
+    2: dict(taxa=512, trees=10000, bits=32, shards=1, split=False),
+    3: dict(taxa=256, trees=100000, bits=32, shards=1, split=True),
+    4: dict(taxa=1024, trees=5000, bits=16, shards=8, split=False),
+}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)   # 0.2 ms each; short runs measure a cold, down-clocked GPU (20 steps: 0.233 ms, 1000: 0.192)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0, help="0 = automatic: about 6 s of timed steps, between 5 and 500")
+    ap.add_argument("--warmup", type=int, default=-1, help="-1 = automatic: 2 for steps >= 100 ms, else 20")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[k]; 0 = 2 at N=1, 3 at N>1")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed pre-conditioning before the warm-up steps (GPU clock ramp); 0 = off")
-    ap.add_argument("--taxa", type=int, default=128)
-    ap.add_argument("--trees", type=int, default=1000)
+    ap.add_argument("--taxa", type=int, default=0)
+    ap.add_argument("--trees", type=int, default=0, help="trees in total (split over the ranks when the config splits), else per rank")
+    ap.add_argument("--split-trees", type=int, default=-1, help="1: --trees are split over the ranks (strong scaling); 0: every rank counts --trees of its own")
     ap.add_argument("--algo", choices=["gather", "scatter"], default="gather")
-    ap.add_argument("--count-bits", type=int, default=32)
-    ap.add_argument("--cpu-baseline-trees", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--count-bits", type=int, default=0)
+    ap.add_argument("--cpu-budget-s", type=float, default=8.0, help="seconds of CPU counting per thread setting of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score", action="store_true")
-    ap.add_argument("--no-impl-check", action="store_true", help="skip the on-device comparison with the byte-SWAR implementation (slow at >= 1024 taxa; parameter sweeps)")
-    ap.add_argument("--distinct-trees", type=int, default=0,
-                    help="generate only this many distinct trees and tile them to --trees (large configs; same GPU work)")
+    ap.add_argument("--no-impl-check", action="store_true", help="skip the on-device comparison with the byte-SWAR implementation")
     ap.add_argument("--nni", action="store_true", help="evaluation trees = reference tree + Poisson(n/8) random NNIs (concentrated counts)")
-    ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees)")
-    ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees)")
+    ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees; numpy generator, small sizes)")
+    ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees; numpy generator, small sizes)")
     ap.add_argument("--reduce", choices=["scatter", "all"], default="scatter",
                     help="N>1: reduce-scatter (each rank keeps and scores a shard of the reduced table) or all-reduce")
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto",
-                    help="N>1: format of the table on the wire (auto: while world x trees < 65536, u16x2 for binary full trees, else u16)")
-    ap.add_argument("--table-shards", type=int, default=1,
-                    help="table-sharded mode (configs[4]): split the table by the largest taxon id into this many shards")
-    ap.add_argument("--shard-index", type=int, default=0, help="which shard this single-GPU run owns")
+                    help="N>1: format of the table on the wire (auto: while the total number of trees < 65536, u16x2 for binary full trees, else u16)")
+    ap.add_argument("--table-shards", type=int, default=0, help="table-sharded mode: split the table by the largest taxon id into this many shards")
+    ap.add_argument("--shard-index", type=int, default=-1, help="table-sharded mode on fewer ranks than shards: which shard this rank owns (default: its rank)")
+    ap.add_argument("--slice-bytes", type=int, default=0, help="qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES); 0 = automatic")
+    ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cpu_baseline leg: runs in a CHILD process (no GPU, only the oracle) so that a host-memory problem with the
+# reference's n^4 table can never take the bench line down with it.
+# ---------------------------------------------------------------------------------------------------------------
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    mem = 0
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    mem = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/memory.max") as f:
+            v = f.read().strip()
+            if v != "max":
+                mem = min(mem, int(v)) if mem else int(v)
+    except (OSError, ValueError):
+        pass
+    return {"host_cpus": os.cpu_count() or 1, "cpu_model": model, "mem_available_bytes": mem}
+
+
+def cpu_child(spec_path):
+    """Times the oracle on a bounded sample; prints one JSON object."""
+    from oracle_api import Oracle
+    with open(spec_path) as f:
+        spec = json.load(f)
+    with open(spec["trees_path"]) as f:
+        text = f.read()
+    n, m, nq, budget = spec["n"], spec["m"], spec["nq"], spec["budget_s"]
+    info = host_info()
+    ncpu = info["host_cpus"]
+    cint_bits = 8 if m < 256 else 16 if m < 65536 else 32               # QuartetScores.cpp:115-147
+    fast_bytes = n ** 4 * cint_bits // 8
+    # QuartetScoreComputer.hpp:739: the n^4 table unless it exceeds 0.9 x RAM (here: half of what is available, so
+    # that the leg stays a guest on the box)
+    savemem = bool(info["mem_available_bytes"] and fast_bytes > 0.5 * info["mem_available_bytes"])
+    o = Oracle(spec["ref"])
+    out = dict(info)
+    out.update({"kind": "port", "unit": "quartets/s", "table": "compact C(n,4)x3 (--savemem)" if savemem else "fast n^4",
+                "cint_bits": cint_bits, "runs": []})
+
+    def run(th, secs):
+        o.set_budget(secs, True)
+        t = o.count(text, savemem=savemem, cint_bits=cint_bits, nthreads=th)
+        inc = o.increments_done()
+        # the reference increments twice per displayed quartet (SURVEY.md 3.2 iii): units = increments / 2
+        r = {"threads": th, "seconds": t, "units": inc / 2.0, "trees_equiv": inc / (2.0 * nq), "value": inc / 2.0 / t}
+        out["runs"].append(r)
+        return r
+
+    r1 = run(1, budget)
+    best = r1
+    if not savemem:                                                     # savemem + threads is racy in the reference (SURVEY Q2)
+        for th in sorted({min(t, ncpu) for t in (8, 32, 128, ncpu)} - {1}):
+            r = run(th, max(2.0, budget / 2))
+            if r["value"] > best["value"]:
+                best = r
+    out["t1"] = {"value": r1["value"], "cores": 1}
+    out["value"], out["cores"] = best["value"], best["threads"]
+    out["sample"] = (f"first {best['trees_equiv']:.2f} trees' worth of increments of the {m}-tree batch (n={n}), "
+                     f"{out['table']} table of u{cint_bits} cells, OpenMP -t {best['threads']}, {best['seconds']:.1f} s; "
+                     f"-t 1: {r1['value']:.3g} quartets/s over {r1['seconds']:.1f} s")
+    o.close()
+    print(json.dumps(out))
+
+
+def run_cpu_baseline(ref_nw, eval_text, n, m, nq, budget_s):
+    import tempfile
+    d = tempfile.mkdtemp(prefix="qsbench_")
+    tp, sp = os.path.join(d, "trees.nwk"), os.path.join(d, "spec.json")
+    # the child needs only as many trees as it can count in its budget: cap the sample text
+    lines = eval_text.split(b"\n") if isinstance(eval_text, bytes) else eval_text.encode().split(b"\n")
+    keep = lines[: max(8, min(len(lines), 4096))]
+    with open(tp, "wb") as f:
+        f.write(b"\n".join(keep))
+    with open(sp, "w") as f:
+        json.dump({"trees_path": tp, "ref": ref_nw, "n": n, "m": m, "nq": nq, "budget_s": budget_s}, f)
+    env = dict(os.environ)
+    env.pop("HIP_VISIBLE_DEVICES", None)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", sp], capture_output=True, text=True,
+                           timeout=60 + 12 * budget_s, env=env)
+        last = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not last:
+            return {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed (rc {p.returncode}): {p.stderr[-300:]}"}
+        return json.loads(last[-1])
+    except Exception as e:  # the baseline is reported, never required for the metric
+        return {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    finally:
+        for q in (tp, sp):
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for fn in ("qs_count.hip", "qs_common.hpp", "qs_internal.hpp"):
+        with open(os.path.join(ROOT, "quartetscores_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_for(workload_key, variant):
+    """PMC figures of the count kernel for exactly this workload / variant / kernel source, or None."""
+    import glob
+    sha = kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for ent in doc.get("entries", []):
+            if ent.get("workload_key") == workload_key and ent.get("variant") == variant and ent.get("kernel_source_sha") == sha:
+                ent = dict(ent)
+                ent["file"] = os.path.relpath(path, ROOT)
+                return ent
+    return None
 
 
 def main():
     args = parse_args()
+    if args.cpu_child:
+        return cpu_child(args.cpu_child)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -70,15 +235,54 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if torch.cuda.device_count() == 0:   # (counting devices does not initialise the GPU)
         raise SystemExit("bench.py needs a GPU (no CPU fallback in quartetscores_amd)")
+    use_dist = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
+
+    from quartetscores_amd import _lib, distributed, engine, flatten, native_ingest, ranks, synth
+
+    # ---- workload -----------------------------------------------------------------------------------------
+    cfg_no = args.config or (2 if world == 1 else 3)
+    cfg = dict(CONFIGS[cfg_no])
+    custom = bool(args.taxa or args.trees or args.count_bits or args.table_shards or args.split_trees >= 0)
+    n = args.taxa or cfg["taxa"]
+    m_total = args.trees or cfg["trees"]
+    count_bits = args.count_bits or cfg["bits"]
+    shards = args.table_shards or cfg["shards"]
+    split = bool(args.split_trees) if args.split_trees >= 0 else cfg["split"]
+    if shards > 1:
+        shards = max(shards, world)
+    t_lo, t_hi = distributed.shard_range(m_total, world, rank) if split else (0, m_total)
+    m = t_hi - t_lo                                                      # trees THIS rank counts per step
+    # seeded inputs: seed = 1000 * config + tree-set id. Split configs: ONE set of m_total trees, rank
+    # r takes trees [t_lo, t_hi); otherwise rank r counts its own set r (tree t of a set depends only on (seed, t)).
+    seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or shards > 1) else rank)
+    binary_full_trees = not (args.collapse or args.dropout)
+    t_gen = time.perf_counter()
+    ref_nw = native_ingest.synth_trees(n, 1, seed_ref).decode().strip()
+    ref = flatten.flatten_reference(ref_nw)
+    if binary_full_trees:
+        all_text = native_ingest.synth_trees(n, m_total if split else m, seed_set, kind="nni" if args.nni else "random",
+                                             ref_text=ref_nw if args.nni else None)
+        batch, _ = native_ingest.ingest_text(ref_nw, all_text, t_lo if split else 0, t_hi if split else m, want_ranges=(args.algo == "scatter"))
+        sample_text = all_text
+    else:                                   # multifurcating / partial trees: the numpy generator (small sizes only)
+        trees = synth.tree_set(n, m, seed_set, collapse=args.collapse, dropout=args.dropout)
+        batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+        sample_text = "\n".join(trees).encode()
+    assert batch.n_trees == m
+    gen_s = time.perf_counter() - t_gen
+
+    # cpu_baseline leg first, in a child process, BEFORE this process touches the GPU (N = 1 only)
+    cpu_baseline = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu_baseline = run_cpu_baseline(ref_nw, sample_text, n, m, ranks.n_quartets(n), args.cpu_budget_s)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # QS_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all-reduce) even with one rank
-    use_dist = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
+    # QS_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, collective) even with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -86,72 +290,55 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from quartetscores_amd import engine, flatten, ranks, synth
-
-    n, m = args.taxa, args.trees
-    nq = ranks.n_quartets(n)
-    # seeded inputs: seed = 1000 * config + tree set id; rank r counts tree set r
-    ref_nw = synth.reference_tree(n, 2000)
-    distinct = min(args.distinct_trees or m, m)
-    if args.nni:   # SURVEY 8(d), second distribution: the reference tree + Poisson(n/8) random NNIs -> concentrated counts
-        assert not (args.collapse or args.dropout), "--nni trees are binary and full"
-        trees = synth.nni_tree_set(ref_nw, distinct, 2001 + rank)
-    else:
-        trees = synth.tree_set(n, distinct, 2001 + rank, collapse=args.collapse, dropout=args.dropout)
-    ref = flatten.flatten_reference(ref_nw)
-    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
-    if distinct < m:  # tile the flattened trees (needs every tree to hold all n taxa -> fixed stride)
-        assert args.dropout == 0.0, "--distinct-trees needs full trees"
-        reps = -(-m // distinct)
-        ids = np.tile(batch.leaf_ids, reps)[: m * n]
-        dep = np.tile(batch.adj_depth, reps)[: m * n]
-        batch = flatten.TreeBatch(m, np.arange(m + 1, dtype=np.uint32) * n, ids, dep, np.zeros(m + 1, dtype=np.uint32),
-                                  np.zeros(1, dtype=np.uint32), np.zeros(0, dtype=np.uint16))
-
     stream = torch.cuda.current_stream(dev)
     d_lo, d_hi = 0, n
-    if args.table_shards > 1:
-        from quartetscores_amd import distributed
-        d_lo, d_hi = distributed.shard_of_largest_id(n, args.table_shards, args.shard_index)
-        nq = ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo)  # quartets this GPU owns
-    ctx = engine.Context(n, args.count_bits, device=local_rank, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
+    shard_index = None
+    if shards > 1:
+        shard_index = args.shard_index if args.shard_index >= 0 else rank
+        d_lo, d_hi = distributed.shard_of_largest_id(n, shards, shard_index)
+    nq_all = ranks.n_quartets(n)
+    nq = ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo)                 # quartets this rank's table holds
+    ctx = engine.Context(n, count_bits, device=local_rank, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
+    if args.slice_bytes:
+        ctx.set_tuning(_lib.QS_TUNE_PANEL_SLICE_BYTES, args.slice_bytes)
     n_words = (ctx.table_bytes + 3) // 4
-    table = torch.zeros(n_words, dtype=torch.int32, device=dev)  # u16 tables all-reduce as packed words
+    table = torch.zeros(n_words, dtype=torch.int32, device=dev)          # u16 tables reduce as packed words
     ctx.table_attach(table)
-    # N > 1: the per-rank tables are combined with ONE collective per step, asynchronous on RCCL's stream, so that
-    # it overlaps the counting of the next step (two buffers in flight).
-    #   --reduce scatter (default): reduce-scatter; rank r ends with tuples [r*T, (r+1)*T) of the reduced table and
-    #       scores that shard (distributed.score_sharded): half the bytes per link of an all-reduce.
-    #   --reduce all: all-reduce, every rank ends with the full table (the wording of BASELINE.json north_star).
-    # Wire format: while the summed counts stay below 2^16 (world x m trees; the reference's own CINT rule,
-    # QuartetScores.cpp:115-147) the u32 table is packed to u16 cells first (qs_table_pack16): half the bytes again.
-    from quartetscores_amd import distributed
+
+    # N > 1, tree-sharded: the per-rank tables are combined with ONE collective per step, asynchronous on RCCL's
+    # stream, so that it overlaps the counting of the next step (two buffers in flight).
+    #   --reduce scatter (default): rank r ends with tuples [r*T, (r+1)*T) of the reduced table and scores that shard
+    #       (distributed.score_sharded): half the bytes per link of an all-reduce.
+    #   --reduce all: every rank ends with the full table (the wording of BASELINE.json north_star).
+    # Wire format: while the summed counts stay below 2^16 (the reference's own CINT rule, QuartetScores.cpp:115-147)
+    # the u32 table travels as u16 cells, binary full batches as ONE word per tuple; else the table's own cells.
+    collective = use_dist and shards == 1
+    total_trees_reduced = m_total if split else m * world
     tables = [table]
-    binary_full_trees = not (args.collapse or args.dropout)
-    wire_fmt = None                       # None: the table's own cells travel; "u16" / "u16x2": packed first
-    if use_dist and args.count_bits == 32 and args.algo == "gather":
-        small = world * m < 65536
+    wire_fmt = None
+    if collective and count_bits == 32 and args.algo == "gather":
+        small = total_trees_reduced < 65536
         if args.wire == "u16x2" or (args.wire == "auto" and small and binary_full_trees):
-            wire_fmt = "u16x2"            # one word n0 | n1 << 16 per tuple (n2 = world * m - n0 - n1)
+            wire_fmt = "u16x2"
         elif args.wire == "u16" or (args.wire == "auto" and small):
             wire_fmt = "u16"
     wire16 = wire_fmt is not None
     if wire16:
-        assert world * m < 65536, "--wire u16 / u16x2 need world x trees < 65536"
+        assert total_trees_reduced < 65536, "--wire u16 / u16x2 need fewer than 65536 trees in total"
     assert wire_fmt != "u16x2" or binary_full_trees, "--wire u16x2 needs binary trees that hold all taxa"
-    reduce_mode = args.reduce if use_dist else None
-    bits_wire = 16 if wire16 else args.count_bits
-    layout_wire = wire_fmt or args.count_bits
-    chunk_words = 0
+    reduce_mode = args.reduce if collective else None
+    bits_wire = 16 if wire16 else count_bits
+    layout_wire = wire_fmt or count_bits
+    send_words = 0
     if reduce_mode == "scatter":
         _, chunk_words = distributed.scatter_layout(ctx.table_tuples, world, layout_wire)
         send_words = world * chunk_words
         recv = [torch.zeros(chunk_words, dtype=torch.int32, device=dev) for _ in range(2)]
-    else:
+    elif reduce_mode == "all":
         send_words = ctx.table_tuples if wire_fmt == "u16x2" else distributed.table_words(ctx.table_tuples, bits_wire)
     if wire16:
         wire = [torch.zeros(send_words, dtype=torch.int32, device=dev) for _ in range(2)]
-    elif use_dist:
+    elif collective:
         table = torch.zeros(max(n_words, send_words), dtype=torch.int32, device=dev)  # padded to world chunks
         ctx.table_attach(table)
         tables = [table]
@@ -160,29 +347,28 @@ def main():
     pending = [None] * 2
     step_no = [0]
     last_buf = [0]
-    hb = ctx.batch_upload(batch, with_nodes=(args.algo == "scatter"))  # inputs resident in HBM before the timed region
+    coll_ms = []
+    hb = ctx.batch_upload(batch, with_nodes=(args.algo == "scatter"))    # inputs resident in HBM before the timed region
     algo = engine.QS_ALGO_GATHER if args.algo == "gather" else engine.QS_ALGO_SCATTER
-
-    # gather: QS_COUNT_OVERWRITE = "clear + count" in one pass (the kernel stores instead of accumulating)
+    # gather: QS_COUNT_OVERWRITE = "clear + count" in one pass (the first slice stores instead of accumulating)
     step_algo = algo | engine.QS_COUNT_OVERWRITE if args.algo == "gather" else algo
 
     def step(timed=False):
         i = step_no[0] % (2 if wire16 else len(tables))
         step_no[0] += 1
-        if pending[i] is not None:       # the all-reduce that last used this buffer must be done
+        if pending[i] is not None:       # the collective that last used this buffer must be done
             pending[i].wait()
             pending[i] = None
         if len(tables) > 1:
             ctx.table_attach(tables[i])
         if args.algo != "gather":
             ctx.table_clear()
-        if use_dist and wire_fmt == "u16x2" and not timed:
-            # counted straight into the wire words: no table write, no pack pass (QS_COUNT_WIRE16X2)
-            ctx.wire_attach(wire[i])
+        if collective and wire_fmt == "u16x2" and not timed:
+            ctx.wire_attach(wire[i])     # counted straight into the wire words: no table write, no pack pass
             ctx.count_batch(hb, step_algo | engine.QS_COUNT_WIRE16X2)
         else:
             ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
-        if use_dist:
+        if collective:
             if wire_fmt == "u16x2" and not timed:
                 src = wire[i]
             elif wire16:
@@ -209,71 +395,91 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Untimed pre-conditioning, then the W warm-up steps the contract asks for: a 0.2 ms step is far shorter than the
-    # GPU's clock ramp, so a run of 20 steps from idle measures 0.233 ms per step where 1000 steps measure 0.192 ms.
+    # first step: lazy initialisation (code objects, RCCL communicator); second step: its duration sizes the run
+    step()
+    drain()
+    torch.cuda.synchronize(dev)
+    t_pre = time.perf_counter()
+    step()
+    drain()
+    torch.cuda.synchronize(dev)
+    one_ms = max((time.perf_counter() - t_pre) * 1e3, 1e-3)
+    if use_dist:
+        tt = torch.tensor([one_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        one_ms = float(tt.item())
+    steps = args.steps or int(min(500, max(5, 6000.0 / one_ms)))
+    warmup = args.warmup if args.warmup >= 0 else (2 if one_ms >= 100 else 20)
+    # untimed pre-conditioning (a sub-millisecond step is far shorter than the GPU's clock ramp: 20 steps of configs[1]
+    # from idle measure 0.233 ms per step where 1000 steps measure 0.192 ms)
     if args.prewarm_ms > 0:
-        step()                     # first step: lazy initialisation (code objects, RCCL communicator), not representative
-        drain()
-        torch.cuda.synchronize(dev)
-        t_pre = time.perf_counter()
-        step()
-        drain()
-        torch.cuda.synchronize(dev)
-        one_ms = max((time.perf_counter() - t_pre) * 1e3, 1e-3)
-        n_pre = int(min(1024, max(0, args.prewarm_ms / one_ms - 1)))
-        if use_dist:      # the same number of steps (= collectives) on every rank
-            npt = torch.tensor([n_pre], device=dev)
-            dist.all_reduce(npt, op=dist.ReduceOp.MAX)
-            n_pre = int(npt.item())
-        for _ in range(n_pre):
+        for _ in range(int(min(1024, max(0, args.prewarm_ms / one_ms - 1)))):
             step()
         drain()
         torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     ctx.sync()
     fence()
-    kern_ms = []
-    # HIP events on the launch stream: two bracket the whole timed region (GPU time per step); the kernels of
-    # the LAST timed step are bracketed individually inside qs_count_batch (QS_COUNT_TIMED; bracketing every
-    # launch costs ~5 % of a 0.25 ms step, and reading events inside the loop would synchronise).
+    # HIP events on the launch stream bracket the whole timed region (GPU time per step); the kernels of the LAST
+    # timed step are bracketed individually inside qs_count_batch (QS_COUNT_TIMED: an event after every launch)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for k_ in range(args.steps):
-        step(timed=(k_ == args.steps - 1))
+    for k_ in range(steps):
+        step(timed=(k_ == steps - 1))
     ev1.record(stream)
     fence()
     t1 = time.perf_counter()
     ctx.sync()
     elapsed = t1 - t0
-    region_gpu_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
-    last_step_ms = ctx.last_count_ms() if args.steps > 0 else None
+    region_gpu_ms = ev0.elapsed_time(ev1) / max(steps, 1)
+    last_step_ms = ctx.last_count_ms() if steps > 0 else None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     drain()
-    # gate on the REDUCED table of the last timed step: every tuple sums to world x m (binary, full trees)
+    # collective alone (N > 1): the same buffers, nothing else on the GPU, a few repetitions
+    coll_alone_ms = None
+    if collective and steps > 0:
+        src = (wire if wire16 else tables)[last_buf[0]]
+        fence()
+        c0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            if reduce_mode == "scatter":
+                dist.reduce_scatter_tensor(recv[last_buf[0]], src[:send_words], op=dist.ReduceOp.SUM)
+            else:
+                dist.all_reduce(src, op=dist.ReduceOp.SUM)
+        fence()
+        coll_alone_ms = (time.perf_counter() - c0) * 1e3 / reps
+        step()                              # restore a freshly counted + reduced buffer for the gates below
+        drain()
+        torch.cuda.synchronize(dev)
+    # gate on the REDUCED table of the last step: every tuple sums to the total number of trees (binary, full trees)
     reduced_ok = None
     shard16 = None
-    if use_dist and args.steps > 0:
+    if collective and steps > 0:
         if reduce_mode == "scatter":
             own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
             red, n_red = recv[last_buf[0]], own_n
         else:
             red, n_red = (wire if wire16 else tables)[last_buf[0]], nq
-        if wire_fmt == "u16x2":        # restore the third cell of the reduced tuples (a u16 table again)
+        if wire_fmt == "u16x2":            # restore the third cell of the reduced tuples (a u16 table again)
             shard16 = torch.zeros(distributed.table_words(max(n_red, 1), 16), dtype=torch.int32, device=dev)
-            ctx.unpack16x2(red, n_red, world * m, shard16)
-            ctx.sync()                 # raises if a reduced tuple exceeds world x m
+            ctx.unpack16x2(red, n_red, total_trees_reduced, shard16)
+            ctx.sync()                     # raises if a reduced tuple exceeds the total
             w_ = red[:n_red]
-            ok_local = bool((((w_ & 0xFFFF) + ((w_ >> 16) & 0xFFFF)) <= world * m).all().item())
+            ok_local = bool((((w_ & 0xFFFF) + ((w_ >> 16) & 0xFFFF)) <= total_trees_reduced).all().item())
         elif binary_full_trees:
-            cells = red[: n_red * 3] if bits_wire == 32 else (red.view(torch.int16)[: n_red * 3].to(torch.int32) & 0xFFFF)
-            ok_local = bool((cells.view(n_red, 3).sum(dim=1) == world * m).all().item())
-            del cells
+            ok_local = True
+            for c0_ in range(0, n_red, 1 << 26):   # chunked: the shard can be GBs
+                c1_ = min(n_red, c0_ + (1 << 26))
+                cells = red[c0_ * 3: c1_ * 3] if bits_wire == 32 else (red.view(torch.int16)[c0_ * 3: c1_ * 3].to(torch.int32) & 0xFFFF)
+                ok_local = ok_local and bool((cells.view(c1_ - c0_, 3).sum(dim=1) == total_trees_reduced).all().item())
+                del cells
         else:
             ok_local = None
         if ok_local is not None:
@@ -284,45 +490,70 @@ def main():
         ctx.table_attach(table)
         tables[:] = [table]
         pending[:] = [None]
-    use_dist_saved, use_dist = use_dist, False
-    # per-kernel durations: an extra, untimed pass that reads the HIP events after every launch
-    for _ in range(max(3, min(args.steps, 10))):
+    collective_saved, collective = collective, False
+    # per-kernel durations: an extra, untimed pass that reads the HIP events after every step
+    kern = []
+    for _ in range(3 if one_ms >= 100 else max(3, min(steps, 10))):
         step(timed=True)
-        kern_ms.append(ctx.last_count_ms())
-    panel_ms = float(np.mean([k[0] for k in kern_ms]))
-    count_ms = float(np.mean([k[1] for k in kern_ms]))
+        kern.append(ctx.last_count_ms() + (ctx.last_count_launches(),))
+    panel_ms = float(np.mean([k[0] for k in kern]))
+    count_ms = float(np.mean([k[1] for k in kern]))                      # all count-kernel launches of one step
+    launches = int(kern[-1][3]) or 1
     variant = ctx.last_count_variant()
 
-    # parity gate run with every measurement: table of this rank's trees, checked on rank 0
+    # ---- parity gates run with every measurement -------------------------------------------------------------
     step()
     ctx.sync()
-    if args.collapse or args.dropout:
-        parity = None                  # tuples sum to m only when every tree resolves every quartet
-    elif args.count_bits == 32:        # checked on the device
-        parity = bool((table[: nq * 3].view(nq, 3).sum(dim=1) == m).all().item())
-    else:
-        parity = bool((ctx.table_download().sum(axis=1, dtype=np.uint64) == m).all())
-    # stronger gate (the tuple sums are trivially m in the binary_full variant): the table must equal the one
-    # the independent byte-SWAR implementation of the same count produces, bit for bit, on the device
+    parity = None
+    if binary_full_trees:              # tuples sum to m only when every tree resolves every quartet
+        parity = True
+        t16 = table.view(torch.int16)
+        for c0_ in range(0, nq, 1 << 26):
+            c1_ = min(nq, c0_ + (1 << 26))
+            cells = table[c0_ * 3: c1_ * 3] if count_bits == 32 else (t16[c0_ * 3: c1_ * 3].to(torch.int32) & 0xFFFF)
+            parity = parity and bool((cells.view(c1_ - c0_, 3).sum(dim=1) == m).all().item())
+            del cells
+    # stronger gate (the tuple sums are trivially m in the binary_full variant): the table must equal the one the
+    # independent byte-SWAR implementation of the same count produces, bit for bit, on the device
     impl_match = None
-    if args.algo == "gather" and "bitslice" in variant and not args.no_impl_check:
+    free_b, _tot = torch.cuda.mem_get_info(dev)
+    if args.algo == "gather" and "bitslice" in variant and not args.no_impl_check and free_b > table.numel() * 4 + (4 << 30):
         mine = table.clone()
-        os.environ["QS_GATHER_IMPL"] = "swar"
+        ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
         step()
         ctx.sync()
-        del os.environ["QS_GATHER_IMPL"]
-        impl_match = bool(torch.equal(mine, table))
         swar_variant = ctx.last_count_variant()
-        step()  # restore the default implementation's table (and variant string)
+        impl_match = bool(torch.equal(mine, table))
+        ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_AUTO)
+        step()                          # restore the default implementation's table (and variant string)
         ctx.sync()
-        assert "swar" not in ctx.last_count_variant() and "depth_u" in swar_variant
+        assert "bitslice" in ctx.last_count_variant() and "depth_u" in swar_variant
         del mine
+    # third gate, independent of every kernel: random quartets of this rank's table against the split-based brute
+    # force (tests/bruteforce.py) on a short prefix of this rank's trees, counted into a scratch context
+    lookup_ok = None
+    if rank == 0 and binary_full_trees:
+        import bruteforce
+        k_trees = min(m, 48)
+        rng = np.random.default_rng(12345)
+        qs_ = np.sort(np.stack([rng.choice(d_hi, size=4, replace=False) for _ in range(20000)]), axis=1)
+        qs_ = qs_[qs_[:, 3] >= d_lo].astype(np.uint16)
+        prefix = sample_text.split(b"\n")[(t_lo if split else 0):][:k_trees]
+        ctx_s = engine.Context(n, 16, device=local_rank, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)   # scratch u16 table
+        if torch.cuda.mem_get_info(dev)[0] > ctx_s.table_bytes + (4 << 30):
+            ctx_s.table_alloc()
+            ctx_s.count_trees(batch.slice(0, k_trees), algo)
+            got = ctx_s.lookup(qs_)
+            # lookup ids = the reference tree's leaf order (ref.names): the brute force works on the same ids
+            want = bruteforce.quartet_counts_for([ln.decode() for ln in prefix], ref.names, qs_.astype(np.int64))
+            lookup_ok = bool((got == want).all())
+        ctx_s.close()
 
     score_ms = None
-    if not args.no_score and args.count_bits == 32 and args.table_shards == 1:
+    if not args.no_score and shards == 1:
         torch.cuda.synchronize(dev)
         s0 = time.perf_counter()
-        if reduce_mode == "scatter" and args.steps > 0:
+        if reduce_mode == "scatter" and steps > 0:
             # every rank scores the shard it received (view), accumulators combined with small collectives
             own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
             ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
@@ -337,118 +568,107 @@ def main():
         dist.destroy_process_group()
         return
 
-    units_per_step = m * nq * world
-    value = units_per_step * args.steps / elapsed
-    bytes_per_unit = 2 * (args.count_bits // 8)
-    achieved = (m * nq * bytes_per_unit) / (count_ms * 1e-3) / 1e9
+    # ---- the JSON line ----------------------------------------------------------------------------------------
+    # units of one step over all ranks: tree-sharded = every rank's trees x all quartets; table-sharded = all trees x
+    # the quartets of every rank's shard (with one shard per rank that is all quartets)
+    if shards > 1:
+        owned = [ranks.n_quartets(hi_) - ranks.n_quartets(lo_) for lo_, hi_ in
+                 (distributed.shard_of_largest_id(n, shards, (args.shard_index if args.shard_index >= 0 else r)) for r in range(world))]
+        units_per_step = m * sum(owned)
+    else:
+        units_per_step = (m_total if split else m * world) * nq_all
+    value = units_per_step * steps / elapsed
+    bytes_per_unit = 2 * (count_bits // 8)
+    units_per_launch = m * nq / launches
+    launch_ms = count_ms / launches
+    depth_bits = None
+    if "bitslice_b" in variant:
+        depth_bits = int(variant.split("bitslice_b")[1][0])
+    mode = "binary_full" if "binary_full" in variant else "general_full" if "general_full" in variant else "partial" if "partial" in variant else None
+    # minimal VALU lane-operations per (tree, quartet) of the bit-sliced four-point test, DESIGN.md 3.1:
+    #   binary_full: [L > R] and [L < R] over B+1 planes (2 v_bitop3 per plane) + 2 v_bcnt per 32 trees
+    #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 combine + 1 v_bcnt; partial: + 3 presence masks
+    ops32 = None
+    if depth_bits:
+        ops32 = {"binary_full": 2 * (depth_bits + 1) + 2, "general_full": 3 * (depth_bits + 1) + 4, "partial": 3 * (depth_bits + 1) + 8}[mode]
+    wl_name = (f"configs[{cfg_no}]" if not custom else "custom")
+    workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}")
     out = {
         "metric": "quartets counted/sec",
         "value": value,
         "unit": "quartets/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if split else "weak",
         "vs_baseline": None,
-        "dtype": "u32" if args.count_bits == 32 else "u16",
+        "dtype": "u32" if count_bits == 32 else "u16",
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: {n} taxa, {m} random eval trees per GPU, uint{args.count_bits} C(n,4)x3 table "
-                        f"({nq} quartets), seeds 2000/2001+rank" + (", NNI-perturbed copies of the reference tree" if args.nni else ""),
-            "distinct_trees": distinct,
-            "table_shard": [d_lo, d_hi] if args.table_shards > 1 else None,
+            "workload": f"{wl_name}: {n} taxa, {m_total} eval trees" + (f" split over {world} rank(s) ({m} on rank 0)" if split else f" per rank" if world > 1 else "")
+                        + f", uint{count_bits} C(n,4)x3 table ({nq_all} quartets" + (f"; table-sharded by the largest id into {shards}, this rank d in [{d_lo},{d_hi}) = {nq} quartets" if shards > 1 else "") + ")"
+                        + (", reference tree + Poisson(n/8) NNIs" if args.nni else ", uniformly random binary trees" if binary_full_trees else f", collapse {args.collapse} dropout {args.dropout}")
+                        + f", seeds {seed_ref}/{seed_set}" + ("+rank" if not (split or shards > 1) and world > 1 else ""),
+            "workload_key": workload_key,
+            "table_shard": [d_lo, d_hi] if shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel (overwrite mode: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((({"u16": " + pack to u16 cells", "u16x2": ", counted straight into one word n0|n1<<16 per tuple (binary full trees: n2 = trees - n0 - n1; no table write, no pack pass)", None: ""}[wire_fmt]) + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if use_dist_saved else ""),
+            "step": ("pair-depth panel build + count kernel per panel slice (first slice stores: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((({"u16": " + pack to u16 cells", "u16x2": ", counted straight into one word n0|n1<<16 per tuple (binary full trees: n2 = trees - n0 - n1; no table write, no pack pass)", None: ""}[wire_fmt]) + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if collective_saved else ""),
             "collective": reduce_mode,
-            "collective_input_bytes_per_rank": send_words * 4 if use_dist_saved else None,
+            "collective_input_bytes_per_rank": send_words * 4 if collective_saved else None,
+            "collective_alone_ms": coll_alone_ms,
             "parity_reduced_tuple_sums_ok": reduced_ok,
             "parity_tuple_sums_ok": parity,
             "parity_bitslice_equals_swar_impl": impl_match,
-            "panel_kernel_ms": panel_ms,
-            "count_kernel_ms": count_ms,
+            "parity_lookup_equals_bruteforce": lookup_ok,
+            "panel_kernels_ms_per_step": panel_ms,
+            "count_kernels_ms_per_step": count_ms,
+            "count_launches_per_step": launches,
             "prewarm_ms": args.prewarm_ms,
-            "count_kernel_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
+            "count_kernels_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
             "score_phase_ms": score_ms,
-        },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "kernel": ("count_bitslice3_kernel" if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel",
-            "algorithmic_bytes_per_launch": m * nq * bytes_per_unit,
-            "avg_launch_ms": count_ms,
-            "note": "achieved = algorithmic RMW bytes of the reference formulation (8 B per tree x quartet) / kernel time; "
-                    "the gather kernel keeps counters in registers and writes each cell once, so real HBM traffic is far "
-                    "below this and frac can exceed 1 (its own limit is VALU issue, see DESIGN.md)",
+            "input_generation_s": gen_s,
         },
     }
+    kname = ("count_bitslice3_kernel" if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel"
+    hbm_ratio = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    table_bytes = ctx.table_bytes
+    panel_bytes = ((m + 31) // 32) * (n * (n - 1) // 2) * (max(depth_bits or 4, 4) * 4) if depth_bits else None
+    if ops32:
+        achieved = units_per_launch * ops32 / 32.0 / (launch_ms * 1e-3) / 1e12
+        roof = {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLOPS,
+                "algorithmic_ops_per_unit": ops32 / 32.0,
+                "algorithmic_ops_note": f"{ops32} wave-instructions per (quartet, 32 trees): the minimal chain of the bit-sliced four-point test at {depth_bits} depth bits, mode {mode} (DESIGN.md 3.1); instructions really issued: see `issued`"}
+    else:                                   # scatter / SWAR paths: priced against HBM with SURVEY 8(d)'s bytes
+        achieved = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    roof.update({"traffic": None, "kernel": kname, "units_per_launch": units_per_launch, "avg_launch_ms": launch_ms,
+                 "launches_per_step": launches, "hbm_algorithmic_ratio": hbm_ratio,
+                 "hbm_algorithmic_note": "SURVEY 8(d): 2 x sizeof(counter) per (tree, quartet) / kernel time / 8 TB/s = speed-up over a perfect "
+                                         "scatter implementation of the reference's RMW loop; not a fraction (the gather kernel does not perform those RMWs)",
+                 "hbm_model_bytes_per_step": (table_bytes * (2 * launches - 1) + 2 * panel_bytes) if panel_bytes else None,
+                 "hbm_model_note": "gather formulation's own minimum per step: table written once by the first slice and read+written by each later one, panel written and read once",
+                 "issued": None})
+    pmc = pmc_for(workload_key, variant)
+    if pmc:
+        roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+        if pmc.get("valu_insts_per_launch"):
+            per_simd = pmc["valu_insts_per_launch"] / 1024.0
+            roof["issued"] = {"valu_wave_insts_per_launch": pmc["valu_insts_per_launch"],
+                              "cycles_per_valu_inst_at_2.4GHz": launch_ms * 1e-3 * 2.4e9 / per_simd,
+                              "frac_of_2_cycle_issue": 2.0 * per_simd / (launch_ms * 1e-3 * 2.4e9),
+                              "minimal_share": units_per_launch * ops32 / 32.0 / 64.0 / pmc["valu_insts_per_launch"] if ops32 else None}
+        roof["pmc_source"] = {k_: pmc.get(k_) for k_ in ("file", "collected", "kernel_source_sha", "fetch_size_kb", "write_size_kb", "l2_hit")}
+    else:
+        roof["pmc_source"] = f"no PMC summary under profiles/ matches workload_key={workload_key}, variant={variant}, kernel source {kernel_source_sha()}"
+    out["roofline"] = roof
 
-    # HBM traffic of the dominant kernel: bench.py cannot collect PMC counters itself; when the committed
-    # rocprofv3 summary of THIS kernel variant on THIS default workload exists, report it (per launch;
-    # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is, KB -> bytes)
-    try:
-        if (n, m, args.count_bits, args.table_shards) == (128, 1000, 32, 1) and ("binary_full" in variant or args.algo != "gather"):
-            with open(os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")) as f:
-                pmc = json.load(f)["counters"]
-            kname = out["roofline"]["kernel"]
-            fk = [v for k_, v in pmc["FETCH_SIZE"].items() if kname in k_]
-            wk = [v for k_, v in pmc["WRITE_SIZE"].items() if kname in k_]
-            vi = [v for k_, v in pmc.get("SQ_INSTS_VALU", {}).items() if kname in k_]
-            if vi and "bitslice" in variant:
-                # the kernel's real bound: VALU issue. Time the launch would take if the 1024 SIMDs issued its VALU
-                # instructions at the rate tools/valu_rates.hip measures for this mix at 4 waves/SIMD
-                # (85 % v_bitop3-class at 3.13 cycles, 15 % v_bcnt at 5.6 cycles, of a 2.4 GHz clock)
-                ns_per_inst = (0.85 * 3.13 + 0.15 * 5.6) / 2.4
-                bound_ms = vi[0]["avg_per_dispatch"] / 1024.0 * ns_per_inst * 1e-6
-                out["roofline"]["valu_issue"] = {"wave_insts_per_launch": vi[0]["avg_per_dispatch"], "bound_ms": bound_ms,
-                                                 "frac": bound_ms / count_ms,
-                                                 "source": "profiles/r01_final_pmc_summary.json (SQ_INSTS_VALU) x profiles/r01_valu_rates_pass2.txt"}
-            if fk and wk:
-                out["roofline"]["traffic"] = (2 * fk[0]["avg_per_dispatch"] + wk[0]["avg_per_dispatch"]) * 1024
-                out["roofline"]["traffic_source"] = ("profiles/r01_final_pmc_summary.json (tools/pmc_collect.sh: rocprofv3 --pmc, "
-                                                     "separate FETCH_SIZE / WRITE_SIZE passes; L2 miss traffic, most of it served by the Infinity Cache)")
-    except Exception:
-        pass
+    if cpu_baseline is not None:                     # reported at N=1 only
+        out["cpu_baseline"] = cpu_baseline
 
-    if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0 would stall the other ranks' exit)
-        try:
-            from oracle_api import Oracle
-            ncpu = os.cpu_count() or 1
-            o = Oracle(ref_nw)
-            # The reference's OpenMP loop runs INSIDE one tree over very unequal items
-            # (QuartetCounterLookup.hpp:223-228) and stops scaling early; calibrate the thread
-            # count on a few trees, then time a bounded sample (~10-20 s) at the best setting.
-            calib = max(2, min(8, m))
-            best_t, best_rate = 1, 0.0
-            for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
-                tcal = o.count("\n".join(trees[:calib]), savemem=False, cint_bits=16, nthreads=th)
-                if calib * nq / tcal > best_rate:
-                    best_t, best_rate = th, calib * nq / tcal
-            cores = best_t
-            mp = args.cpu_baseline_trees or max(8, int(best_rate * 12.0 / nq))
-            mp = min(mp, distinct)
-            tc = o.count("\n".join(trees[:mp]), savemem=False, nthreads=cores)
-            cpu_val = mp * nq / tc
-            # the same prefix counted on the GPU must give the same table (bit-exact gate)
-            ctx.table_clear()
-            ctx.count_trees(batch.slice(0, mp), algo)
-            same = bool((ctx.table_download().astype(np.uint64) == o.counts()).all())
-            out["cpu_baseline"] = {
-                "value": cpu_val, "unit": "quartets/s", "cores": cores, "kind": "port",
-                "sample": f"first {mp} of the {m} trees, n={n}, reference fast (n^4) table, OpenMP -t {cores}, {tc:.2f} s",
-                "gpu_table_bit_exact_on_sample": same,
-            }
-            o.close()
-        except Exception as e:  # the baseline is reported, never required for the metric
-            out["cpu_baseline"] = {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-
-    if use_dist_saved:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     # the JSON line must be the LAST line on stdout: RCCL prints a version banner through C stdio, which is

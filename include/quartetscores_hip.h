@@ -140,6 +140,17 @@ int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uint32_t flags
               uint32_t d_lo, uint32_t d_hi);
 void qs_destroy(qs_ctx *ctx);
 const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the last failed qs_create */
+
+/* Tuning knobs of one context (A/B measurements and tests; the defaults are what the product uses). They replace
+ * the reference's compile-time switches of this path (USE_STXXL, quartet_lookup_table.hpp:3; table mode by RAM,
+ * QuartetScoreComputer.hpp:739). */
+#define QS_TUNE_PANEL_SLICE_BYTES 1u /* upper bound of the pair-depth panel of one sub-batch; 0 = automatic */
+#define QS_TUNE_GATHER_IMPL 2u       /* QS_IMPL_AUTO | QS_IMPL_SWAR (byte-SWAR kernel) | QS_IMPL_BITSLICE */
+#define QS_TUNE_PANEL_KERNEL 3u      /* 0 = automatic, 1 = always the general bit-plane panel builder */
+#define QS_IMPL_AUTO 0u
+#define QS_IMPL_SWAR 1u
+#define QS_IMPL_BITSLICE 2u
+int qs_set_tuning(qs_ctx *ctx, uint32_t key, uint64_t value);
 const char *qs_version(void);
 
 /* ---- count table (QuartetLookupTable) ------------------------------------------------- */
@@ -246,9 +257,11 @@ int qs_raw_qic(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, ui
 /* ---- measurement hooks ------------------------------------------------------------------ */
 
 /* Device time in milliseconds of the most recent qs_count_batch that carried QS_COUNT_TIMED, split by kernel
- * (HIP events on the context's stream): [0] pair-panel build, [1] count kernel, [2] total. QS_ERR_STATE if the
- * most recent call was not timed. */
+ * (HIP events on the context's stream after every launch): [0] pair-panel builds, [1] count kernels (summed over
+ * the panel slices of the batch), [2] whole call. QS_ERR_STATE if the most recent call was not timed.
+ * qs_last_count_launches: how many count-kernel launches [1] covers (0 if the call was not timed). */
 int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
+int qs_last_count_launches(const qs_ctx *ctx);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);
 

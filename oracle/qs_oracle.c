@@ -356,6 +356,13 @@ typedef struct {
     int have_qp;
     int qp_exact64; /* 0 = reference-compatible 32-bit wrap (QSC:382), 1 = 64-bit sums */
     double t_count, t_score;
+    /* bench.py's cpu_baseline leg only: stop counting after budget_s seconds (checked per inner node) and
+     * report how many table increments were done; 0 = off (every parity test) */
+    double budget_s, budget_t0;
+    volatile int budget_hit;
+    unsigned long long incr_done;
+    int prefault;
+    int table_savemem, table_bits;
     char err[256];
 } Oracle;
 
@@ -417,6 +424,10 @@ const char *qso_taxon_name(void *h, int lookup_id) {
     return s ? s : "";
 }
 double qso_time_count(void *h) { return ((Oracle *)h)->t_count; }
+/* bench.py cpu_baseline: bound the next qso_count calls to `seconds` of counting (0 = unbounded, the default) and
+ * optionally touch the table's pages before the clock starts. A bounded count leaves an INCOMPLETE table. */
+void qso_set_budget(void *h, double seconds, int prefault) { Oracle *o = (Oracle *)h; o->budget_s = seconds; o->prefault = prefault; }
+unsigned long long qso_increments_done(void *h) { return ((Oracle *)h)->incr_done; }
 double qso_time_score(void *h) { return ((Oracle *)h)->t_score; }
 
 /* QuartetScores.cpp:115-147: CINT width follows m */
@@ -501,6 +512,11 @@ static void update_three_links(Oracle *o, const Tree *t, int l1, int l2, int l3,
     subtree_leaf_indices(t, l2, lteli, &a2, &b2);
     subtree_leaf_indices(t, l3, lteli, &a3, &b3);
     size_t s1 = a1 % L, e1 = b1 % L, s2 = a2 % L, e2 = b2 % L, s3 = a3 % L, e3 = b3 % L;
+    if (o->budget_s > 0) { /* increments of the three calls below: C(|S1|,2)|S2||S3| + ... (trip count of QCL:73-105) */
+        const unsigned long long n1 = (e1 + L - s1) % L, n2 = (e2 + L - s2) % L, n3 = (e3 + L - s3) % L;
+        const unsigned long long inc = n1 * (n1 - (n1 > 0)) / 2 * n2 * n3 + n2 * (n2 - (n2 > 0)) / 2 * n1 * n3 + n3 * (n3 - (n3 > 0)) / 2 * n1 * n2;
+        __atomic_fetch_add(&o->incr_done, inc, __ATOMIC_RELAXED);
+    }
     update_three_clades(o, s1, e1, s2, e2, s3, e3, etl, L, mult);
     update_three_clades(o, s2, e2, s1, e1, s3, e3, etl, L, mult);
     update_three_clades(o, s3, e3, s1, e1, s2, e2, etl, L, mult);
@@ -566,8 +582,13 @@ int qso_count(void *h, const char *eval_text, size_t len, int savemem, int cint_
     o->savemem = savemem;
     o->bits = cint_bits ? cint_bits : qso_cint_bits_for_m(m);
     o->mask = o->bits == 64 ? ~0ull : ((1ull << o->bits) - 1);
-    free(o->fast); free(o->compact); o->fast = o->compact = NULL;
-    if (savemem) {
+    /* bounded timing runs (qso_set_budget) re-use a table of the same shape: re-allocating and re-touching a
+     * 137 GB fast table per thread setting would dominate the leg; its contents are not read afterwards */
+    const int reuse = o->budget_s > 0 && o->table_savemem == savemem && o->table_bits == o->bits && (savemem ? o->compact != NULL : o->fast != NULL);
+    if (!reuse) { free(o->fast); free(o->compact); o->fast = o->compact = NULL; }
+    o->table_savemem = savemem; o->table_bits = o->bits;
+    if (reuse) {
+    } else if (savemem) {
         o->compact = calloc((size_t)(o->nq * 3 + 1), cint_bytes(o->bits));
         if (!o->compact) { snprintf(o->err, sizeof o->err, "Insufficient memory!"); return -3; }
     } else {
@@ -585,10 +606,23 @@ int qso_count(void *h, const char *eval_text, size_t len, int savemem, int cint_
 #else
     (void)nthreads;
 #endif
+    if (o->prefault && !reuse) { /* touch every page of the table outside the timed region (a bounded sample would otherwise time page faults) */
+        unsigned char *base = (unsigned char *)(savemem ? o->compact : o->fast);
+        const size_t bytes = (savemem ? (size_t)(o->nq * 3 + 1) : (size_t)n * n * n * n + 1) * cint_bytes(o->bits);
+#ifdef _OPENMP
+        omp_set_num_threads(omp_get_num_procs()); /* first touch with every core, whatever -t the timed run uses */
+#endif
+#pragma omp parallel for schedule(static)
+        for (long long pg = 0; pg < (long long)((bytes + 4095) / 4096); pg++) base[(size_t)pg * 4096] = 0;
+#ifdef _OPENMP
+        if (nthreads > 0) omp_set_num_threads(savemem ? 1 : nthreads);
+#endif
+    }
     double t0 = now_s();
+    o->budget_t0 = t0; o->budget_hit = 0; o->incr_done = 0;
     size_t pos = 0, ti = 0;
     int rc = 0;
-    while (pos < len && rc == 0) {
+    while (pos < len && rc == 0 && !o->budget_hit) {
         size_t used = 0; char e[256] = {0};
         Tree *t = tree_parse(eval_text + pos, len - pos, &used, e, sizeof e);
         pos += used;
@@ -615,6 +649,7 @@ int qso_count(void *h, const char *eval_text, size_t len, int savemem, int cint_
             /* QCL:223-228 */
 #pragma omp parallel for schedule(dynamic)
             for (int j = 0; j < nEval; j++) {
+                if (o->budget_s > 0 && (o->budget_hit || now_s() - o->budget_t0 > o->budget_s)) { o->budget_hit = 1; continue; }
                 if (!node_is_leaf(t, j)) update_quartets(o, t, j, etl, (size_t)L, lteli, k);
             }
         }

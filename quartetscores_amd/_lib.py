@@ -16,6 +16,8 @@ QS_COUNT_TIMED = 0x200
 QS_COUNT_WIRE16X2 = 0x400
 QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
 QS_SCORE_CAND_SLOTS = 8
+QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL = 1, 2, 3
+QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares
 EXPORTS = [
@@ -23,6 +25,7 @@ EXPORTS = [
     "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_wire_attach", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
+    "qs_set_tuning", "qs_last_count_launches",
 ]
 
 
@@ -122,6 +125,10 @@ def load():
     L.qs_raw_qic.argtypes = [vp, C.POINTER(RefTreeC), u64, u64, vp, vp]
     L.qs_last_count_ms.restype = i32
     L.qs_last_count_ms.argtypes = [vp, C.POINTER(C.c_float * 3)]
+    L.qs_set_tuning.restype = i32
+    L.qs_set_tuning.argtypes = [vp, u32, u64]
+    L.qs_last_count_launches.restype = i32
+    L.qs_last_count_launches.argtypes = [vp]
     L.qs_last_count_variant.restype = C.c_char_p
     L.qs_last_count_variant.argtypes = [vp]
     _lib = L

@@ -45,9 +45,14 @@ struct qs_ctx {
     void *panel = nullptr;
     size_t panel_bytes = 0;
     uint32_t *dev_flags = nullptr; // [0] counter overflow, [1] score flags, [3] two-cell wire format: tuple sum mismatch
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> evs;   // QS_COUNT_TIMED: evs[0] = start, then one event after every kernel launch
+    std::vector<uint8_t> ev_kind;  // per event after evs[0]: 0 = panel build, 1 = count kernel
+    uint32_t ev_used = 0;
     bool last_timed = false;
-    bool ev_valid = false;
+    // qs_set_tuning
+    uint64_t tune_slice_bytes = 0; // 0 = automatic
+    uint32_t tune_gather_impl = 0; // QS_IMPL_*
+    uint32_t tune_panel_kernel = 0;
     double *dev_logk = nullptr, *dev_invk = nullptr; // tables of the device QIC (qs_score.hip), tbl_n entries each
     uint32_t tbl_n = 0;
     // scoring view (qs_score_set_view): tuples [view_rank_lo, view_rank_lo + view_n) in caller-owned device memory
@@ -59,14 +64,24 @@ struct qs_ctx {
 };
 
 static std::string g_create_err;
-// upper bound of the pair-depth panel of one sub-batch (QS_PANEL_SLICE_BYTES overrides it: tests)
-// Panel bytes per sub-batch: QS_PANEL_SLICE_BYTES, else 96 MiB (Infinity-Cache resident) but at least 32 tree groups
-// (a tile's fixed cost -- decode, first staging, table read-modify-write -- needs that many 32-tree steps to
-// amortise; at 1024 taxa a group is 10 MB and 96 MiB would leave 7 steps per launch), capped at 384 MiB.
-static size_t panel_slice_bytes(size_t group_bytes) {
-    const char *e = getenv("QS_PANEL_SLICE_BYTES");
-    if (e && *e) { long long v = atoll(e); if (v > 0) return (size_t)v; }
+// Panel bytes per sub-batch: qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES), else 96 MiB (Infinity-Cache resident) but at
+// least 32 tree groups (a tile's fixed cost -- decode, first staging, table read-modify-write -- needs that many
+// 32-tree steps to amortise; at 1024 taxa a group is 10 MB and 96 MiB would leave 7 steps per launch), capped at 384 MiB.
+static size_t panel_slice_bytes(const qs_ctx *c, size_t group_bytes) {
+    if (c->tune_slice_bytes) return (size_t)c->tune_slice_bytes;
     return std::min<size_t>(std::max<size_t>(96ull << 20, 32 * group_bytes), 384ull << 20);
+}
+
+// QS_COUNT_TIMED: an event after every kernel launch of the call (created on demand, re-used by later calls)
+static hipError_t mark(qs_ctx *c, int kind) {
+    if (c->ev_used == c->evs.size()) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return rc;
+        c->evs.push_back(e); c->ev_kind.push_back(0);
+    }
+    c->ev_kind[c->ev_used] = (uint8_t)kind;
+    return hipEventRecord(c->evs[c->ev_used++], c->stream);
 }
 
 static int fail(qs_ctx *c, int code, const std::string &msg) {
@@ -85,6 +100,20 @@ static int fail(qs_ctx *c, int code, const std::string &msg) {
 extern "C" const char *qs_version(void) { return "quartetscores_amd 0.1.0 (gfx950)"; }
 
 extern "C" const char *qs_last_error(const qs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
+    if (!c) return QS_ERR_ARG;
+    switch (key) {
+        case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
+        case QS_TUNE_GATHER_IMPL:
+            if (value > QS_IMPL_BITSLICE) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_GATHER_IMPL takes QS_IMPL_AUTO / _SWAR / _BITSLICE");
+            c->tune_gather_impl = (uint32_t)value; return QS_OK;
+        case QS_TUNE_PANEL_KERNEL:
+            if (value > 1) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_PANEL_KERNEL takes 0 (automatic) or 1 (general builder)");
+            c->tune_panel_kernel = (uint32_t)value; return QS_OK;
+        default: return fail(c, QS_ERR_ARG, "qs_set_tuning: unknown key");
+    }
+}
 
 extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uint32_t flags, int device, void *stream,
                          uint32_t d_lo, uint32_t d_hi) {
@@ -149,8 +178,6 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     }
     if (hipMalloc(&c->dev_flags, 16) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc flags");
     if (hipMemset(c->dev_flags, 0, 16) != hipSuccess) return cleanup(QS_ERR_HIP, "memset flags");
-    for (int i = 0; i < 3; ++i)
-        if (hipEventCreate(&c->ev[i]) != hipSuccess) return cleanup(QS_ERR_HIP, "hipEventCreate");
     *out = c;
     return QS_OK;
 }
@@ -168,7 +195,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->dprefix1t) (void)hipFree(c->dprefix1t);
     if (c->cprefix3) (void)hipFree(c->cprefix3);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
-    for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -404,7 +431,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     const uint32_t compact_nw = std::max(depth_bits, 4u);
     const size_t chunk_bytes = (size_t)binom2(c->n) * compact_nw * 4;
     const uint32_t n_chunks_total = (d.n_trees + 31) / 32;
-    const uint32_t chunks_per_slice = std::min<uint32_t>((uint32_t)std::max<size_t>(1, panel_slice_bytes(chunk_bytes) / chunk_bytes), n_chunks_total);
+    const uint32_t chunks_per_slice = std::min<uint32_t>((uint32_t)std::max<size_t>(1, panel_slice_bytes(c, chunk_bytes) / chunk_bytes), n_chunks_total);
     const size_t need = (size_t)chunks_per_slice * chunk_bytes;
     if (need > c->panel_bytes) {
         if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
@@ -417,7 +444,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
         DeviceBatch sub = d;
         sub.leaf_off = d.leaf_off + t0;
         sub.n_trees = nt;
-        QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, false, c->panel, nch, compact_nw));
+        QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, false, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
         QS_HIP(c, launch_count_bitslice3(c->stream, g, c->panel, (int)depth_bits, MODE_BINARY_FULL, nch, nt, nullptr, 32, c->dev_flags,
                                          overwrite && ch0 == 0, c->wire_out));
     }
@@ -449,23 +476,22 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     if (algo == QS_ALGO_AUTO) algo = QS_ALGO_GATHER;
     if (overwrite && algo != QS_ALGO_GATHER) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_COUNT_OVERWRITE needs the gather algorithm");
     if (overwrite) c->trees_counted = 0;
-    if (timed) QS_HIP(c, hipEventRecord(c->ev[0], c->stream));
+    c->ev_used = 0;
+    if (timed) QS_HIP(c, mark(c, 0));
     if (algo == QS_ALGO_GATHER) {
         int mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
         static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
         CountGeometry g;
         g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
         g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
-        hipEvent_t ev_panel_end = c->ev[1];
         // bits needed for the largest LCA depth
         uint32_t depth_bits = 1;
         while ((1u << depth_bits) <= d.max_depth) ++depth_bits;
-        const char *impl_env = getenv("QS_GATHER_IMPL"); // "swar" | "bitslice" (tests / A-B runs)
         const bool bits_ok = depth_bits <= (mode == MODE_PARTIAL ? 6u : 7u);
         bool use_bitslice = bits_ok;
-        if (impl_env && std::string(impl_env) == "swar") use_bitslice = false;
-        if (impl_env && std::string(impl_env) == "bitslice" && !bits_ok)
-            return fail(c, QS_ERR_UNSUPPORTED, "QS_GATHER_IMPL=bitslice: tree depth needs more than 7 (6 with missing taxa) bits");
+        if (c->tune_gather_impl == QS_IMPL_SWAR) use_bitslice = false;
+        if (c->tune_gather_impl == QS_IMPL_BITSLICE && !bits_ok)
+            return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 7 (6 with missing taxa) bits");
         // The panel of a sub-batch is kept at or below the slice size so that it stays resident in the
         // 256 MiB Infinity Cache while every wave streams through it; the price is one read-modify-write of
         // the table per sub-batch. Measured at 512 taxa x 10000 trees (819 MB of panel, 34 GB table):
@@ -490,7 +516,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             tpc = 16 / (bits / 8); elem_bytes = 16;
         }
         const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
-        uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes(use_bitslice ? chunk_bytes : 0) / chunk_bytes);
+        uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes(c, use_bitslice ? chunk_bytes : 0) / chunk_bytes);
         const uint32_t n_chunks_total = (d.n_trees + tpc - 1) / tpc;
         chunks_per_slice = std::min(chunks_per_slice, n_chunks_total);
         const size_t need = (size_t)chunks_per_slice * chunk_bytes;
@@ -506,9 +532,9 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             DeviceBatch sub = d;
             sub.leaf_off = d.leaf_off + t0; // offsets stay absolute into leaf_ids / adj_depth
             sub.n_trees = nt;
-            if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw));
+            if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
             else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
-            if (ch0 == 0 && timed) QS_HIP(c, hipEventRecord(ev_panel_end, c->stream));
+            if (timed) QS_HIP(c, mark(c, 0));
             if (use_bitslice) {
                 CountGeometry g3 = g;
                 if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
@@ -516,6 +542,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0, nullptr));
             }
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
+            if (timed) QS_HIP(c, mark(c, 1));
         }
         if (use_bitslice)
             c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (mode == MODE_BINARY_FULL ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
@@ -524,15 +551,13 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");
-        if (timed) QS_HIP(c, hipEventRecord(c->ev[1], c->stream));
         QS_HIP(c, launch_count_scatter(c->stream, d, c->n, c->d_lo, c->d_hi, c->rank_lo, c->table, (int)c->count_bits));
+        if (timed) QS_HIP(c, mark(c, 1));
         c->variant = std::string("scatter/atomic/count_u") + std::to_string(c->count_bits);
     } else {
         return fail(c, QS_ERR_ARG, "qs_count_batch: unknown algo");
     }
-    if (timed) QS_HIP(c, hipEventRecord(c->ev[2], c->stream));
     c->last_timed = timed;
-    c->ev_valid = true;
     c->trees_counted += d.n_trees;
     return QS_OK;
 }
@@ -565,12 +590,23 @@ extern "C" int qs_count_trees(qs_ctx *c, const qs_tree_batch *batch, uint32_t al
 }
 
 extern "C" int qs_last_count_ms(qs_ctx *c, float out_ms[3]) {
-    if (!c || !c->ev_valid || !c->last_timed) return fail(c, QS_ERR_STATE, "qs_last_count_ms: the last qs_count_batch did not carry QS_COUNT_TIMED");
-    QS_HIP(c, hipEventSynchronize(c->ev[2]));
-    QS_HIP(c, hipEventElapsedTime(&out_ms[0], c->ev[0], c->ev[1]));
-    QS_HIP(c, hipEventElapsedTime(&out_ms[1], c->ev[1], c->ev[2]));
-    QS_HIP(c, hipEventElapsedTime(&out_ms[2], c->ev[0], c->ev[2]));
+    if (!c || !c->last_timed || c->ev_used < 2) return fail(c, QS_ERR_STATE, "qs_last_count_ms: the last qs_count_batch did not carry QS_COUNT_TIMED");
+    QS_HIP(c, hipEventSynchronize(c->evs[c->ev_used - 1]));
+    out_ms[0] = out_ms[1] = 0.f;
+    for (uint32_t i = 1; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        QS_HIP(c, hipEventElapsedTime(&ms, c->evs[i - 1], c->evs[i]));
+        out_ms[c->ev_kind[i] ? 1 : 0] += ms;
+    }
+    QS_HIP(c, hipEventElapsedTime(&out_ms[2], c->evs[0], c->evs[c->ev_used - 1]));
     return QS_OK;
+}
+
+extern "C" int qs_last_count_launches(const qs_ctx *c) {
+    if (!c || !c->last_timed) return 0;
+    int k = 0;
+    for (uint32_t i = 1; i < c->ev_used; ++i) k += c->ev_kind[i] ? 1 : 0;
+    return k;
 }
 
 extern "C" const char *qs_last_count_variant(const qs_ctx *c) { return c ? c->variant.c_str() : ""; }

@@ -631,14 +631,13 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
 }
 
 hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel,
-                                 uint32_t n_groups, uint32_t compact_nw) {
+                                 uint32_t n_groups, uint32_t compact_nw, bool force_general) {
     const uint32_t npairs = (uint32_t)binom2(n);
     const uint32_t levels = panel_levels(n);
     {   // all 32 trees' tables resident at once -> the small-n kernel
         const uint32_t tree_bytes = (n * 2 + levels * n + 3) & ~3u;
         const size_t lds_small = (size_t)kBitTrees * tree_bytes;
-        const char *pe = getenv("QS_PANEL_KERNEL"); // "big" forces the general kernel (tests / A-B runs)
-        if (lds_small <= 96 * 1024 && !(pe && pe[0] == 'b')) {
+        if (lds_small <= 96 * 1024 && !force_general) { // force_general: qs_set_tuning(QS_TUNE_PANEL_KERNEL, 1) (tests / A-B runs)
             dim3 grid((npairs + kBPSThreads - 1) / kBPSThreads, n_groups), block(kBPSThreads);
 #define QS_BPS(PART, NWC)                                                                                          \
     do {                                                                                                           \

@@ -52,7 +52,8 @@ hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void
                                uint32_t n_chunks, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                bool overwrite);
 hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n, bool partial, void *panel, uint32_t n_groups,
-                                 uint32_t compact_nw); // words per panel element: planes (>= 4) [+ presence word]
+                                 uint32_t compact_nw, // words per panel element: planes (>= 4) [+ presence word]
+                                 bool force_general);
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite, uint32_t *wire); // wire != NULL (binary_full only): one word n0 | n1 << 16 per tuple instead of the table

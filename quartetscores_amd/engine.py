@@ -34,6 +34,10 @@ def count_bits_for(m: int) -> int:
     return 16 if m < (1 << 16) else 32
 
 
+# qs_set_tuning values applied to every new Context (tests and A/B runs set entries here; empty in production)
+DEFAULT_TUNING = {}
+
+
 class Context:
     """Thin RAII wrapper of qs_ctx."""
 
@@ -48,6 +52,8 @@ class Context:
         self.count_bits = count_bits
         self.d_lo, self.d_hi = d_lo, d_hi or n_taxa
         self._attached = None  # keeps an attached torch tensor alive
+        for key, value in DEFAULT_TUNING.items():
+            self.set_tuning(key, value)
 
     def close(self):
         if getattr(self, "h", None):
@@ -157,6 +163,13 @@ class Context:
         out = (C.c_float * 3)()
         self._chk(self.L.qs_last_count_ms(self.h, C.byref(out)))
         return tuple(float(x) for x in out)
+
+    def last_count_launches(self) -> int:
+        return int(self.L.qs_last_count_launches(self.h))
+
+    def set_tuning(self, key: int, value: int):
+        """qs_set_tuning: _lib.QS_TUNE_PANEL_SLICE_BYTES / QS_TUNE_GATHER_IMPL / QS_TUNE_PANEL_KERNEL (A/B runs, tests)."""
+        self._chk(self.L.qs_set_tuning(self.h, key, value))
 
     def last_count_variant(self) -> str:
         return self.L.qs_last_count_variant(self.h).decode()

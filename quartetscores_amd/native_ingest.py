@@ -34,6 +34,13 @@ def _lib():
         L.qsh_last_error.restype = C.c_char_p
         L.qsh_ingest.restype = C.c_int
         L.qsh_ingest.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.qsh_ingest_text.restype = C.c_int
+        L.qsh_ingest_text.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.qsh_synth_trees.restype = C.c_int
+        L.qsh_synth_trees.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_double, C.c_uint,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.qsh_free_text.argtypes = [C.c_void_p]
         L.qsh_batch_n_trees.restype = C.c_uint32
         L.qsh_batch_n_trees.argtypes = [C.c_void_p]
         L.qsh_batch_array.restype = C.c_void_p
@@ -57,6 +64,43 @@ def ingest(ref_path: str, eval_path: str, tree_lo: int = 0, tree_hi: int = ALL, 
                       C.byref(h), C.byref(total))
     if rc != 0:
         raise IngestError(L.qsh_last_error().decode())
+    return _take(L, h), int(total.value)
+
+
+def ingest_text(ref_text: str, eval_text, tree_lo: int = 0, tree_hi: int = ALL, threads: int = 0,
+                want_ranges: bool = True) -> Tuple[flatten.TreeBatch, int]:
+    """ingest() on Newick text in memory (eval_text: str or bytes holding ';'-terminated trees)."""
+    L = _lib()
+    h = C.c_void_p()
+    total = C.c_uint64(0)
+    rb = ref_text.encode() if isinstance(ref_text, str) else ref_text
+    eb = eval_text.encode() if isinstance(eval_text, str) else eval_text
+    rc = L.qsh_ingest_text(rb, len(rb), eb, len(eb), tree_lo, min(tree_hi, ALL), threads, 1 if want_ranges else 0,
+                           C.byref(h), C.byref(total))
+    if rc != 0:
+        raise IngestError(L.qsh_last_error().decode())
+    return _take(L, h), int(total.value)
+
+
+def synth_trees(n: int, m: int, seed: int, kind: str = "random", ref_text: str = None, mean_nni: float = -1.0,
+                threads: int = 0) -> bytes:
+    """m seeded synthetic trees on taxa t0..t{n-1} as ';'-terminated Newick lines (csrc/host/synth.hpp):
+    kind "random" = uniformly random pairwise joining; "nni" = ref_text + Poisson(mean_nni, default n/8) random NNIs.
+    Tree t depends only on (n, seed, t)."""
+    L = _lib()
+    p = C.c_void_p()
+    ln = C.c_uint64(0)
+    rc = L.qsh_synth_trees(n, m, seed, {"random": 0, "nni": 1}[kind], ref_text.encode() if ref_text else None, mean_nni,
+                           threads, C.byref(p), C.byref(ln))
+    if rc != 0:
+        raise IngestError(L.qsh_last_error().decode())
+    try:
+        return C.string_at(p, ln.value)
+    finally:
+        L.qsh_free_text(p)
+
+
+def _take(L, h) -> flatten.TreeBatch:
     try:
         def arr(which, dtype):
             n = C.c_uint64(0)
@@ -69,4 +113,4 @@ def ingest(ref_path: str, eval_path: str, tree_lo: int = 0, tree_hi: int = ALL, 
                                   arr(3, np.uint32), arr(4, np.uint32), arr(5, np.uint16))
     finally:
         L.qsh_batch_free(h)
-    return batch, int(total.value)
+    return batch

@@ -88,3 +88,31 @@ def rank_order_quads(n):
 
 def all_quartets(n):
     return itertools.combinations(range(n), 4)
+
+
+def quartet_counts_for(eval_newicks, names, quads, mult=None):
+    """Semantic counts (len(quads), 3) uint64 of the given id 4-tuples (a,b,c,d) -> (#ab|cd, #ac|bd, #ad|bc), any order of
+    ids, for large n: the same split test as count_table, with every leaf's split memberships packed into 64-bit
+    words (a tree displays ab|cd iff some split has a,b on one side and c,d on the other)."""
+    ids = {nm: i for i, nm in enumerate(names)}
+    quads = np.asarray(quads, dtype=np.int64).reshape(-1, 4)
+    T = np.zeros((len(quads), 3), dtype=np.uint64)
+    for ti, nw in enumerate(eval_newicks):
+        k = 1 if mult is None else int(mult[ti])
+        splits, present = splits_of(parse_newick(nw), ids)
+        S = np.array(splits, dtype=bool)                      # (E, n)
+        E = S.shape[0]
+        pad = (-E) % 64
+        if pad:
+            S = np.concatenate([S, np.zeros((pad, S.shape[1]), dtype=bool)])
+        # member[x] = packed bits over the splits: bit e set iff leaf x is on the "below" side of split e
+        member = np.ascontiguousarray(np.packbits(np.ascontiguousarray(S.T), axis=1, bitorder="little")).view(np.uint64)   # (n, words)
+        A, B, Cc, D = (member[quads[:, i]] for i in range(4))
+        ok = present[quads].all(axis=1)
+
+        def displayed(p, q, r, s):   # pq|rs
+            return ((~(p ^ q)) & (~(r ^ s)) & (p ^ r)).any(axis=1)
+        # padding bits: all four are 0 there -> (p ^ r) = 0, never a hit
+        for slot, hit in enumerate((displayed(A, B, Cc, D), displayed(A, Cc, B, D), displayed(A, D, B, Cc))):
+            T[:, slot] += (hit & ok).astype(np.uint64) * np.uint64(k)
+    return T

@@ -43,6 +43,10 @@ def lib():
         L.qso_time_count.argtypes = [C.c_void_p]
         L.qso_time_score.restype = C.c_double
         L.qso_time_score.argtypes = [C.c_void_p]
+        L.qso_set_budget.restype = None
+        L.qso_set_budget.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.qso_increments_done.restype = C.c_ulonglong
+        L.qso_increments_done.argtypes = [C.c_void_p]
         L.qso_count.restype = C.c_int
         L.qso_count.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.qso_lookup.restype = C.c_int
@@ -134,6 +138,14 @@ class Oracle:
         if rc != 0:
             raise OracleError(lib().qso_last_error(self._h).decode())
         return lib().qso_time_count(self._h)
+
+    def set_budget(self, seconds: float, prefault: bool = True):
+        """bench.py cpu_baseline only: bound the following count() calls to `seconds` (0 = off). A bounded count
+        leaves an incomplete table; increments_done() says how much of the work was timed."""
+        lib().qso_set_budget(self._h, float(seconds), int(prefault))
+
+    def increments_done(self) -> int:
+        return int(lib().qso_increments_done(self._h))
 
     def counts(self) -> np.ndarray:
         """(C(n,4), 3) uint64: what countQuartetOccurrences returns for every a<b<c<d."""

@@ -1,0 +1,160 @@
+"""The HIP path at BASELINE.json's FULL sizes (configs[2], configs[3]'s per-GPU share, one table shard of configs[4]).
+
+At these sizes the oracle cannot produce the whole table in bounded time (one 512-taxon tree is 5.7e9 increments of
+QuartetCounterLookup.hpp:73-105), so parity goes through
+  * size-independent properties on the device: every tuple of a batch of binary trees holding all taxa sums to the
+    number of trees; the bit-sliced kernel's table equals the byte-SWAR kernel's table bit for bit;
+  * qs_lookup (= countQuartetOccurrences, QuartetCounterLookup.hpp:299-318) of 10^5 random quartets against the
+    independent split-based brute force (tests/bruteforce.py) on a 64-tree prefix of the same trees;
+  * at 256 taxa additionally the oracle itself (fast n^4 table, 8-tree prefix): counts bit-exact, LQ-/QP-/EQP-IC identical
+    (QuartetScoreComputer.hpp:379-490) -- the one test that reaches the XCD-remapped tile order (n >= 200) and the
+    64-iteration variant of score pass 1 with an exact answer.
+Trees: csrc/host/synth.hpp (seed = 1000 * config + set id, as bench.py). Run on the GPU box: python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+import bruteforce
+from oracle_api import Oracle
+from quartetscores_amd import _lib, distributed, flatten, native_ingest, ranks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from quartetscores_amd import engine
+    return engine
+
+
+def workload(cfg_no, n, m):
+    ref_nw = native_ingest.synth_trees(n, 1, 1000 * cfg_no).decode().strip()
+    text = native_ingest.synth_trees(n, m, 1000 * cfg_no + 1)
+    ref = flatten.flatten_reference(ref_nw)
+    batch, total = native_ingest.ingest_text(ref_nw, text, want_ranges=False)
+    assert total == m and batch.n_trees == m
+    return ref_nw, ref, text, batch
+
+
+def tuple_sums_equal(torch, table, nq, bits, m):
+    t16 = table.view(torch.int16)
+    for lo in range(0, nq, 1 << 26):
+        hi = min(nq, lo + (1 << 26))
+        cells = table[lo * 3: hi * 3] if bits == 32 else (t16[lo * 3: hi * 3].to(torch.int32) & 0xFFFF)
+        if not bool((cells.view(hi - lo, 3).sum(dim=1) == m).all().item()):
+            return False
+    return True
+
+
+def check_full_size(eng, cfg_no, n, m, bits, d_lo=0, d_hi=0, expect_slices=True):
+    """Property gates + brute-force lookups for one (shard of a) table at full size; returns (ctx, table, extras)."""
+    import torch
+    ref_nw, ref, text, batch = workload(cfg_no, n, m)
+    d_hi = d_hi or n
+    ctx = eng.Context(n, bits, d_lo=d_lo, d_hi=d_hi)
+    nq = ctx.table_tuples
+    assert nq == ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo)
+    table = torch.zeros((ctx.table_bytes + 3) // 4, dtype=torch.int32, device="cuda")
+    ctx.table_attach(table)
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE | eng.QS_COUNT_TIMED)
+    ctx.sync()
+    variant = ctx.last_count_variant()
+    assert "binary_full/bitslice" in variant, variant
+    if expect_slices:   # the default panel-slice size is in force: several slices, i.e. the table read-modify-write path
+        assert ctx.last_count_launches() > 1
+    assert ctx.trees_counted == m
+    assert tuple_sums_equal(torch, table, nq, bits, m)
+    # the independent byte-SWAR kernel gives the same table, bit for bit
+    mine = table.clone()
+    ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    assert "depth_u" in ctx.last_count_variant()
+    assert torch.equal(mine, table)
+    del mine
+    ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_AUTO)
+    # accumulate mode on top of the existing table: exactly twice the counts (checks the RMW of every slice)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER)
+    ctx.sync()
+    if 2 * m < (1 << bits):
+        assert tuple_sums_equal(torch, table, nq, bits, 2 * m)
+    # 10^5 random quartets of a 64-tree prefix against the split-based brute force
+    k = 64
+    hb_prefix = ctx.batch_upload(batch.slice(0, k), with_nodes=False)
+    ctx.count_batch(hb_prefix, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    rng = np.random.default_rng(1000 * cfg_no + 7)
+    # largest id uniform over the shard's range, the other three below it (every 4-set of the shard can occur)
+    dd = rng.integers(max(d_lo, 3), d_hi, size=100000)
+    q = np.sort(np.stack([np.append(rng.choice(d, size=3, replace=False), d) for d in dd]), axis=1)
+    # shuffle the order inside each 4-tuple: countQuartetOccurrences takes ids in any order
+    perm = np.stack([rng.permutation(4) for _ in range(len(q))])
+    qp = np.take_along_axis(q, perm, axis=1)
+    got = ctx.lookup(qp.astype(np.uint16))
+    lines = [ln.decode() for ln in text.split(b"\n")[:k]]
+    want = bruteforce.quartet_counts_for(lines, ref.names, qp)
+    assert (got == want).all()
+    assert (got.sum(axis=1) == k).all()
+    ctx.batch_free(hb_prefix)
+    ctx.batch_free(hb)
+    return ctx, table, (ref_nw, ref, text, batch)
+
+
+def test_configs2_512_taxa_10000_trees_u32(eng):
+    """BASELINE configs[2]: 34 GB table, bitslice_b5x2, default 96 MiB panel slices (9 launches with table RMW)."""
+    ctx, table, _ = check_full_size(eng, 2, 512, 10000, 32)
+    assert ctx.table_bytes == 33958525440
+    ctx.close()
+
+
+def test_configs3_share_256_taxa_12500_trees_u32_with_oracle(eng):
+    """One GPU's share of BASELINE configs[3] + the oracle on an 8-tree prefix: counts bit-exact, scores identical."""
+    n, m = 256, 12500
+    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 3, n, m, 32)
+    assert ctx.table_bytes == 2097511680
+    k = 8
+    lines = b"\n".join(text.split(b"\n")[:k]).decode()
+    hb = ctx.batch_upload(batch.slice(0, k), with_nodes=False)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    o = Oracle(ref_nw)
+    o.count(lines, savemem=False, cint_bits=16, nthreads=32)
+    assert o.names == ref.names
+    T = ctx.table_download()
+    want = o.counts()
+    assert T.shape == want.shape and (T == want).all()
+    del T, want
+    lq, qp, eqp, bif = ctx.score(ref)
+    assert bif
+    o.score(nthreads=1)
+    # oracle edges are keyed by bipartition; compare through the canonical keys
+    from quartetscores_amd import newick
+    mine = {}
+    names = ref.names
+    for e in range(ref.n_nodes - 1):
+        node = ref.nodes[e + 1]
+        below = frozenset(x.name for x in newick.preorder(node) if x.is_leaf)
+        if len(below) <= 1 or len(below) >= n - 1:
+            continue
+        other = frozenset(names) - below
+        key = below if (len(below) < len(other) or (len(below) == len(other) and min(names) not in below)) else other
+        mine[key] = (lq[e + 1], qp[e + 1], eqp[e + 1])
+    theirs = o.scores_by_bipartition()
+    assert set(mine) == set(theirs)
+    for key in mine:
+        assert mine[key] == theirs[key], (sorted(key)[:4], mine[key], theirs[key])
+    o.close()
+    ctx.batch_free(hb)
+    ctx.close()
+
+
+def test_configs4_shard_1024_taxa_5000_trees_u16(eng):
+    """One of the 8 table shards of BASELINE configs[4] (34 GB of u16 cells; every GPU counts all 5000 trees)."""
+    n, m = 1024, 5000
+    d_lo, d_hi = distributed.shard_of_largest_id(n, 8, 3)
+    ctx, table, _ = check_full_size(eng, 4, n, m, 16, d_lo, d_hi)
+    assert 33e9 < ctx.table_bytes < 35e9
+    ctx.close()

@@ -11,9 +11,10 @@ import pytest
 
 from helpers import d5_trees, key_of, ulp_diff
 from oracle_api import Oracle
-from quartetscores_amd import flatten, ranks, synth
+from quartetscores_amd import _lib, flatten, ranks, synth
 
 pytestmark = pytest.mark.gpu
+IMPLS = {"bitslice": _lib.QS_IMPL_BITSLICE, "swar": _lib.QS_IMPL_SWAR, "auto": _lib.QS_IMPL_AUTO}
 
 SCORE_ULP_TOL = 1  # north_star: IC scores within 1 ulp (we expect 0)
 
@@ -69,9 +70,9 @@ def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, root
     """Both gather implementations: bit-sliced (default: count_bitslice3_kernel; "bitslice_bigpanel" forces the
     panel builder meant for n > ~256) and the byte-SWAR one (fallback for deep trees)."""
     if impl == "bitslice_bigpanel":
-        monkeypatch.setenv("QS_PANEL_KERNEL", "big")
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_KERNEL, 1)
         impl = "bitslice"
-    monkeypatch.setenv("QS_GATHER_IMPL", impl)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, IMPLS[impl])
     ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
@@ -104,7 +105,7 @@ def test_tiny_and_odd_taxon_counts(eng, monkeypatch, n, impl):
     if impl == "scatter":
         algo = eng.QS_ALGO_SCATTER
     elif impl == "swar":
-        monkeypatch.setenv("QS_GATHER_IMPL", "swar")
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
     for m, kw in ((1, {}), (33, {}), (21, dict(collapse=0.3)), (19, dict(dropout=0.3))):
         ref_nw, trees = make_case(n, m, 60 + n, **kw)
         ref = flatten.flatten_reference(ref_nw)
@@ -182,11 +183,11 @@ def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     ctx, T = gpu_table(eng, ref, batch)
     assert "bitslice_b7" in ctx.last_count_variant()  # 7 depth bits still fit the bit-sliced kernel
     assert (T.astype(np.uint64) == o.counts()).all()
-    monkeypatch.setenv("QS_GATHER_IMPL", "swar")
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
     ctx, T = gpu_table(eng, ref, batch)
     assert "depth_u16" in ctx.last_count_variant()
     assert (T.astype(np.uint64) == o.counts()).all()
-    monkeypatch.delenv("QS_GATHER_IMPL")
+    monkeypatch.delitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL)
     # partial + deep
     trees2 = [cat + ";"] * 2 + synth.tree_set(n, 6, 11, dropout=0.2)
     batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id, recentre=False)
@@ -213,7 +214,7 @@ def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, ki
     assert (1 << (bits - 1)) <= int(batch.adj_depth.max()) < (1 << bits)
     want = oracle_counts(ref_nw, trees).counts()
     for builder in ("small", "big"):
-        monkeypatch.setenv("QS_PANEL_KERNEL", builder)
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_KERNEL, 1 if builder == "big" else 0)
         ctx, T = gpu_table(eng, ref, batch, count_bits)
         v = ctx.last_count_variant()
         assert kind in v
@@ -257,7 +258,7 @@ def test_overwrite_mode_equals_clear_plus_count(eng, monkeypatch):
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     for impl in ("bitslice", "swar"):
-        monkeypatch.setenv("QS_GATHER_IMPL", impl)
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, IMPLS[impl])
         ctx = eng.Context(26, 32)
         ctx.table_alloc()
         ctx.table_upload(np.full((ranks.n_quartets(26), 3), 12345, dtype=np.uint32))  # stale contents
@@ -279,7 +280,7 @@ def test_panel_slicing_gives_the_same_table(eng, monkeypatch):
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     _, T1 = gpu_table(eng, ref, batch)
-    monkeypatch.setenv("QS_PANEL_SLICE_BYTES", str(190 * 16 * 2))  # two 16-tree chunks per slice
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_SLICE_BYTES, 190 * 16 * 2)  # two 16-tree chunks per slice
     _, T2 = gpu_table(eng, ref, batch)
     assert (T1 == T2).all()
     assert (T1.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all()
@@ -783,7 +784,7 @@ def test_counting_straight_into_the_wire_format(eng, monkeypatch):
 
     def wire_count(parts, overwrite_first=False, slice_bytes=None):
         if slice_bytes:
-            monkeypatch.setenv("QS_PANEL_SLICE_BYTES", str(slice_bytes))
+            monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_SLICE_BYTES, slice_bytes)
         c2 = eng.Context(n, 32)                      # no table at all
         words = torch.full((nq,), 0x7F7F7F7F, dtype=torch.int32, device="cuda") if overwrite_first else torch.zeros(nq, dtype=torch.int32, device="cuda")
         c2.wire_attach(words)
@@ -793,7 +794,7 @@ def test_counting_straight_into_the_wire_format(eng, monkeypatch):
             c2.sync()
             c2.batch_free(hb)
         if slice_bytes:
-            monkeypatch.delenv("QS_PANEL_SLICE_BYTES")
+            monkeypatch.delitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_SLICE_BYTES)
         assert "wire_u16x2" in c2.last_count_variant()
         return words
 
