@@ -147,6 +147,9 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_PANEL_SLICE_BYTES 1u /* upper bound of the pair-depth panel of one sub-batch; 0 = automatic */
 #define QS_TUNE_GATHER_IMPL 2u       /* QS_IMPL_AUTO | QS_IMPL_SWAR (byte-SWAR kernel) | QS_IMPL_BITSLICE */
 #define QS_TUNE_PANEL_KERNEL 3u      /* 0 = automatic, 1 = always the general bit-plane panel builder */
+#define QS_TUNE_TILE_ORDER 4u        /* launch order of the count kernel's tiles: 0 = (d,c)-major (the order of the table);
+                                      * chunk | cblock << 16 = (a,b)-major: b-block, chunks of `chunk` a-blocks, blocks of
+                                      * `cblock` values of c, d-blocks (default 4 | 16 << 16) */
 #define QS_IMPL_AUTO 0u
 #define QS_IMPL_SWAR 1u
 #define QS_IMPL_BITSLICE 2u

@@ -16,7 +16,7 @@ QS_COUNT_TIMED = 0x200
 QS_COUNT_WIRE16X2 = 0x400
 QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
 QS_SCORE_CAND_SLOTS = 8
-QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL = 1, 2, 3
+QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares

@@ -39,6 +39,12 @@ struct qs_ctx {
     uint32_t n_dblk = 0, total_tiles = 0;
     uint32_t *dprefix3 = nullptr, *cprefix3 = nullptr; // tiling of count_bitslice3_kernel, binary batches (16x8 tiles, d-blocks counted down from d_hi)
     uint32_t total_tiles3 = 0;
+    // (a,b)-major launch order of count_bitslice3_kernel's tiles (tile_order below): launch slot -> tile id, built on
+    // first use; [0] binary tiling (16x8), [1] general / partial tiling (8x8). NULL = (d,c)-major (identity).
+    uint32_t *perm[2] = {nullptr, nullptr};
+    bool perm_built[2] = {false, false};
+    uint32_t tile_chunk = 4, tile_cblock = 16;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major
+    std::vector<uint32_t> h_cp3, h_dp3, h_cp, h_dp1t;  // host copies of the prefix arrays
     uint32_t *dprefix1t = nullptr;                     // the same kernel on general / partial batches: 8x8 tiles (cprefix), d-blocks counted down
     uint32_t total_tiles1t = 0;
     // workspace
@@ -64,12 +70,27 @@ struct qs_ctx {
 };
 
 static std::string g_create_err;
-// Panel bytes per sub-batch: qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES), else 96 MiB (Infinity-Cache resident) but at
-// least 32 tree groups (a tile's fixed cost -- decode, first staging, table read-modify-write -- needs that many
-// 32-tree steps to amortise; at 1024 taxa a group is 10 MB and 96 MiB would leave 7 steps per launch), capped at 384 MiB.
-static size_t panel_slice_bytes(const qs_ctx *c, size_t group_bytes) {
-    if (c->tune_slice_bytes) return (size_t)c->tune_slice_bytes;
-    return std::min<size_t>(std::max<size_t>(96ull << 20, 32 * group_bytes), 384ull << 20);
+// Tree groups (panel elements along the tree axis) per sub-batch of a batch of n_total groups.
+// A batch is counted slice by slice: panel build + count kernel per slice, the first slice stores into the table, the
+// others read-modify-write it. qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES) fixes the slice size in bytes (tests, sweeps).
+//  * bit-sliced kernel in (a,b)-major tile order (the default): what must stay in an XCD's 4 MB L2 is the working set of
+//    its concurrent tiles, which grows with the number of groups G of the slice (about 40 KB x G at 20-byte elements), not
+//    with the panel's size; against that every extra slice costs one read + one write of the table. Measured optimum
+//    (profiles/r02_experiments.md): 128-150 groups at 256 taxa (2 GB table), ~105 at 512 taxa (34 GB table; 3 slices
+//    for 10000 trees: 401 ms, 2: 415, 5: 432, unsliced 440), >= 80 at 1024 taxa (34 GB table shard). Rule: 128 groups,
+//    slices balanced (313 groups -> 3 x 105, not 128 + 128 + 57), at most 2 GiB of panel.
+//  * (d,c)-major order and the byte-SWAR kernel: the whole slice has to stay in the 256 MiB Infinity Cache while every
+//    wave streams through it: 96 MiB, but at least 32 groups (a tile's fixed cost needs that many steps to amortise),
+//    capped at 384 MiB (round-1 measurements: 512 taxa 0.60 s at 100 MB, 0.72 s at 50 MB, 0.80 s unsliced).
+static uint32_t slice_groups(const qs_ctx *c, size_t group_bytes, uint32_t n_total, bool ab_major) {
+    size_t g;
+    bool balance = false;
+    if (c->tune_slice_bytes) g = (size_t)c->tune_slice_bytes / group_bytes;
+    else if (ab_major) { g = std::min<size_t>(128, (2048ull << 20) / group_bytes); balance = true; }
+    else g = std::min<size_t>(std::max<size_t>(96ull << 20, 32 * group_bytes), 384ull << 20) / group_bytes;
+    g = std::min<size_t>(std::max<size_t>(g, 1), std::max<uint32_t>(n_total, 1));
+    if (balance) { const size_t slices = (n_total + g - 1) / g; g = (n_total + slices - 1) / std::max<size_t>(slices, 1); }
+    return (uint32_t)std::max<size_t>(g, 1);
 }
 
 // QS_COUNT_TIMED: an event after every kernel launch of the call (created on demand, re-used by later calls)
@@ -101,9 +122,75 @@ extern "C" const char *qs_version(void) { return "quartetscores_amd 0.1.0 (gfx95
 
 extern "C" const char *qs_last_error(const qs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+// (a,b)-major launch order of the tiles of count_bitslice3_kernel. The kernel decodes a tile id as (d-block k, c, tile
+// inside c) -- the order in which the TABLE is contiguous. Walked in that order, the waves that run at the same time
+// cover every (a,b) pair, so the private M[ab] loads (60 % of a wave's panel bytes) never hit in L2 and the launch is
+// bound by the Infinity Cache (knock-out at 512 taxa: no panel loads = 45 % less time; profiles/r02_experiments.md).
+// Here the launch slots are permuted: outermost the b-block Bk and a chunk of `chunk` a-blocks (pairs of a-blocks in
+// the binary tiling) under it, then blocks of `cblock` values of c, then the d-blocks, then c inside the block,
+// innermost the a-blocks of the chunk. Concurrent waves of an XCD (with xcd_remap each XCD walks a contiguous eighth of
+// the slots) then share one chunk's M[ab] elements (8 b-rows x 16*chunk a's x the tree groups of the slice), the
+// M[bd] elements of (Bk, d-block) and the M[xc] rows of the c-block, which stay in its 4 MB L2; per (c,d) a chunk still
+// writes 8 contiguous runs of the table. Diagonal tiles follow at the end. 512 taxa x 10000 trees: 568 -> 401 ms,
+// 256 taxa: -35 %. Shards with more than 2^26 tiles keep the (d,c)-major order (the slot array would be > 256 MB).
+static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
+    *out = nullptr;
+    if (c->perm_built[which]) { *out = c->perm[which]; return QS_OK; }
+    c->perm_built[which] = true;
+    const bool bin = which == 0;
+    const uint32_t total = bin ? c->total_tiles3 : c->total_tiles1t;
+    const uint32_t chunk = c->tile_chunk;
+    if (chunk == 0 || total == 0 || total > (1u << 26)) return QS_OK;
+    const uint32_t d_hi = c->d_hi, n_dblk = c->n_dblk;
+    const std::vector<uint32_t> &cp = bin ? c->h_cp3 : c->h_cp, &dp = bin ? c->h_dp3 : c->h_dp1t;
+    std::vector<uint32_t> perm;
+    perm.reserve(total);
+    auto T_of = [](uint32_t cc) { return (cc + 7) / 8; };
+    const uint32_t cmax = d_hi >= 2 ? d_hi - 2 : 0;          // largest c of any tile
+    const uint32_t Tmax = T_of(cmax);
+    const uint32_t cblock = c->tile_cblock ? c->tile_cblock : cmax + 1;
+    for (uint32_t Bk = 1; Bk < Tmax; ++Bk) {                 // off-diagonal tiles under b-block Bk
+        // binary: tile Bk^2/4 + j = a-blocks (2j, 2j+1); general: tile C(Bk,2) + j = a-block j (unrank2 in the kernel)
+        const uint32_t base = bin ? (Bk * Bk) / 4 : Bk * (Bk - 1) / 2;
+        const uint32_t nj = bin ? ((Bk + 1) * (Bk + 1)) / 4 - base : Bk;
+        const uint32_t c_lo = std::max(2u, 8 * Bk + 1);      // T(c) > Bk
+        for (uint32_t j0 = 0; j0 < nj; j0 += chunk) {
+            const uint32_t j1 = std::min(nj, j0 + chunk);
+            for (uint32_t cb = c_lo; cb <= cmax; cb += cblock)
+                for (uint32_t k = 0; k < n_dblk; ++k) {
+                    const uint32_t d1 = d_hi - k * kDB;
+                    for (uint32_t cc = cb; cc < cb + cblock && cc + 1 < d1; ++cc) {
+                        const uint32_t id = dp[k] + cp[cc] + base;
+                        for (uint32_t j = j0; j < j1; ++j) perm.push_back(id + j);
+                    }
+                }
+        }
+    }
+    for (uint32_t kd = 0; kd < (Tmax + 1) / 2; ++kd)          // diagonal tiles (two diagonal blocks each)
+        for (uint32_t k = 0; k < n_dblk; ++k) {
+            const uint32_t d1 = d_hi - k * kDB;
+            for (uint32_t cc = 2; cc + 1 < d1; ++cc) {
+                const uint32_t T = T_of(cc);
+                if (kd < (T + 1) / 2) perm.push_back(dp[k] + cp[cc] + (bin ? (T * T) / 4 : T * (T - 1) / 2) + kd);
+            }
+        }
+    if (perm.size() != total) return fail(c, QS_ERR_STATE, "tile order: enumeration does not match the tiling");
+    if (hipMalloc(&c->perm[which], perm.size() * 4) != hipSuccess) return fail(c, QS_ERR_OOM, "hipMalloc tile order");
+    if (hipMemcpyAsync(c->perm[which], perm.data(), perm.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, QS_ERR_HIP, "memcpy tile order");
+    *out = c->perm[which];
+    return QS_OK;
+}
+
 extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
     if (!c) return QS_ERR_ARG;
     switch (key) {
+        case QS_TUNE_TILE_ORDER:
+            QS_HIP(c, hipSetDevice(c->device));
+            QS_HIP(c, hipStreamSynchronize(c->stream));
+            for (int w = 0; w < 2; ++w) { if (c->perm[w]) (void)hipFree(c->perm[w]); c->perm[w] = nullptr; c->perm_built[w] = false; }
+            c->tile_chunk = (uint32_t)(value & 0xFFFF); c->tile_cblock = (uint32_t)(value >> 16);
+            return QS_OK;
         case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
         case QS_TUNE_GATHER_IMPL:
             if (value > QS_IMPL_BITSLICE) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_GATHER_IMPL takes QS_IMPL_AUTO / _SWAR / _BITSLICE");
@@ -168,6 +255,7 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
         c->total_tiles3 = dp3[c->n_dblk];
         std::vector<uint32_t> dp1(c->n_dblk + 1, 0);
         for (uint32_t k = 0; k < c->n_dblk; ++k) dp1[k + 1] = dp1[k] + cp[d_hi - k * kDB - 1]; // total equals total_tiles (< 2^31, checked above)
+        c->h_cp3 = cp3; c->h_dp3 = dp3; c->h_cp = cp; c->h_dp1t = dp1;
         c->total_tiles1t = dp1[c->n_dblk];
         if (hipMalloc(&c->dprefix1t, dp1.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix1t");
         if (hipMemcpy(c->dprefix1t, dp1.data(), dp1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix1t");
@@ -190,6 +278,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->dprefix) (void)hipFree(c->dprefix);
     if (c->cprefix) (void)hipFree(c->cprefix);
     if (c->dprefix3) (void)hipFree(c->dprefix3);
+    for (int w = 0; w < 2; ++w) if (c->perm[w]) (void)hipFree(c->perm[w]);
     if (c->dev_logk) (void)hipFree(c->dev_logk);
     if (c->dev_invk) (void)hipFree(c->dev_invk);
     if (c->dprefix1t) (void)hipFree(c->dprefix1t);
@@ -428,10 +517,11 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     CountGeometry g;
     g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo; g.n_dblk = c->n_dblk;
     g.total_tiles = c->total_tiles3; g.dprefix = c->dprefix3; g.cprefix = c->cprefix3;
+    { int rc_o = tile_order(c, 0, &g.perm); if (rc_o != QS_OK) return rc_o; }
     const uint32_t compact_nw = std::max(depth_bits, 4u);
     const size_t chunk_bytes = (size_t)binom2(c->n) * compact_nw * 4;
     const uint32_t n_chunks_total = (d.n_trees + 31) / 32;
-    const uint32_t chunks_per_slice = std::min<uint32_t>((uint32_t)std::max<size_t>(1, panel_slice_bytes(c, chunk_bytes) / chunk_bytes), n_chunks_total);
+    const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, g.perm != nullptr);
     const size_t need = (size_t)chunks_per_slice * chunk_bytes;
     if (need > c->panel_bytes) {
         if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
@@ -492,15 +582,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         if (c->tune_gather_impl == QS_IMPL_SWAR) use_bitslice = false;
         if (c->tune_gather_impl == QS_IMPL_BITSLICE && !bits_ok)
             return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 7 (6 with missing taxa) bits");
-        // The panel of a sub-batch is kept at or below the slice size so that it stays resident in the
-        // 256 MiB Infinity Cache while every wave streams through it; the price is one read-modify-write of
-        // the table per sub-batch. Measured at 512 taxa x 10000 trees (819 MB of panel, 34 GB table):
-        // 0.72 s with 50 MB slices, 0.60 s with 100 MB, 0.64 s with 192 MB, 0.71 s with 400 MB, 0.80 s unsliced.
-        // At 1024 taxa (10 MB per tree group) the optimum moves up: one of 8 table shards 1.03 s at 96 MiB, 0.78 s at
-        // 160 MB, 0.73 s at 224 MB; see panel_slice_bytes.
-        // Two things that did NOT help (profiles/r01_experiments.md): visiting the tree groups in rotated order so
-        // that late tiles stay in phase with the resident ones (the panel still streams from HBM once per
-        // round of tiles), and non-temporal table accesses.
+        // the batch is counted slice by slice (slice_groups above)
         // bit-sliced batches run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane)
         int bits = 8;
         uint32_t tpc;            // trees per panel element
@@ -516,9 +598,10 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             tpc = 16 / (bits / 8); elem_bytes = 16;
         }
         const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
-        uint32_t chunks_per_slice = (uint32_t)std::max<size_t>(1, panel_slice_bytes(c, use_bitslice ? chunk_bytes : 0) / chunk_bytes);
         const uint32_t n_chunks_total = (d.n_trees + tpc - 1) / tpc;
-        chunks_per_slice = std::min(chunks_per_slice, n_chunks_total);
+        const uint32_t *order = nullptr;   // launch order of the bit-sliced kernel's tiles for this batch's tiling
+        if (use_bitslice) { int rc_o = tile_order(c, mode == MODE_BINARY_FULL ? 0 : 1, &order); if (rc_o != QS_OK) return rc_o; }
+        const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, order != nullptr);
         const size_t need = (size_t)chunks_per_slice * chunk_bytes;
         if (need > c->panel_bytes) {
             if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
@@ -539,6 +622,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 CountGeometry g3 = g;
                 if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
                 else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
+                g3.perm = order;
                 QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0, nullptr));
             }
             else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));

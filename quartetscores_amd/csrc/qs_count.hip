@@ -806,6 +806,7 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 #ifndef QS_BS3_WAVES
 #define QS_BS3_WAVES 4
 #endif
+
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
 // one table tuple = three cells: moved with ONE 12-byte access for u32 cells (global_load/store_dwordx3; a tuple
@@ -831,7 +832,8 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
                                                                         const uint32_t *__restrict__ cprefix,
                                                                         CT *__restrict__ table,
                                                                         uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
-                                                                        uint32_t xcd_remap, uint32_t *__restrict__ wire) {
+                                                                        uint32_t xcd_remap, uint32_t *__restrict__ wire,
+                                                                        const uint32_t *__restrict__ perm) {
     constexpr bool BIN = MODE == MODE_BINARY_FULL, PART = MODE == MODE_PARTIAL;
     constexpr int NB = B + 1;
     constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
@@ -857,8 +859,9 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         const uint32_t nb = gridDim.x, q8 = nb / 8, r8 = nb % 8, xcd = lb % 8, y = lb / 8;
         lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + y; // bijective on [0, nb)
     }
-    const uint32_t tile = lb * kWavesPerBlock + wave;
+    uint32_t tile = lb * kWavesPerBlock + wave;
     if (tile >= total_tiles) return;
+    if (perm) tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)perm[tile]);
     uint32_t dp_k, cp_c;
     const uint32_t k = wave_search_le(dprefix, 0, n_dblk, tile, lane, dp_k);
     const uint32_t local = tile - dp_k;
@@ -920,11 +923,16 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv;
     const uint32_t yoff = dok ? (rowd + c) * 16u : kS3Inv;      // M[c,d]: shared by both R elements of the lane
     const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
+    // the 16 M[x,c] elements are staged by ALL lanes, four copies of each (lane & 15 picks the element; the copies
+    // load the same address and store the same value to the same slot). With the store under `if (lane < 16)` the
+    // compiler sank the load into that branch, i.e. behind the whole compute of the step, and waited for it with
+    // vmcnt(0) right there: one exposed memory latency per 32-tree step (knock-out: profiles/r02_experiments.md).
+    const uint32_t l16 = lane & 15;
     uint32_t xa = 0xFFFFFFFFu;
-    if (lane < 8) xa = blk0 * kTA + lane;
-    else if (lane < 16 && blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (lane - 8);
+    if (l16 < 8) xa = blk0 * kTA + l16;
+    else if (blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (l16 - 8);
     const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
-    const uint32_t rowslot = kS3Row0 + lane;   // lanes 0..15
+    const uint32_t rowslot = kS3Row0 + l16;
     const uint32_t ab1off = v1 ? pi1 * 16u : kS3Inv, ab2off = v2 ? pi2 * 16u : kS3Inv;
     const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
@@ -1012,10 +1020,8 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         }
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
         if (TWO) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
-        if (lane < 16) {
-            if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
-            else lstore(nxt, rowslot, st.row);
-        }
+        if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
+        else lstore(nxt, rowslot, st.row);
     };
 
     auto run = [&](auto a2_tag, auto full_tag, auto two_tag) {
@@ -1029,7 +1035,7 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
             lstore(buf0, slot0, sub_biased<B>(gload(r, x0off), y));
             if (TWO) lstore(buf0, slot1, sub_biased<B>(gload(r, x1off), y));
             const Planes row = gload(r, rowoff);
-            if (lane < 16) lstore(buf0, rowslot, row);
+            lstore(buf0, rowslot, row);
             abA1 = gload(r, ab1off);
             if (A2) abA2 = gload(r, ab2off);
         }
@@ -1111,7 +1117,7 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const v
 #define QS_BS3(BB, MM, CT)                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 1u : 0u, wire)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 1u : 0u, wire, g.perm)
 #define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
         if (depth_bits <= 4) QS_BS3(4, MM, CT);                                                                     \

@@ -43,6 +43,7 @@ struct CountGeometry {
     uint32_t total_tiles;
     const uint32_t *dprefix; // device, n_dblk+1
     const uint32_t *cprefix; // device, n+1
+    const uint32_t *perm = nullptr; // device, total_tiles: launch slot -> tile id (nullptr = identity); see qs_abi.hip tile_order
 };
 
 // qs_count.hip
