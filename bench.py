@@ -581,16 +581,19 @@ def main():
     bytes_per_unit = 2 * (count_bits // 8)
     units_per_launch = m * nq / launches
     launch_ms = count_ms / launches
-    depth_bits = None
-    if "bitslice_b" in variant:
-        depth_bits = int(variant.split("bitslice_b")[1][0])
+    import re
     mode = "binary_full" if "binary_full" in variant else "general_full" if "general_full" in variant else "partial" if "partial" in variant else None
     # minimal VALU lane-operations per (tree, quartet) of the bit-sliced four-point test, DESIGN.md 3.1:
     #   binary_full: [L > R] and [L < R] over B+1 planes (2 v_bitop3 per plane) + 2 v_bcnt per 32 trees
     #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 combine + 1 v_bcnt; partial: + 3 presence masks
+    # The batch is counted in depth classes (B = bits of a tree's deepest LCA): "bitslice_b4x2:2358+bitslice_b5x2:7642"
+    def ops_of(bits_):
+        return {"binary_full": 2 * (bits_ + 1) + 2, "general_full": 3 * (bits_ + 1) + 4, "partial": 3 * (bits_ + 1) + 8}[mode]
+    classes = [(int(b_), int(cnt_) if cnt_ else m) for b_, cnt_ in re.findall(r"bitslice_b(\d)(?:x2)?(?::(\d+))?", variant)]
+    depth_bits = max((b_ for b_, _ in classes), default=None)
     ops32 = None
-    if depth_bits:
-        ops32 = {"binary_full": 2 * (depth_bits + 1) + 2, "general_full": 3 * (depth_bits + 1) + 4, "partial": 3 * (depth_bits + 1) + 8}[mode]
+    if classes and "depth_u" not in variant and mode:
+        ops32 = sum(ops_of(b_) * cnt_ for b_, cnt_ in classes) / float(sum(cnt_ for _, cnt_ in classes))
     wl_name = (f"configs[{cfg_no}]" if not custom else "custom")
     workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}")
     out = {
@@ -640,7 +643,7 @@ def main():
         achieved = units_per_launch * ops32 / 32.0 / (launch_ms * 1e-3) / 1e12
         roof = {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLOPS,
                 "algorithmic_ops_per_unit": ops32 / 32.0,
-                "algorithmic_ops_note": f"{ops32} wave-instructions per (quartet, 32 trees): the minimal chain of the bit-sliced four-point test at {depth_bits} depth bits, mode {mode} (DESIGN.md 3.1); instructions really issued: see `issued`"}
+                "algorithmic_ops_note": f"{ops32:.3f} wave-instructions per (quartet, 32 trees): the minimal chain of the bit-sliced four-point test, 2(B+1)+2 at B depth bits for binary trees, averaged over the batch's depth classes {classes} (bits, trees), mode {mode} (DESIGN.md 3.1); instructions really issued: see `issued`"}
     else:                                   # scatter / SWAR paths: priced against HBM with SURVEY 8(d)'s bytes
         achieved = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}

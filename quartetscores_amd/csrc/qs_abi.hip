@@ -389,7 +389,7 @@ extern "C" int qs_unpack16x2(qs_ctx *c, const void *src_device, uint64_t n_tuple
 extern "C" void qs_batch_free(qs_ctx *c, qs_device_batch *b) {
     if (!b) return;
     if (c) (void)hipSetDevice(c->device);
-    (void)hipFree(b->d.leaf_off); (void)hipFree(b->d.leaf_ids); (void)hipFree(b->d.adj_depth);
+    (void)hipFree(b->d.leaf_off); (void)hipFree(b->d.leaf_ids); (void)hipFree(b->d.adj_depth); (void)hipFree(b->d.tree_order);
     (void)hipFree(b->d.node_off); (void)hipFree(b->d.rng_off); (void)hipFree(b->d.node_tree); (void)hipFree(b->d.ranges);
     delete b;
 }
@@ -411,6 +411,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     // ---- validate (the reference dies on malformed input; we return a status) ----
     // Trees are independent: large batches are checked by a few host threads, the first error in tree order wins.
     struct Part { uint32_t max_depth = 0; bool all_full = true, all_binary = true; uint32_t err_tree = 0xFFFFFFFFu; std::string err; };
+    std::vector<uint16_t> tree_depth(nt, 0); // deepest LCA of every tree
     auto check = [&](uint32_t t0, uint32_t t1, Part &P) {
         std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
         std::vector<uint32_t> stack;
@@ -432,6 +433,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
             for (uint32_t i = 0; i + 1 < L; ++i) {
                 const uint32_t dd = hb->adj_depth[base + i];
                 P.max_depth = std::max(P.max_depth, dd);
+                tree_depth[t] = (uint16_t)std::max<uint32_t>(tree_depth[t], dd);
                 if (dd == 0) ++zeros;
                 while (!stack.empty() && stack.back() > dd) stack.pop_back();
                 if (stack.empty() || stack.back() < dd) { stack.push_back(dd); ++nodes; }
@@ -462,10 +464,47 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     d.n_trees = nt;
     d.total_leaves = nt ? hb->leaf_off[nt] : 0;
     d.max_depth = max_depth; d.all_full = all_full && nt > 0; d.all_binary = all_binary && nt > 0;
+    // Depth classes. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B of the deepest LCA of the
+    // trees it is given (2(B+1)+2 instructions, B >= 4), and one deep tree would put the whole batch on B = 7 or on the
+    // byte-SWAR kernel (4x slower). Trees are therefore counted class by class: B = 4, 5, 6, 7 (6 is the limit with
+    // missing taxa) and "deeper" (SWAR). A class below the batch's top class that holds fewer than max(1024, 10 %) of
+    // the trees is merged upwards: every class costs at least one more panel slice = one more pass over the table.
+    // (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
+    std::vector<uint32_t> order_host;
+    {
+        const uint32_t top_bits = d.all_full ? 7u : 6u;
+        auto cls_of = [&](uint32_t depth) { uint32_t bb = 1; while ((1u << bb) <= depth) ++bb; return bb <= 4 ? 4u : (bb <= top_bits ? bb : 8u); };
+        uint32_t cnt[9] = {0}, mx[9] = {0};
+        std::vector<uint8_t> cls(nt);
+        for (uint32_t t = 0; t < nt; ++t) { cls[t] = (uint8_t)cls_of(tree_depth[t]); cnt[cls[t]]++; mx[cls[t]] = std::max<uint32_t>(mx[cls[t]], tree_depth[t]); }
+        uint32_t remap[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+        const uint32_t small = std::max<uint32_t>(1024, nt / 10);
+        for (uint32_t bb = 4; bb < top_bits; ++bb) {
+            if (cnt[bb] == 0 || cnt[bb] >= small) continue;
+            uint32_t up = bb + 1;
+            while (up <= top_bits && cnt[up] == 0) ++up;
+            if (up > top_bits) continue;               // nothing above it among the bit-sliced classes
+            cnt[up] += cnt[bb]; mx[up] = std::max(mx[up], mx[bb]); cnt[bb] = 0; remap[bb] = up;
+        }
+        auto final_cls = [&](uint32_t k) { while (remap[k] != k) k = remap[k]; return k; };
+        d.n_classes = 0;
+        uint32_t run = 0, start[9] = {0};
+        for (uint32_t k = 4; k <= 8; ++k) {
+            if (cnt[k] == 0) continue;
+            start[k] = run; run += cnt[k];
+            d.class_bits[d.n_classes] = k; d.class_end[d.n_classes] = run; d.class_max_depth[d.n_classes] = mx[k];
+            d.n_classes++;
+        }
+        if (d.n_classes > 1) {
+            order_host.resize(nt);
+            for (uint32_t t = 0; t < nt; ++t) order_host[start[final_cls(cls[t])]++] = t;
+        }
+    }
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = to_device(&d.leaf_off, hb->leaf_off, (size_t)nt + 1);
     if (e == hipSuccess) e = to_device(&d.leaf_ids, hb->leaf_ids, d.total_leaves);
     if (e == hipSuccess) e = to_device(&d.adj_depth, hb->adj_depth, d.total_leaves);
+    if (e == hipSuccess && !order_host.empty()) e = to_device(&d.tree_order, order_host.data(), order_host.size());
     if (e == hipSuccess && hb->node_off && hb->rng_off && hb->ranges) {
         d.n_nodes = hb->node_off[nt];
         d.n_links = hb->rng_off[d.n_nodes];
@@ -511,34 +550,39 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
         return fail(c, QS_ERR_STATE, "QS_COUNT_WIRE16X2: the batch is not made of binary trees that hold all taxa (count into the table and use qs_table_pack16)");
     if ((overwrite ? 0 : c->wire_trees) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "QS_COUNT_WIRE16X2: more than 65535 trees do not fit 16-bit cells");
-    uint32_t depth_bits = 1;
-    while ((1u << depth_bits) <= d.max_depth) ++depth_bits;
-    if (depth_bits > 7) return fail(c, QS_ERR_UNSUPPORTED, "QS_COUNT_WIRE16X2: tree depth needs more than 7 bits; count into the table instead");
+    if (d.class_bits[d.n_classes - 1] > 7) return fail(c, QS_ERR_UNSUPPORTED, "QS_COUNT_WIRE16X2: tree depth needs more than 7 bits; count into the table instead");
     CountGeometry g;
     g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo; g.n_dblk = c->n_dblk;
     g.total_tiles = c->total_tiles3; g.dprefix = c->dprefix3; g.cprefix = c->cprefix3;
     { int rc_o = tile_order(c, 0, &g.perm); if (rc_o != QS_OK) return rc_o; }
-    const uint32_t compact_nw = std::max(depth_bits, 4u);
-    const size_t chunk_bytes = (size_t)binom2(c->n) * compact_nw * 4;
-    const uint32_t n_chunks_total = (d.n_trees + 31) / 32;
-    const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, g.perm != nullptr);
-    const size_t need = (size_t)chunks_per_slice * chunk_bytes;
-    if (need > c->panel_bytes) {
-        if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
-        if (hipMalloc(&c->panel, need) != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
-        c->panel_bytes = need;
+    bool first = true;
+    c->variant = "gather/binary_full/bitslice_";
+    for (uint32_t k = 0; k < d.n_classes; ++k) {
+        const uint32_t s_lo = k ? d.class_end[k - 1] : 0, s_hi = d.class_end[k], depth_bits = d.class_bits[k];
+        const uint32_t compact_nw = std::max(depth_bits, 4u);
+        const size_t chunk_bytes = (size_t)binom2(c->n) * compact_nw * 4;
+        const uint32_t n_chunks_total = (s_hi - s_lo + 31) / 32;
+        const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, g.perm != nullptr);
+        const size_t need = (size_t)chunks_per_slice * chunk_bytes;
+        if (need > c->panel_bytes) {
+            if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
+            if (hipMalloc(&c->panel, need) != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
+            c->panel_bytes = need;
+        }
+        for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
+            const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
+            const uint32_t t0 = ch0 * 32, nt = std::min(nch * 32, s_hi - s_lo - t0);
+            DeviceBatch sub = d;
+            sub.slot0 = s_lo + t0;
+            sub.n_trees = nt;
+            QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, false, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
+            QS_HIP(c, launch_count_bitslice3(c->stream, g, c->panel, (int)depth_bits, MODE_BINARY_FULL, nch, nt, nullptr, 32, c->dev_flags,
+                                             overwrite && first, c->wire_out));
+            first = false;
+        }
+        c->variant += (k ? "+b" : "b") + std::to_string(depth_bits) + "x2" + (d.n_classes > 1 ? ":" + std::to_string(s_hi - s_lo) : "");
     }
-    for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
-        const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
-        const uint32_t t0 = ch0 * 32, nt = std::min(nch * 32, d.n_trees - t0);
-        DeviceBatch sub = d;
-        sub.leaf_off = d.leaf_off + t0;
-        sub.n_trees = nt;
-        QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, false, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
-        QS_HIP(c, launch_count_bitslice3(c->stream, g, c->panel, (int)depth_bits, MODE_BINARY_FULL, nch, nt, nullptr, 32, c->dev_flags,
-                                         overwrite && ch0 == 0, c->wire_out));
-    }
-    c->variant = std::string("gather/binary_full/bitslice_b") + std::to_string(std::max(depth_bits, 4u)) + "x2/wire_u16x2";
+    c->variant += "/wire_u16x2";
     c->wire_trees = (overwrite ? 0 : c->wire_trees) + d.n_trees;
     c->last_timed = false;
     return QS_OK;
@@ -574,64 +618,73 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         CountGeometry g;
         g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
         g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
-        // bits needed for the largest LCA depth
-        uint32_t depth_bits = 1;
-        while ((1u << depth_bits) <= d.max_depth) ++depth_bits;
-        const bool bits_ok = depth_bits <= (mode == MODE_PARTIAL ? 6u : 7u);
-        bool use_bitslice = bits_ok;
-        if (c->tune_gather_impl == QS_IMPL_SWAR) use_bitslice = false;
-        if (c->tune_gather_impl == QS_IMPL_BITSLICE && !bits_ok)
+        // One (panel build + count kernel) per slice of every depth class of the batch (classes: qs_batch_upload; slices:
+        // slice_groups). With QS_IMPL_SWAR the whole batch is one class of the byte-SWAR kernel.
+        const uint32_t top_bits = mode == MODE_PARTIAL ? 6u : 7u;
+        if (c->tune_gather_impl == QS_IMPL_BITSLICE && d.class_bits[d.n_classes - 1] > top_bits)
             return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 7 (6 with missing taxa) bits");
-        // the batch is counted slice by slice (slice_groups above)
-        // bit-sliced batches run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane)
-        int bits = 8;
-        uint32_t tpc;            // trees per panel element
-        size_t elem_bytes;       // bytes per (pair, element)
-        const uint32_t compact_nw = std::max(depth_bits, 4u) + (mode == MODE_PARTIAL ? 1u : 0u); // words per compact panel element
-        if (use_bitslice) { tpc = 32; elem_bytes = compact_nw * 4; }
-        else {
-            const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
-            const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
-            if (d.max_depth <= lim8) bits = 8;
-            else if (d.max_depth <= lim16) bits = 16;
-            else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(d.max_depth) + " exceeds the panel range; re-root the tree at its centre");
-            tpc = 16 / (bits / 8); elem_bytes = 16;
-        }
-        const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
-        const uint32_t n_chunks_total = (d.n_trees + tpc - 1) / tpc;
-        const uint32_t *order = nullptr;   // launch order of the bit-sliced kernel's tiles for this batch's tiling
-        if (use_bitslice) { int rc_o = tile_order(c, mode == MODE_BINARY_FULL ? 0 : 1, &order); if (rc_o != QS_OK) return rc_o; }
-        const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, order != nullptr);
-        const size_t need = (size_t)chunks_per_slice * chunk_bytes;
-        if (need > c->panel_bytes) {
-            if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
-            hipError_t e = hipMalloc(&c->panel, need);
-            if (e != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
-            c->panel_bytes = need;
-        }
-        for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
-            const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
-            const uint32_t t0 = ch0 * tpc, nt = std::min(nch * tpc, d.n_trees - t0);
-            DeviceBatch sub = d;
-            sub.leaf_off = d.leaf_off + t0; // offsets stay absolute into leaf_ids / adj_depth
-            sub.n_trees = nt;
-            if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
-            else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
-            if (timed) QS_HIP(c, mark(c, 0));
-            if (use_bitslice) {
-                CountGeometry g3 = g;
-                if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
-                else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
-                g3.perm = order;
-                QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0, nullptr));
+        const bool all_swar = c->tune_gather_impl == QS_IMPL_SWAR;
+        const uint32_t n_cls = all_swar ? 1u : d.n_classes;
+        bool first = true;
+        std::string names;
+        for (uint32_t k = 0; k < n_cls; ++k) {
+            const uint32_t s_lo = (all_swar || k == 0) ? 0u : d.class_end[k - 1], s_hi = all_swar ? d.n_trees : d.class_end[k];
+            const uint32_t depth_bits = all_swar ? 8u : d.class_bits[k];
+            const uint32_t cls_max_depth = all_swar ? d.max_depth : d.class_max_depth[k];
+            const bool use_bitslice = depth_bits <= top_bits;
+            // bit-sliced classes run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane)
+            int bits = 8;
+            uint32_t tpc;            // trees per panel element
+            size_t elem_bytes;       // bytes per (pair, element)
+            const uint32_t compact_nw = std::max(depth_bits, 4u) + (mode == MODE_PARTIAL ? 1u : 0u); // words per compact panel element
+            if (use_bitslice) { tpc = 32; elem_bytes = compact_nw * 4; }
+            else {
+                const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
+                const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
+                if (cls_max_depth <= lim8) bits = 8;
+                else if (cls_max_depth <= lim16) bits = 16;
+                else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(cls_max_depth) + " exceeds the panel range; re-root the tree at its centre");
+                tpc = 16 / (bits / 8); elem_bytes = 16;
             }
-            else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && ch0 == 0));
-            if (timed) QS_HIP(c, mark(c, 1));
+            const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
+            const uint32_t n_chunks_total = (s_hi - s_lo + tpc - 1) / tpc;
+            const uint32_t *order = nullptr;   // launch order of the bit-sliced kernel's tiles for this batch's tiling
+            if (use_bitslice) { int rc_o = tile_order(c, mode == MODE_BINARY_FULL ? 0 : 1, &order); if (rc_o != QS_OK) return rc_o; }
+            const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, order != nullptr);
+            const size_t need = (size_t)chunks_per_slice * chunk_bytes;
+            if (need > c->panel_bytes) {
+                if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
+                hipError_t e = hipMalloc(&c->panel, need);
+                if (e != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
+                c->panel_bytes = need;
+            }
+            for (uint32_t ch0 = 0; ch0 < n_chunks_total; ch0 += chunks_per_slice) {
+                const uint32_t nch = std::min(chunks_per_slice, n_chunks_total - ch0);
+                const uint32_t t0 = ch0 * tpc, nt = std::min(nch * tpc, s_hi - s_lo - t0);
+                DeviceBatch sub = d;
+                sub.slot0 = s_lo + t0;        // slots [slot0, slot0 + nt) of the class-ordered batch
+                sub.n_trees = nt;
+                if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
+                else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
+                if (timed) QS_HIP(c, mark(c, 0));
+                if (use_bitslice) {
+                    CountGeometry g3 = g;
+                    if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
+                    else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
+                    g3.perm = order;
+                    QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && first, nullptr));
+                }
+                else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && first));
+                first = false;
+                if (timed) QS_HIP(c, mark(c, 1));
+            }
+            // kernel variant of the class; several classes: "a:trees+b:trees"
+            std::string nm = use_bitslice ? "bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (mode == MODE_BINARY_FULL ? "x2" : "")
+                                          : "depth_u" + std::to_string(bits);
+            if (n_cls > 1) nm += ":" + std::to_string(s_hi - s_lo);
+            names += (k ? "+" : "") + nm;
         }
-        if (use_bitslice)
-            c->variant = std::string("gather/") + mode_names[mode] + "/bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (mode == MODE_BINARY_FULL ? "x2" : "") + "/count_u" + std::to_string(c->count_bits);
-        else
-            c->variant = std::string("gather/") + mode_names[mode] + "/depth_u" + std::to_string(bits) + "/count_u" + std::to_string(c->count_bits);
+        c->variant = std::string("gather/") + mode_names[mode] + "/" + names + "/count_u" + std::to_string(c->count_bits);
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");

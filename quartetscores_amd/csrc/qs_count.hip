@@ -53,6 +53,7 @@ constexpr int kPanelPB = kPanelThreads * kPanelPPT;
 // (TPC = 16 for u8 depths, 8 for u16). pair index of x<y is C(y,2)+x.
 template <typename DT, bool PARTIAL>
 __global__ __launch_bounds__(kPanelThreads) void build_panel_kernel(const uint32_t *__restrict__ leaf_off,
+                                                                    const uint32_t *__restrict__ order, uint32_t slot0,
                                                                     const uint16_t *__restrict__ leaf_ids,
                                                                     const uint16_t *__restrict__ adj_depth,
                                                                     uint32_t n_trees, uint32_t n, uint32_t npairs,
@@ -77,12 +78,13 @@ __global__ __launch_bounds__(kPanelThreads) void build_panel_kernel(const uint32
     }
 
     for (int j = 0; j < TPC; ++j) {
-        const uint32_t t = tc * TPC + j;
-        if (t >= n_trees) { // uniform: padding trees resolve nothing (all sums equal)
+        const uint32_t slot = tc * TPC + j;
+        if (slot >= n_trees) { // uniform: padding trees resolve nothing (all sums equal)
 #pragma unroll
             for (int q = 0; q < kPanelPPT; ++q) out[(q * kPanelThreads + tid) * TPC + j] = 0;
             continue;
         }
+        const uint32_t t = order ? order[slot0 + slot] : slot0 + slot; // tree behind this slot of the sub-batch
         const uint32_t base = leaf_off[t];
         const uint32_t L = leaf_off[t + 1] - base;
         __syncthreads(); // previous tree's queries done
@@ -144,7 +146,7 @@ hipError_t launch_build_panel(hipStream_t s, const DeviceBatch &b, uint32_t n, i
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.tree_order, b.slot0, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
                            (uint4 *)panel);                                                                     \
     } while (0)
     if (panel_bits == 8) { if (partial) QS_PANEL(uint8_t, true); else QS_PANEL(uint8_t, false); }
@@ -459,100 +461,100 @@ hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void
 constexpr int kBitWords = 8;   // words per bit-plane element (32 bytes)
 constexpr int kBitTrees = 32;  // trees per element
 
-constexpr int kBPThreads = 256;
-constexpr int kBPPPT = 1;      // pairs per thread (small workgroups: many resident per CU hide the LDS round trips)
+// Bit-plane panel, general builder (any n). Workgroup = (group of 32 trees, 4096 pairs), 16 waves. The 32 trees are
+// taken in rounds of as many trees as fit in LDS together (8 at 1024 taxa, 16 at 512): every wave builds the leaf
+// positions and the sparse table (range minimum over adj_depth, u8: depths are < 128 whenever the bit-plane panel is
+// used) of one tree of the round in its own LDS region -- DS operations of one wave execute in order, so no barrier is
+// needed inside a build --, one barrier, then thread = 4 pairs: it answers its pairs' queries in the round's trees (4 LDS
+// reads + min each) and keeps the planes in registers until all rounds are done. The tables are built once per 4096
+// pairs; the round-1 builder rebuilt them for every 256 pairs (44 table entries written per query answered at 1024 taxa)
+// and ran one workgroup of 4 waves per CU: 105 ms for 1024 taxa x 5000 trees, 21 % of a table-sharded step.
+constexpr int kBPThreads = 1024;
+constexpr int kBPPPT = 4;      // pairs per thread
 constexpr int kBPPB = kBPThreads * kBPPPT;
-
-// Bit-plane panel, general builder (any n). Workgroup = (group of 32 trees, 256 pairs). The four waves work on
-// different trees at the same time: a wave builds the tree's leaf positions and sparse table (range minimum over
-// adj_depth) in its own LDS region -- DS operations of one wave execute in order, so no workgroup barrier is
-// needed -- and answers the workgroup's pair queries for that tree (2 LDS reads + min each). One barrier, then
-// the 32 depth bytes of every pair are transposed to planes (+ the presence plane) and stored in the compact layout.
-template <bool PARTIAL>
+template <bool PARTIAL, int NWC>
 __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32_t *__restrict__ leaf_off,
+                                                                    const uint32_t *__restrict__ order, uint32_t slot0,
                                                                     const uint16_t *__restrict__ leaf_ids,
                                                                     const uint16_t *__restrict__ adj_depth,
                                                                     uint32_t n_trees, uint32_t n, uint32_t npairs,
-                                                                    uint32_t levels, uint4 *__restrict__ Pb, uint32_t compact_nw) {
+                                                                    uint32_t levels, uint32_t tree_bytes, uint32_t per_round,
+                                                                    uint4 *__restrict__ Pb) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint8_t *out = smem;                                     // [kBPPB][32] depth bytes (0xFF = absent)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const size_t per_wave = (size_t)n * 2 * (1 + levels);
-    uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)kBPPB * kBitTrees + wave * per_wave); // [n]
-    uint16_t *st = pos + n;                                                                          // [levels][n]
     const uint32_t g = blockIdx.y, p0 = blockIdx.x * kBPPB;
-    constexpr int kWavesPB = kBPThreads / kWave;
-    constexpr int kQPL = kBPPB / kWave; // queries per lane and tree (16)
+    constexpr int kWaves = kBPThreads / kWave;
+    constexpr int kPlanes = PARTIAL ? NWC - 1 : NWC; // partial elements end with the presence word
 
-    for (int j = (int)wave; j < kBitTrees; j += kWavesPB) {
-        const uint32_t t = g * kBitTrees + j;
-        if (t >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
-            for (int q = 0; q < kQPL; ++q) out[(size_t)(q * kWave + lane) * kBitTrees + j] = PARTIAL ? 0xFF : 0;
-            continue;
-        }
-        const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
-        for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
-        for (uint32_t i = lane; i < L; i += kWave) {
-            pos[leaf_ids[base + i]] = (uint16_t)i;
-            st[i] = adj_depth[base + i];
-        }
-        for (uint32_t k = 1; k < levels; ++k) {
-            const uint32_t half = 1u << (k - 1), span = 1u << k;
-            if (span + 1 <= L)
-                for (uint32_t i = lane; i + span <= L - 1; i += kWave)
-                    st[k * n + i] = min(st[(k - 1) * n + i], st[(k - 1) * n + i + half]);
-        }
-        for (int q = 0; q < kQPL; ++q) {
-            const uint32_t pl = q * kWave + lane, p = p0 + pl;
-            uint32_t val = 0;
-            if (p < npairs) {
-                uint32_t x, y;
-                unrank2(p, x, y);
-                const uint32_t a = pos[x], b = pos[y];
-                if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) val = 0xFF;
-                else {
-                    const uint32_t lo = min(a, b), hi = max(a, b), len = hi - lo;
-                    const uint32_t k = 31u - (uint32_t)__clz((int)len);
-                    val = min(st[k * n + lo], st[k * n + hi - (1u << k)]);
-                }
-            }
-            out[(size_t)pl * kBitTrees + j] = (uint8_t)val;
-        }
-    }
-    __syncthreads();
-    // transpose 32 depth bytes -> 7 planes + presence plane
+    uint32_t px[kBPPPT], py[kBPPPT];
+    uint32_t w[kBPPPT][kBitWords];
 #pragma unroll
     for (int q = 0; q < kBPPPT; ++q) {
-        const uint32_t pl = q * kBPThreads + tid, p = p0 + pl;
-        if (p >= npairs) continue;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(out + (size_t)pl * kBitTrees);
-        uint32_t w[kBitWords];
+        const uint32_t p = p0 + q * kBPThreads + tid;
+        px[q] = 0; py[q] = 1;
+        if (p < npairs) unrank2(p, px[q], py[q]);
 #pragma unroll
-        for (int k = 0; k < kBitWords; ++k) w[k] = 0;
-#pragma unroll
-        for (int wd = 0; wd < 8; ++wd) {
-            const uint32_t v = src[wd]; // 4 trees
-#pragma unroll
-            for (int bt = 0; bt < 4; ++bt) {
-                const uint32_t byte = (v >> (8 * bt)) & 0xFFu;
-                const uint32_t tbit = wd * 4 + bt;
-                const bool absent = PARTIAL && byte == 0xFFu;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) w[k] |= (absent ? 0u : ((byte >> k) & 1u)) << tbit;
-                w[7] |= (absent ? 0u : 1u) << tbit;
+        for (int k = 0; k < kBitWords; ++k) w[q][k] = 0;
+    }
+    for (uint32_t r0 = 0; r0 < (uint32_t)kBitTrees; r0 += per_round) {
+        __syncthreads(); // the previous round's queries are done
+        for (uint32_t j = wave; j < per_round; j += kWaves) {
+            const uint32_t slot = g * kBitTrees + r0 + j;
+            if (slot >= n_trees) continue;
+            const uint32_t t = order ? order[slot0 + slot] : slot0 + slot;
+            uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)j * tree_bytes); // [n]
+            uint8_t *st = reinterpret_cast<uint8_t *>(pos + n);                          // [levels][n]
+            const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
+            for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
+            for (uint32_t i = lane; i < L; i += kWave) {
+                pos[leaf_ids[base + i]] = (uint16_t)i;
+                st[i] = (uint8_t)adj_depth[base + i];
+            }
+            for (uint32_t k = 1; k < levels; ++k) {
+                const uint32_t half = 1u << (k - 1), span = 1u << k;
+                if (span + 1 <= L)
+                    for (uint32_t i = lane; i + span <= L - 1; i += kWave)
+                        st[k * n + i] = min(st[(k - 1) * n + i], st[(k - 1) * n + i + half]);
             }
         }
-        // compact layout: per tree group uint4 lo[npairs] (planes 0..3), then (compact_nw - 4) upper words per pair;
-        // partial batches: the last word is the presence plane
-        char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * compact_nw * 4;
-        reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
-        uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (compact_nw - 4);
-        const uint32_t plane_words = PARTIAL ? compact_nw - 1 : compact_nw;
+        __syncthreads();
+        for (uint32_t j = 0; j < per_round; ++j) {
+            const uint32_t bit = r0 + j, slot = g * kBitTrees + bit;
+            if (slot >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
+                if (!PARTIAL) {
 #pragma unroll
-        for (int k = 4; k < 7; ++k)
-            if ((uint32_t)k < plane_words) hi[k - 4] = w[k];
-        if (PARTIAL) hi[compact_nw - 5] = w[7];
+                    for (int q = 0; q < kBPPPT; ++q) w[q][7] |= 1u << bit;
+                }
+                continue;
+            }
+            const uint16_t *pos = reinterpret_cast<const uint16_t *>(smem + (size_t)j * tree_bytes);
+            const uint8_t *st = reinterpret_cast<const uint8_t *>(pos + n);
+#pragma unroll
+            for (int q = 0; q < kBPPPT; ++q) {
+                const uint32_t a = pos[px[q]], b = pos[py[q]];
+                if (PARTIAL && (a == 0xFFFFu || b == 0xFFFFu)) continue;
+                const uint32_t lo = min(a, b), hi = max(a, b), len = hi - lo;
+                const uint32_t k = 31u - (uint32_t)__clz((int)len);
+                const uint32_t val = min((uint32_t)st[k * n + lo], (uint32_t)st[k * n + hi - (1u << k)]);
+#pragma unroll
+                for (int pl = 0; pl < kPlanes; ++pl) w[q][pl] |= ((val >> pl) & 1u) << bit;
+                w[q][7] |= 1u << bit;
+            }
+        }
+    }
+    // compact layout: per tree group uint4 lo[npairs] (planes 0..3), then (NWC - 4) upper words per pair; partial
+    // batches: the last word is the presence plane
+    char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * NWC * 4;
+#pragma unroll
+    for (int q = 0; q < kBPPPT; ++q) {
+        const uint32_t p = p0 + q * kBPThreads + tid;
+        if (p >= npairs) continue;
+        if (PARTIAL) w[q][NWC - 1] = w[q][7];
+        reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
+        uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
+#pragma unroll
+        for (int k = 4; k < NWC; ++k) hi[k - 4] = w[q][k];
     }
 }
 
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
 constexpr int kBPSThreads = 1024;
 template <bool PARTIAL, int NWC>
 __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const uint32_t *__restrict__ leaf_off,
+                                                                          const uint32_t *__restrict__ order, uint32_t slot0,
                                                                           const uint16_t *__restrict__ leaf_ids,
                                                                           const uint16_t *__restrict__ adj_depth,
                                                                           uint32_t n_trees, uint32_t n, uint32_t npairs,
@@ -577,8 +580,9 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
     constexpr int kWaves = kBPSThreads / kWave;
 
     for (int j = (int)wave; j < kBitTrees; j += kWaves) {
-        const uint32_t t = g * kBitTrees + j;
-        if (t >= n_trees) continue;
+        const uint32_t slot = g * kBitTrees + j;
+        if (slot >= n_trees) continue;
+        const uint32_t t = order ? order[slot0 + slot] : slot0 + slot; // tree behind this slot of the sub-batch
         uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)j * tree_bytes); // [n]
         uint8_t *st = reinterpret_cast<uint8_t *>(pos + n);                          // [levels][n]
         const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
@@ -646,7 +650,7 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small); \
             if (e != hipSuccess) return e;                                                                         \
         }                                                                                                          \
-        hipLaunchKernelGGL(k, grid, block, lds_small, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
+        hipLaunchKernelGGL(k, grid, block, lds_small, s, b.leaf_off, b.tree_order, b.slot0, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
                            tree_bytes, (uint4 *)panel);                                                            \
     } while (0)
             if (partial) { // planes + presence word: 5..7
@@ -662,17 +666,33 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
             return hipGetLastError();
         }
     }
-    const size_t lds = (size_t)kBPPB * kBitTrees + (size_t)(kBPThreads / kWave) * n * 2 * (1 + levels);
+    // general builder: as many trees per round as fit in 128 KB of LDS (a power of two, at most 16 = one per wave)
+    const uint32_t tree_bytes = (n * 2 + levels * n + 3) & ~3u;
+    uint32_t per_round = 16;
+    while (per_round > 1 && (size_t)per_round * tree_bytes > 128 * 1024) per_round >>= 1;
+    const size_t lds = (size_t)per_round * tree_bytes;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((npairs + kBPPB - 1) / kBPPB, n_groups), block(kBPThreads);
-    if (partial) {
-        auto k = build_bitpanel_kernel<true>;
-        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel, compact_nw);
-    } else {
-        auto k = build_bitpanel_kernel<false>;
-        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, (uint4 *)panel, compact_nw);
+#define QS_BPG(PART, NWC)                                                                                          \
+    do {                                                                                                           \
+        auto k = build_bitpanel_kernel<PART, NWC>;                                                                 \
+        if (lds > 48 * 1024) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                         \
+        }                                                                                                          \
+        hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.tree_order, b.slot0, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
+                           tree_bytes, per_round, (uint4 *)panel);                                                 \
+    } while (0)
+    if (partial) { // planes + presence word: 5..7
+        if (compact_nw <= 5) QS_BPG(true, 5);
+        else if (compact_nw == 6) QS_BPG(true, 6);
+        else QS_BPG(true, 7);
     }
+    else if (compact_nw <= 4) QS_BPG(false, 4);
+    else if (compact_nw == 5) QS_BPG(false, 5);
+    else if (compact_nw == 6) QS_BPG(false, 6);
+    else QS_BPG(false, 7);
+#undef QS_BPG
     return hipGetLastError();
 }
 

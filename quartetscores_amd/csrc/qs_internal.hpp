@@ -26,6 +26,14 @@ struct DeviceBatch {
     uint32_t max_depth = 0;
     bool all_full = false;
     bool all_binary = false;
+    // Trees are counted class by class (classes = bits of the deepest LCA of a tree, so that shallow trees run the
+    // cheaper kernel instances): slot s of the class-ordered batch is tree tree_order[s]; class k holds the slots
+    // [class_end[k-1], class_end[k]) and needs class_bits[k] depth bits (> 7: byte-SWAR kernel). A sub-batch for the
+    // panel builders = slots [slot0, slot0 + n_trees).
+    uint32_t *tree_order = nullptr; // device, n_trees entries, or NULL = identity
+    uint32_t slot0 = 0;
+    uint32_t n_classes = 0;
+    uint32_t class_bits[8] = {0}, class_end[8] = {0}, class_max_depth[8] = {0};
     uint32_t *leaf_off = nullptr;  // device
     uint16_t *leaf_ids = nullptr;  // device
     uint16_t *adj_depth = nullptr; // device

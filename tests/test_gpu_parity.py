@@ -192,8 +192,68 @@ def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     trees2 = [cat + ";"] * 2 + synth.tree_set(n, 6, 11, dropout=0.2)
     batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id, recentre=False)
     ctx2, T2 = gpu_table(eng, ref, batch2)
-    assert "partial/depth_u16" in ctx2.last_count_variant()
+    v2 = ctx2.last_count_variant()   # the two caterpillars go to the SWAR kernel, the shallow trees stay bit-sliced
+    assert "partial/" in v2 and "depth_u16:2" in v2 and "bitslice_b" in v2, v2
     assert (T2.astype(np.uint64) == oracle_counts(ref_nw, trees2).counts()).all()
+
+
+def _concat_batches(a, b):
+    return flatten.TreeBatch(
+        a.n_trees + b.n_trees,
+        np.concatenate([a.leaf_off, b.leaf_off[1:] + a.leaf_off[-1]]).astype(np.uint32),
+        np.concatenate([a.leaf_ids, b.leaf_ids]), np.concatenate([a.adj_depth, b.adj_depth]),
+        np.concatenate([a.node_off, b.node_off[1:] + a.node_off[-1]]).astype(np.uint32),
+        np.concatenate([a.rng_off, b.rng_off[1:] + a.rng_off[-1]]).astype(np.uint32),
+        np.concatenate([a.ranges, b.ranges]))
+
+
+@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial"])
+def test_depth_classes_are_counted_separately(eng, kind):
+    """Trees are counted class by class (bits of the deepest LCA): 1100 shallow trees run the B = 4 instance, the 40
+    deep ones (interleaved in the batch) the B = 6 instance; the table equals the oracle's."""
+    n = 40
+    ref_nw = synth.reference_tree(n, 410)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    kw = {"binary_full": {}, "general_full": {"collapse": 0.2}, "partial": {"dropout": 0.1}}[kind]
+    shallow = synth.tree_set(n, 1100, 411, **kw)
+    parts, trees = [], []
+    for k in range(4):   # deep, shallow, deep, shallow, ... in the batch
+        parts.append(flatten.flatten_eval_trees([cat + ";"] * 10, ref.name_to_id, recentre=False))
+        parts.append(flatten.flatten_eval_trees(shallow[k * 275:(k + 1) * 275], ref.name_to_id))
+        trees += [cat + ";"] * 10 + shallow[k * 275:(k + 1) * 275]
+    batch = parts[0]
+    for p_ in parts[1:]:
+        batch = _concat_batches(batch, p_)
+    assert batch.n_trees == 1140
+    for algo_split in (None, 500):
+        ctx, T = gpu_table(eng, ref, batch, 32, split=algo_split)
+        if algo_split is None:
+            v = ctx.last_count_variant()
+            assert "bitslice_b4" in v and ":1100+" in v and "bitslice_b6" in v and v.count(":40") == 1, v
+        assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all(), (kind, algo_split)
+
+
+def test_only_the_deep_trees_take_the_swar_kernel(eng, monkeypatch):
+    n = 140
+    ref_nw = synth.reference_tree(n, 420)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    deep = flatten.flatten_eval_trees([cat + ";"] * 2, ref.name_to_id, recentre=False)
+    batch = _concat_batches(flatten.flatten_eval_trees(synth.tree_set(n, 70, 421), ref.name_to_id), deep)
+    assert int(batch.adj_depth.max()) > 127
+    ctx, T = gpu_table(eng, ref, batch)
+    v = ctx.last_count_variant()
+    assert "bitslice_b" in v and "depth_u16:2" in v, v
+    assert (T.sum(axis=1) == 72).all()
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+    ctx2, T2 = gpu_table(eng, ref, batch)
+    assert "depth_u16" in ctx2.last_count_variant() and "bitslice" not in ctx2.last_count_variant()
+    assert (T == T2).all()
 
 
 @pytest.mark.parametrize("n,bits", [(20, 5), (40, 6), (80, 7)])
