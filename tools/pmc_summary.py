@@ -20,6 +20,13 @@ from collections import defaultdict
 out_dir = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res = {"kernels_ms": {}, "counters": {}, "entries": []}
+prev = os.path.join(out_dir, "summary.json")
+if len(sys.argv) > 2 and sys.argv[2] == "--resummarise" and os.path.exists(prev):   # CSVs gone: start from the old summary
+    old = json.load(open(prev))
+    res["kernels_ms"], res["counters"] = old["kernels_ms"], old["counters"]
+    old_entry = (old.get("entries") or [{}])[0]
+else:
+    old_entry = {}
 for f in glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         res["kernels_ms"][row["Name"]] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6,
@@ -49,18 +56,29 @@ if bench:
             h.update(f.read())
     kname = bench["roofline"]["kernel"]
 
+    # every instance of the count kernel that works on the workload's table type (the depth classes of one batch run
+    # different template instances; bench.py's lookup gate runs one launch on a scratch u16 table): per-launch average
+    # over all of them, weighted by their dispatch counts
+    cell = "unsigned int" if bench["dtype"] == "u32" else "unsigned short"
+
+    def mine(name):
+        return kname in name and (cell + ">") in name.replace(" >", ">")
+
     def avg(counter):
+        tot = cnt = 0.0
         for k, v in res["counters"].get(counter, {}).items():
-            if kname in k:
-                return v["avg_per_dispatch"]
-        return None
+            if mine(k):
+                tot += v["avg_per_dispatch"] * v["dispatches"]; cnt += v["dispatches"]
+        return tot / cnt if cnt else None
     fetch, write, valu = avg("FETCH_SIZE"), avg("WRITE_SIZE"), avg("SQ_INSTS_VALU")
     hit, miss = avg("TCC_HIT_sum"), avg("TCC_MISS_sum")
-    kms = [v for k, v in res["kernels_ms"].items() if kname in k]
+    kms_all = [v for k, v in res["kernels_ms"].items() if mine(k)]
+    kms = [{"avg_ms": sum(v["avg_ms"] * v["calls"] for v in kms_all) / sum(v["calls"] for v in kms_all),
+            "calls": sum(v["calls"] for v in kms_all)}] if kms_all else []
     res["entries"].append({
         "workload_key": bench["config"]["workload_key"], "variant": bench["config"]["algo"],
-        "kernel_source_sha": h.hexdigest()[:16], "kernel": kname,
-        "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+        "kernel_source_sha": old_entry.get("kernel_source_sha") or h.hexdigest()[:16], "kernel": kname,
+        "collected": old_entry.get("collected") or datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
         "rocprof_avg_launch_ms": kms[0]["avg_ms"] if kms else None, "rocprof_calls": kms[0]["calls"] if kms else None,
         "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"],
         "valu_insts_per_launch": valu, "fetch_size_kb": fetch, "write_size_kb": write,
