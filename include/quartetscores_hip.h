@@ -192,6 +192,11 @@ typedef struct qs_device_batch qs_device_batch;
 /* Validates and copies the batch into HBM (synchronous w.r.t. the host buffers). */
 int qs_batch_upload(qs_ctx *ctx, const qs_tree_batch *batch, qs_device_batch **out);
 void qs_batch_free(qs_ctx *ctx, qs_device_batch *b);
+/* What the validation found: QS_BATCH_ALL_TAXA = every tree holds all n taxa, QS_BATCH_BINARY = every tree is fully
+ * resolved. Both set = the batch may be counted with QS_COUNT_WIRE16X2 / travel in the two-cell wire format. */
+#define QS_BATCH_ALL_TAXA 1u
+#define QS_BATCH_BINARY 2u
+uint32_t qs_batch_flags(const qs_device_batch *b);
 
 /* Adds the quartet topologies of every tree of the batch to the table. Asynchronous on the
  * context's stream; inputs already resident in HBM. */

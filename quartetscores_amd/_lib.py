@@ -16,6 +16,7 @@ QS_COUNT_TIMED = 0x200
 QS_COUNT_WIRE16X2 = 0x400
 QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
 QS_SCORE_CAND_SLOTS = 8
+QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
@@ -25,7 +26,7 @@ EXPORTS = [
     "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_wire_attach", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
-    "qs_set_tuning", "qs_last_count_launches",
+    "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags",
 ]
 
 
@@ -99,6 +100,8 @@ def load():
     L.qs_batch_upload.argtypes = [vp, C.POINTER(TreeBatchC), C.POINTER(vp)]
     L.qs_batch_free.restype = None
     L.qs_batch_free.argtypes = [vp, vp]
+    L.qs_batch_flags.restype = u32
+    L.qs_batch_flags.argtypes = [vp]
     L.qs_count_batch.restype = i32
     L.qs_count_batch.argtypes = [vp, vp, u32]
     L.qs_count_trees.restype = i32

@@ -23,6 +23,16 @@ struct qs_device_batch {
     DeviceBatch d;
 };
 
+// the reference tree, flattened and indexed for scoring (build_ref)
+struct RefHost {
+    uint32_t n_nodes = 0, n = 0, n_inner = 0, root = 0;
+    std::vector<int32_t> parent;
+    std::vector<uint32_t> depth, nchild, inner_id, inner_node;
+    std::vector<uint32_t> lca; // n*n
+    std::vector<uint32_t> leaf_node_in; // the caller's leaf_node array (cache key)
+    bool bifurcating = false;
+};
+
 struct qs_ctx {
     uint32_t n = 0, count_bits = 32, flags = 0;
     int device = 0;
@@ -67,6 +77,10 @@ struct qs_ctx {
     uint64_t view_rank_lo = 0, view_n = 0;
     std::string variant;
     std::string err;
+    // the flattened reference tree of the last scoring call, its LCA matrix on the device (qs_score_pass1 / pass2 /
+    // raw_qic / finish of one scoring run all get the same tree: built once, not three times)
+    RefHost *ref_cache = nullptr;
+    uint32_t *ref_lca_dev = nullptr;
 };
 
 static std::string g_create_err;
@@ -285,6 +299,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->cprefix3) (void)hipFree(c->cprefix3);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
+    if (c->ref_lca_dev) (void)hipFree(c->ref_lca_dev);
+    delete c->ref_cache;
     delete c;
 }
 
@@ -531,6 +547,11 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     }
     *out = b;
     return QS_OK;
+}
+
+extern "C" uint32_t qs_batch_flags(const qs_device_batch *b) {
+    if (!b) return 0;
+    return (b->d.all_full ? QS_BATCH_ALL_TAXA : 0u) | (b->d.all_binary ? QS_BATCH_BINARY : 0u);
 }
 
 // QS_COUNT_WIRE16X2: count a binary_full batch straight into the attached wire buffer (one word per tuple)
@@ -782,17 +803,10 @@ static double host_log_score(uint64_t q1, uint64_t q2, uint64_t q3) {
     return (q1 < q2 || q1 < q3) ? qic * -1 : qic;
 }
 
-struct RefHost {
-    uint32_t n_nodes = 0, n = 0, n_inner = 0, root = 0;
-    std::vector<int32_t> parent;
-    std::vector<uint32_t> depth, nchild, inner_id, inner_node;
-    std::vector<uint32_t> lca; // n*n
-    bool bifurcating = false;
-};
 
 static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
     if (!ref || !ref->parent || !ref->leaf_node) return fail(c, QS_ERR_ARG, "reference tree: NULL arrays");
-    if (ref->n_taxa != c->n) return fail(c, QS_ERR_ARG, "reference tree: n_taxa differs from the context");
+    if (c && ref->n_taxa != c->n) return fail(c, QS_ERR_ARG, "reference tree: n_taxa differs from the context");
     const uint32_t N = ref->n_nodes, n = ref->n_taxa;
     if (N < n + 1 || N > 65535) return fail(c, QS_ERR_ARG, "reference tree: bad node count");
     R.n_nodes = N; R.n = n;
@@ -875,6 +889,31 @@ static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
     return QS_OK;
 }
 
+// The context's cached reference tree (host arrays + LCA matrix on the device when want_dev); rebuilt only when the
+// caller passes a different tree.
+static int get_ref(qs_ctx *c, const qs_ref_tree *ref, bool want_dev, const RefHost **out) {
+    if (!ref || !ref->parent || !ref->leaf_node) return fail(c, QS_ERR_ARG, "reference tree: NULL arrays");
+    RefHost *R = c->ref_cache;
+    const bool same = R && R->n_nodes == ref->n_nodes && R->n == ref->n_taxa &&
+                      memcmp(R->parent.data(), ref->parent, (size_t)ref->n_nodes * 4) == 0 &&
+                      memcmp(R->leaf_node_in.data(), ref->leaf_node, (size_t)ref->n_taxa * 4) == 0;
+    if (!same) {
+        RefHost *fresh = new RefHost();
+        int rc = build_ref(c, ref, *fresh);
+        if (rc != QS_OK) { delete fresh; return rc; }
+        fresh->leaf_node_in.assign(ref->leaf_node, ref->leaf_node + ref->n_taxa);
+        if (c->ref_lca_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ref_lca_dev); c->ref_lca_dev = nullptr; }
+        delete c->ref_cache;
+        c->ref_cache = R = fresh;
+    }
+    if (want_dev && !c->ref_lca_dev) {
+        QS_HIP(c, hipMalloc(&c->ref_lca_dev, R->lca.size() * 4));
+        QS_HIP(c, hipMemcpyAsync(c->ref_lca_dev, R->lca.data(), R->lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    *out = R;
+    return QS_OK;
+}
+
 struct DevPtr { // RAII for a hipMalloc'ed pointer
     void *p = nullptr;
     ~DevPtr() { if (p) (void)hipFree(p); }
@@ -930,41 +969,36 @@ extern "C" int qs_score_set_view(qs_ctx *c, const void *table_dev, uint32_t coun
 extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev) {
     if (!c || !sums_dev || !min_dev) return fail(c, QS_ERR_ARG, "qs_score_pass1: NULL");
     if (!c->table && !c->view_table) return fail(c, QS_ERR_STATE, "qs_score_pass1: no table");
-    RefHost R;
-    int rc = build_ref(c, ref, R);
-    if (rc != QS_OK) return rc;
     QS_HIP(c, hipSetDevice(c->device));
+    const RefHost *Rp = nullptr;
+    int rc = get_ref(c, ref, true, &Rp);
+    if (rc != QS_OK) return rc;
+    const RefHost &R = *Rp;
     const size_t np = (size_t)R.n_inner * R.n_inner;
-    DevPtr lca;
-    QS_HIP(c, hipMalloc(&lca.p, R.lca.size() * 4));
-    QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
     QS_HIP(c, hipMemsetAsync(sums_dev, 0, np * 3 * 8, c->stream));
     QS_HIP(c, hipMemsetAsync(min_dev, 0x7F, np * 8, c->stream));
     { int rc_t = ensure_score_tables(c); if (rc_t != QS_OK) return rc_t; }
     ScoreDevice sd;
-    fill_score_device(c, R, (const uint32_t *)lca.p, sd);
+    fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
     QS_HIP(c, launch_score_pass1(c->stream, sd));
-    QS_HIP(c, hipStreamSynchronize(c->stream)); // lca is freed on return
-    return QS_OK;
+    return QS_OK;   // asynchronous on the context's stream
 }
 
 extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev) {
     if (!c || !min_dev || !cand_dev) return fail(c, QS_ERR_ARG, "qs_score_pass2: NULL");
     if (!c->table && !c->view_table) return fail(c, QS_ERR_STATE, "qs_score_pass2: no table");
-    RefHost R;
-    int rc = build_ref(c, ref, R);
-    if (rc != QS_OK) return rc;
     QS_HIP(c, hipSetDevice(c->device));
+    const RefHost *Rp = nullptr;
+    int rc = get_ref(c, ref, true, &Rp);
+    if (rc != QS_OK) return rc;
+    const RefHost &R = *Rp;
     const size_t np = (size_t)R.n_inner * R.n_inner;
-    DevPtr lca;
-    QS_HIP(c, hipMalloc(&lca.p, R.lca.size() * 4));
-    QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
     QS_HIP(c, hipMemsetAsync(cand_dev, 0xFF, np * kCand * 8, c->stream));
     QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
     { int rc_t = ensure_score_tables(c); if (rc_t != QS_OK) return rc_t; }
     ScoreDevice sd;
-    fill_score_device(c, R, (const uint32_t *)lca.p, sd);
+    fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_min = (long long *)min_dev; sd.pair_cand = (unsigned long long *)cand_dev;
     QS_HIP(c, launch_score_pass2(c->stream, sd, 1e-12));
     uint32_t fl = 0;
@@ -980,10 +1014,12 @@ extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *
 extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,
                                const int64_t *cand_host, uint32_t n_cand_parts, double *lqic, double *qpic, double *eqpic,
                                int *is_bifurcating) {
-    if (!c || !sums_host || !cand_host || !lqic || n_cand_parts == 0) return fail(c, QS_ERR_ARG, "qs_score_finish: NULL");
-    RefHost R;
-    int rc = build_ref(c, ref, R);
+    if (!sums_host || !cand_host || !lqic || n_cand_parts == 0) return fail(c, QS_ERR_ARG, "qs_score_finish: NULL");
+    RefHost local;          // ctx == NULL: pure host use (no device, no cache)
+    const RefHost *Rp = &local;
+    int rc = c ? get_ref(c, ref, false, &Rp) : build_ref(nullptr, ref, local);
     if (rc != QS_OK) return rc;
+    const RefHost &R = *Rp;
     if (is_bifurcating) *is_bifurcating = R.bifurcating ? 1 : 0;
     if (R.bifurcating && (!qpic || !eqpic)) return fail(c, QS_ERR_ARG, "qs_score: qpic/eqpic required for a bifurcating reference");
     const size_t np = (size_t)R.n_inner * R.n_inner;
@@ -1098,20 +1134,18 @@ extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64
     if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_raw_qic: no table");
     if (r0 + nq > c->n_tuples) return fail(c, QS_ERR_ARG, "qs_raw_qic: rank range outside this context's table");
     if (nq == 0) return QS_OK;
-    RefHost R;
-    int rc = build_ref(c, ref, R);
-    if (rc != QS_OK) return rc;
     QS_HIP(c, hipSetDevice(c->device));
-    DevPtr lca;
-    QS_HIP(c, hipMalloc(&lca.p, R.lca.size() * 4));
-    QS_HIP(c, hipMemcpyAsync(lca.p, R.lca.data(), R.lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+    const RefHost *Rp = nullptr;
+    int rc = get_ref(c, ref, true, &Rp);
+    if (rc != QS_OK) return rc;
+    const RefHost &R = *Rp;
     uint8_t *dt = nullptr; unsigned long long *dq = nullptr;
     QS_HIP(c, hipMalloc(&dt, nq));
     hipError_t e = hipMalloc(&dq, nq * 24);
     if (e != hipSuccess) { (void)hipFree(dt); return fail(c, QS_ERR_OOM, "qs_raw_qic: hipMalloc"); }
     { int rc_t = ensure_score_tables(c); if (rc_t != QS_OK) return rc_t; }
     ScoreDevice sd;
-    fill_score_device(c, R, (const uint32_t *)lca.p, sd);
+    fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.frame = 1; // printRawQICScores uses the multifurcating loop's argument order
     e = launch_raw_qic(c->stream, sd, r0, nq, dt, dq);
     if (e == hipSuccess) e = hipMemcpyAsync(topo, dt, nq, hipMemcpyDeviceToHost, c->stream);

@@ -163,48 +163,59 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
     table with `bits`-bit cells; ctx has that range set as its scoring view, so score_sharded(ctx, ref) gives the
     scores.
 
-    wire: "u32" | "u16" (three cells per tuple; u16 needs fewer than 65536 trees in total, "auto" picks it then) |
-    "u16x2" (one word per tuple; only for batches of binary trees that hold all taxa -- anything else is reported
-    as an error by the library, use "u16" then)."""
+    wire: "u32" | "u16" (three cells per tuple; u16 needs fewer than 65536 trees in total) | "u16x2" (one word per
+    tuple; only for batches of binary trees that hold all taxa -- anything else is reported as an error by the
+    library) | "auto": the narrowest of these that the trees of ALL ranks allow (qs_batch_flags, agreed with a MIN
+    all-reduce)."""
     import torch
     import torch.distributed as dist
-    from . import engine
+    from . import _lib, engine
     if wire not in ("auto", "u16x2", "u16", "u32"):
         raise ValueError("wire must be auto, u16x2, u16 or u32")
     if wire in ("u16", "u16x2") and total_trees >= (1 << 16):
         raise ValueError("a u16 wire format needs fewer than 65536 trees in total")
-    if wire == "auto":
-        wire = "u16" if total_trees < (1 << 16) else "u32"
-    bits = 32 if wire == "u32" else 16
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     multi = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
     stream = torch.cuda.current_stream(dev)
     ctx = engine.Context(ref.n_taxa, 32, device=dev.index or 0, stream=stream.cuda_stream)
-    t_chunk, words = scatter_layout(ctx.table_tuples, world, wire)
-    send = torch.zeros(world * words, dtype=torch.int32, device=dev)
-    if wire == "u16x2":
-        # counted straight into the wire words (QS_COUNT_WIRE16X2): no table, no pack pass; the library refuses
-        # batches that are not binary with all taxa
-        ctx.wire_attach(send)
-        if local_batch.n_trees:
-            hb = ctx.batch_upload(local_batch, with_nodes=False)
-            try:
+    hb = ctx.batch_upload(local_batch, with_nodes=(algo == engine.QS_ALGO_SCATTER)) if local_batch.n_trees else None
+    try:
+        if wire == "auto":   # the narrowest format the trees allow, the same on every rank
+            if total_trees >= (1 << 16):
+                wire = "u32"
+            else:
+                both = _lib.QS_BATCH_ALL_TAXA | _lib.QS_BATCH_BINARY
+                ok = 1 if (hb is None or (ctx.batch_flags(hb) & both) == both) and algo != engine.QS_ALGO_SCATTER else 0
+                if multi and world > 1:
+                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                    ok = int(flag.item())
+                wire = "u16x2" if ok else "u16"
+        bits = 32 if wire == "u32" else 16
+        t_chunk, words = scatter_layout(ctx.table_tuples, world, wire)
+        send = torch.zeros(world * words, dtype=torch.int32, device=dev)
+        if wire == "u16x2":
+            # counted straight into the wire words (QS_COUNT_WIRE16X2): no table, no pack pass; the library refuses
+            # batches that are not binary with all taxa
+            ctx.wire_attach(send)
+            if hb is not None:
                 ctx.count_batch(hb, engine.QS_ALGO_GATHER | engine.QS_COUNT_WIRE16X2)
-                ctx.sync()
-            finally:
-                ctx.batch_free(hb)
-    else:
-        if wire == "u32":
-            ctx.table_attach(send)                 # counted in place, padded to world chunks
         else:
-            table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
-            ctx.table_attach(table)
-        if local_batch.n_trees:
-            ctx.count_trees(local_batch, algo)
-        if wire == "u16":
-            ctx.table_pack16(send)
+            if wire == "u32":
+                ctx.table_attach(send)                 # counted in place, padded to world chunks
+            else:
+                table = torch.zeros(table_words(ctx.table_tuples, 32), dtype=torch.int32, device=dev)
+                ctx.table_attach(table)
+            if hb is not None:
+                ctx.count_batch(hb, algo)
+            if wire == "u16":
+                ctx.table_pack16(send)
+        ctx.sync()
+    finally:
+        if hb is not None:
+            ctx.batch_free(hb)
     recv = torch.zeros(words, dtype=torch.int32, device=dev)
     reduce_scatter_table(send, recv, group)
     rank_lo, n_owned = scatter_owned(ctx.table_tuples, world, rank, wire)

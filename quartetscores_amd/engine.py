@@ -141,6 +141,10 @@ class Context:
         del keep
         return h
 
+    def batch_flags(self, hb) -> int:
+        """_lib.QS_BATCH_ALL_TAXA | _lib.QS_BATCH_BINARY as found by the upload's validation."""
+        return int(self.L.qs_batch_flags(hb))
+
     def batch_free(self, hb):
         self.L.qs_batch_free(self.h, hb)
 
@@ -225,16 +229,7 @@ class Context:
 
     def score_finish(self, ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32):
         """sums_host: int64[3P]; cand_host: int64[parts, 8P] (gathered over the shards)."""
-        s, keep = self._ref_struct(ref)
-        sums_host = np.ascontiguousarray(sums_host, dtype=np.int64)
-        cand_host = np.ascontiguousarray(cand_host, dtype=np.int64)
-        parts = cand_host.size // (_lib.QS_SCORE_CAND_SLOTS * (sums_host.size // 3))
-        lq = np.zeros(ref.n_nodes); qp = np.zeros(ref.n_nodes); eqp = np.zeros(ref.n_nodes)
-        bif = C.c_int(0)
-        self._chk(self.L.qs_score_finish(self.h, C.byref(s), flags, sums_host.ctypes.data_as(C.c_void_p),
-                                         cand_host.ctypes.data_as(C.c_void_p), parts, lq.ctypes.data_as(C.c_void_p),
-                                         qp.ctypes.data_as(C.c_void_p), eqp.ctypes.data_as(C.c_void_p), C.byref(bif)))
-        return lq, qp, eqp, bool(bif.value)
+        return score_finish_host(ref, sums_host, cand_host, flags, _ctx=self)
 
     def raw_qic(self, ref: flatten.RefTree, r0: int, nq: int):
         s, keep = self._ref_struct(ref)
@@ -243,6 +238,25 @@ class Context:
         self._chk(self.L.qs_raw_qic(self.h, C.byref(s), r0, nq, topo.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)))
         del keep
         return topo, q
+
+
+def score_finish_host(ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32, _ctx=None):
+    """qs_score_finish: pure host arithmetic on the reduced per-node-pair sums and the gathered candidates (no device
+    needed; `_ctx` only lends its cached reference tree). sums_host: int64[3P]; cand_host: int64[parts, 8P]."""
+    L = _lib.load()
+    s, keep = Context._ref_struct(ref)
+    sums_host = np.ascontiguousarray(sums_host, dtype=np.int64)
+    cand_host = np.ascontiguousarray(cand_host, dtype=np.int64)
+    parts = cand_host.size // (_lib.QS_SCORE_CAND_SLOTS * (sums_host.size // 3))
+    lq = np.zeros(ref.n_nodes); qp = np.zeros(ref.n_nodes); eqp = np.zeros(ref.n_nodes)
+    bif = C.c_int(0)
+    h = _ctx.h if _ctx is not None else None
+    rc = L.qs_score_finish(h, C.byref(s), flags, sums_host.ctypes.data_as(C.c_void_p), cand_host.ctypes.data_as(C.c_void_p), parts,
+                           lq.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p), eqp.ctypes.data_as(C.c_void_p), C.byref(bif))
+    if rc != 0:
+        raise QSError(rc, L.qs_last_error(h).decode())
+    del keep
+    return lq, qp, eqp, bool(bif.value)
 
 
 def _read_eval(eval_trees) -> List[str]:

@@ -57,3 +57,106 @@ def swar_step(bits, mode, ab, cd, ac, bd, ad, bc):
     if mode == 2:
         hv = ~((ab | cd) << 2) & H & 0xFFFFFFFF
     return pop(t & hv), pop(~x & hv & 0xFFFFFFFF), pop(v & hv)
+
+
+# ---- scoring passes (qs_score.hip) on numpy arrays: stands in for a GPU context in the multi-process CPU tests ----
+
+def _sortable(v):
+    """order-preserving int64 encoding of float64 (qs_common.hpp f64_to_sortable)."""
+    i = np.asarray(v, dtype=np.float64).view(np.int64).astype(object)
+    out = np.array([int(x) if x >= 0 else (-(2 ** 63) - int(x)) for x in np.atleast_1d(i)], dtype=object)
+    return np.array([int(x) for x in out], dtype=np.int64)
+
+
+def _unsortable(s):
+    s = int(s)
+    i = s if s >= 0 else (-(2 ** 63) - s)
+    return np.array([i], dtype=np.int64).view(np.float64)[0]
+
+
+class ScoreEmu:
+    """The three methods distributed.score_sharded calls on a context, for the tuples [rank_lo, rank_lo + len(T)) of a
+    count table T ((k,3) array): classify every quartet like qs_score.hip::classify, per node pair 64-bit sums and the
+    minimum QIC (pass 1), the gcd-reduced near-minimal triples (pass 2). The finish is the library's own host code."""
+    KSORT_MAX = 0x7F7F7F7F7F7F7F7F
+
+    def __init__(self, ref, T, rank_lo):
+        from helpers import quads_in_rank_order
+        self.ref, self.T, self.rank_lo = ref, np.asarray(T, dtype=np.int64), int(rank_lo)
+        n, N = ref.n_taxa, ref.n_nodes
+        par = ref.parent
+        depth = np.zeros(N, dtype=np.int64)
+        for v in range(N):       # preorder numbering: parents come first
+            if par[v] >= 0:
+                depth[v] = depth[par[v]] + 1
+        nchild = np.bincount(par[par >= 0], minlength=N)
+        inner_id = -np.ones(N, dtype=np.int64)
+        inner_id[nchild > 0] = np.arange(int((nchild > 0).sum()))
+        self.n_inner = int((nchild > 0).sum())
+        lca = np.zeros((n, n), dtype=np.int64)
+        for i in range(n):
+            for j in range(i + 1, n):
+                x, y = int(ref.leaf_node[i]), int(ref.leaf_node[j])
+                while x != y:
+                    if depth[x] >= depth[y]:
+                        x = int(par[x])
+                    else:
+                        y = int(par[y])
+                lca[i, j] = lca[j, i] = x
+        self.lca, self.depth, self.inner_id = lca, depth, inner_id
+        self.bif = int((nchild + (par >= 0)).max() - 1) == 2
+        self.quads = quads_in_rank_order(n)[self.rank_lo:self.rank_lo + len(self.T)]
+
+    def score_pair_slots(self, ref):
+        return self.n_inner * self.n_inner
+
+    def _classified(self):
+        from quartetscores_amd.engine import log_score
+        frame = 0 if self.bif else 1
+        for (a, b, c, d), (n0, n1, n2) in zip(self.quads, self.T):
+            e01, e12, e23 = self.lca[a, b], self.lca[b, c], self.lca[c, d]
+            d01, d12, d23 = self.depth[e01], self.depth[e12], self.depth[e23]
+            mx = max(d01, d23)
+            if d12 < mx:
+                q = (n0, n1, n2)
+                j1 = e01 if d01 > d12 else e12
+                j2 = e23 if d23 > d12 else e12
+            elif d12 > mx:
+                q = (n2, n1, n0) if frame == 0 else (n2, n0, n1)
+                j1 = e12
+                j2 = e01 if d01 >= d23 else e23
+            else:
+                continue
+            i1, i2 = int(self.inner_id[j1]), int(self.inner_id[j2])
+            key = min(i1, i2) * self.n_inner + max(i1, i2)
+            yield key, tuple(int(x) for x in q), log_score(*(int(x) for x in q))
+
+    def score_pass1(self, ref, sums, mins):
+        s = np.zeros(sums.numel(), dtype=np.int64)
+        m = np.full(mins.numel(), self.KSORT_MAX, dtype=np.int64)
+        for key, q, qic in self._classified():
+            s[3 * key:3 * key + 3] += q
+            m[key] = min(int(m[key]), int(_sortable(qic)[0]))
+        sums.copy_(__import__("torch").from_numpy(s))
+        mins.copy_(__import__("torch").from_numpy(m))
+
+    def score_pass2(self, ref, mins, cand):
+        import math
+        mn = mins.numpy()
+        out = -np.ones(cand.numel(), dtype=np.int64)
+        for key, q, qic in self._classified():
+            if not qic <= _unsortable(mn[key]) + 1e-12:
+                continue
+            g = math.gcd(math.gcd(q[0], q[1]), q[2]) or 1
+            packed = ((q[0] // g) << 42) | ((q[1] // g) << 21) | (q[2] // g)
+            slots = out[8 * key:8 * key + 8]
+            if packed in slots:
+                continue
+            free = np.where(slots == -1)[0]
+            assert len(free), "candidate overflow"
+            slots[free[0]] = packed
+        cand.copy_(__import__("torch").from_numpy(out))
+
+    def score_finish(self, ref, sums_host, cand_host, flags=0):
+        from quartetscores_amd.engine import score_finish_host
+        return score_finish_host(ref, sums_host, cand_host, flags)

@@ -138,3 +138,65 @@ def test_packed_u16_sum_has_no_cross_carry():
     b = rng.integers(0, 30000, size=1000, dtype=np.uint16)
     s = (a.view(np.int32) + b.view(np.int32)).view(np.uint16)
     assert (s == a + b).all()
+
+
+def _score_worker(rank, world, port, bif, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulate
+    from quartetscores_amd import distributed, flatten, ranks, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m = 11, 40
+    ref_nw = synth.reference_tree(n, 31) if bif else "((t0,t1,t2),(t3,t4),(t5,(t6,t7,t8)),(t9,t10));"
+    ref = flatten.flatten_reference(ref_nw)
+    trees = synth.tree_set(n, m, 32, collapse=0.15)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    nq = ranks.n_quartets(n)
+    full = emulate.counts_from_batch(batch, n)
+    # the shard this rank would hold after the reduce-scatter of the table
+    r_lo, n_own = distributed.scatter_owned(nq, world, rank, 32)
+    ctx = emulate.ScoreEmu(ref, full[r_lo:r_lo + n_own], r_lo)
+    lq, qp, eqp, is_bif = distributed.score_sharded(ctx, ref, device=torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"lq{rank}.npy"), lq)
+    if is_bif:
+        np.save(os.path.join(out_dir, f"qp{rank}.npy"), qp)
+        np.save(os.path.join(out_dir, f"eqp{rank}.npy"), eqp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bif", [True, False])
+def test_score_sharded_sum_min_allgather_plumbing(tmp_path, bif):
+    """distributed.score_sharded over 2 gloo ranks, each holding half of the tuples (the numpy emulation of score pass
+    1 / 2 stands in for the kernels, the finish is the library's host code): SUM of the sums, MIN of the minima,
+    all-gather of the candidates give the oracle's scores exactly, on every rank (QuartetScoreComputer.hpp:379-593)."""
+    from oracle_api import Oracle
+    from quartetscores_amd import flatten, newick, synth
+    world = 2
+    mp.spawn(_score_worker, args=(world, _free_port(), bif, str(tmp_path)), nprocs=world, join=True)
+    n = 11
+    ref_nw = synth.reference_tree(n, 31) if bif else "((t0,t1,t2),(t3,t4),(t5,(t6,t7,t8)),(t9,t10));"
+    trees = synth.tree_set(n, 40, 32, collapse=0.15)
+    o = Oracle(ref_nw)
+    o.count("\n".join(trees))
+    o.score()
+    want = o.scores_by_bipartition()
+    ref = flatten.flatten_reference(ref_nw)
+    names = ref.names
+    for r in range(world):
+        lq = np.load(tmp_path / f"lq{r}.npy")
+        qp = np.load(tmp_path / f"qp{r}.npy") if bif else None
+        eqp = np.load(tmp_path / f"eqp{r}.npy") if bif else None
+        got = {}
+        for e in range(ref.n_nodes - 1):
+            below = frozenset(x.name for x in newick.preorder(ref.nodes[e + 1]) if x.is_leaf)
+            if len(below) <= 1 or len(below) >= n - 1:
+                continue
+            other = frozenset(names) - below
+            key = below if (len(below) < len(other) or (len(below) == len(other) and min(names) not in below)) else other
+            got[key] = (lq[e + 1], None if qp is None else qp[e + 1], None if eqp is None else eqp[e + 1])
+        assert set(got) == set(want)
+        for k in got:
+            assert got[k] == want[k], (r, sorted(k), got[k], want[k])
