@@ -29,6 +29,7 @@ struct RefHost {
     std::vector<int32_t> parent;
     std::vector<uint32_t> depth, nchild, inner_id, inner_node;
     std::vector<uint32_t> lca; // n*n
+    std::vector<uint16_t> next; // n*n: for a < b the first a' > a with lca(a',b) != lca(a,b) (b if none): run ends of the score scan
     std::vector<uint32_t> leaf_node_in; // the caller's leaf_node array (cache key)
     bool bifurcating = false;
 };
@@ -69,7 +70,7 @@ struct qs_ctx {
     uint64_t tune_slice_bytes = 0; // 0 = automatic
     uint32_t tune_gather_impl = 0; // QS_IMPL_*
     uint32_t tune_panel_kernel = 0;
-    double *dev_logk = nullptr, *dev_invk = nullptr; // tables of the device QIC (qs_score.hip), tbl_n entries each
+    double *dev_logk = nullptr;    // log(k) table of the device QIC (qs_score.hip), tbl_n entries
     uint32_t tbl_n = 0;
     // scoring view (qs_score_set_view): tuples [view_rank_lo, view_rank_lo + view_n) in caller-owned device memory
     const void *view_table = nullptr;
@@ -81,6 +82,7 @@ struct qs_ctx {
     // raw_qic / finish of one scoring run all get the same tree: built once, not three times)
     RefHost *ref_cache = nullptr;
     uint32_t *ref_lca_dev = nullptr;
+    uint16_t *ref_next_dev = nullptr;
 };
 
 static std::string g_create_err;
@@ -294,12 +296,12 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->dprefix3) (void)hipFree(c->dprefix3);
     for (int w = 0; w < 2; ++w) if (c->perm[w]) (void)hipFree(c->perm[w]);
     if (c->dev_logk) (void)hipFree(c->dev_logk);
-    if (c->dev_invk) (void)hipFree(c->dev_invk);
     if (c->dprefix1t) (void)hipFree(c->dprefix1t);
     if (c->cprefix3) (void)hipFree(c->cprefix3);
     if (c->dev_flags) (void)hipFree(c->dev_flags);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->ref_lca_dev) (void)hipFree(c->ref_lca_dev);
+    if (c->ref_next_dev) (void)hipFree(c->ref_next_dev);
     delete c->ref_cache;
     delete c;
 }
@@ -886,6 +888,12 @@ static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
             R.lca[(size_t)j * n + i] = e;
         }
     }
+    R.next.assign((size_t)n * n, 0);
+    for (uint32_t b = 1; b < n; ++b) {
+        R.next[(size_t)b * n + (b - 1)] = (uint16_t)b;
+        for (uint32_t a = b - 1; a-- > 0;)
+            R.next[(size_t)b * n + a] = R.lca[(size_t)b * n + a] != R.lca[(size_t)b * n + a + 1] ? (uint16_t)(a + 1) : R.next[(size_t)b * n + a + 1];
+    }
     return QS_OK;
 }
 
@@ -902,13 +910,15 @@ static int get_ref(qs_ctx *c, const qs_ref_tree *ref, bool want_dev, const RefHo
         int rc = build_ref(c, ref, *fresh);
         if (rc != QS_OK) { delete fresh; return rc; }
         fresh->leaf_node_in.assign(ref->leaf_node, ref->leaf_node + ref->n_taxa);
-        if (c->ref_lca_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ref_lca_dev); c->ref_lca_dev = nullptr; }
+        if (c->ref_lca_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ref_lca_dev); (void)hipFree(c->ref_next_dev); c->ref_lca_dev = nullptr; c->ref_next_dev = nullptr; }
         delete c->ref_cache;
         c->ref_cache = R = fresh;
     }
     if (want_dev && !c->ref_lca_dev) {
         QS_HIP(c, hipMalloc(&c->ref_lca_dev, R->lca.size() * 4));
+        QS_HIP(c, hipMalloc(&c->ref_next_dev, R->next.size() * 2));
         QS_HIP(c, hipMemcpyAsync(c->ref_lca_dev, R->lca.data(), R->lca.size() * 4, hipMemcpyHostToDevice, c->stream));
+        QS_HIP(c, hipMemcpyAsync(c->ref_next_dev, R->next.data(), R->next.size() * 2, hipMemcpyHostToDevice, c->stream));
     }
     *out = R;
     return QS_OK;
@@ -926,21 +936,21 @@ static int ensure_score_tables(qs_ctx *c) {
     const uint64_t want64 = std::min<uint64_t>(std::max<uint64_t>(c->trees_counted + 1, 65536), 1ull << 20);
     const uint32_t want = (uint32_t)want64;
     if (c->tbl_n >= want) return QS_OK;
-    if (c->dev_logk) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dev_logk); (void)hipFree(c->dev_invk); c->dev_logk = c->dev_invk = nullptr; c->tbl_n = 0; }
-    std::vector<double> lk(want), ik(want);
-    lk[0] = 0.0; ik[0] = 0.0;
-    for (uint32_t k = 1; k < want; ++k) { lk[k] = std::log((double)k); ik[k] = 1.0 / (double)k; }
+    if (c->dev_logk) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dev_logk); c->dev_logk = nullptr; c->tbl_n = 0; }
+    std::vector<double> lk(want);
+    lk[0] = 0.0;
+    for (uint32_t k = 1; k < want; ++k) lk[k] = std::log((double)k);
     QS_HIP(c, hipMalloc(&c->dev_logk, (size_t)want * 8));
-    QS_HIP(c, hipMalloc(&c->dev_invk, (size_t)want * 8));
     QS_HIP(c, hipMemcpy(c->dev_logk, lk.data(), (size_t)want * 8, hipMemcpyHostToDevice));
-    QS_HIP(c, hipMemcpy(c->dev_invk, ik.data(), (size_t)want * 8, hipMemcpyHostToDevice));
     c->tbl_n = want;
     return QS_OK;
 }
 
 static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t *lca_dev, ScoreDevice &sd) {
-    sd.logk = c->dev_logk; sd.invk = c->dev_invk; sd.tbl_n = c->tbl_n;
-    sd.ref_lca = lca_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
+    sd.logk = c->dev_logk; sd.tbl_n = c->tbl_n;
+    // as much of the log table as fits goes to LDS (every tuple sum of up to 15743 trees); larger arguments are range-checked
+    sd.lds_n = (uint32_t)std::min<uint64_t>(c->tbl_n, score_scan_max_lds_log());
+    sd.ref_lca = lca_dev; sd.ref_next = c->ref_next_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
     if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;

@@ -90,13 +90,17 @@ struct ScoreDevice {
     long long *pair_min;           // n_inner*n_inner (f64_to_sortable of the device QIC)
     unsigned long long *pair_cand; // n_inner*n_inner*kCand
     uint32_t *flags;               // [0] candidate overflow
-    const double *logk, *invk;     // log(k) (0 at k = 0) and 1/k for k < tbl_n: integer arguments of the device QIC
+    const uint16_t *ref_next; // n*n: for a < b the first a' > a with lca(a',b) != lca(a,b), b if there is none
+    const double *logk;            // log(k) (0 at k = 0) for k < tbl_n: integer arguments of the device QIC
     uint32_t tbl_n;
+    uint32_t lds_n;                // leading entries of logk the scan kernel keeps in LDS
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
                                    //    order of the multifurcating / raw-QIC loops (QSC:551-558, 661-668)
 };
 constexpr int kCand = 8;
 constexpr unsigned long long kCandEmpty = ~0ull;
+constexpr unsigned long long kCandOverflow = ~0ull - 1; // in the LAST slot of a node pair: its slots did not suffice (qs_score_overflow)
+uint32_t score_scan_max_lds_log();
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd);
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol);
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,

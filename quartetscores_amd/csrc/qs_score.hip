@@ -29,28 +29,6 @@
 
 namespace qs {
 
-// QuartetScoreComputer.hpp:135-159 (device evaluation; only used to ORDER candidates -- the host re-evaluates the
-// near-minimal ones with libm). With s = q1+q2+q3:  sum_i (q_i/s) log(q_i/s) = (sum_i q_i log q_i) / s - log s,
-// and every argument is a small integer (<= number of trees), so log k and 1/k come from tables built on the host:
-// 4 lookups + a handful of f64 ops instead of 3 divisions + 3 logs. Values beyond the tables take the slow path.
-__device__ __forceinline__ double dev_logk(const ScoreDevice &sd, uint32_t k) {
-    return k < sd.tbl_n ? sd.logk[k] : log((double)k);
-}
-__device__ __forceinline__ double dev_log_score(const ScoreDevice &sd, uint32_t q1, uint32_t q2, uint32_t q3) {
-    if ((q1 | q2 | q3) == 0) return 0.0;
-    const uint64_t s64 = (uint64_t)q1 + q2 + q3;
-    const double inv_log3 = 0.91023922662683739361;
-    double acc = 0.0; // sum q_i log q_i (0 log 0 = 0: logk[0] is stored as 0)
-    acc += (double)q1 * dev_logk(sd, q1);
-    acc += (double)q2 * dev_logk(sd, q2);
-    acc += (double)q3 * dev_logk(sd, q3);
-    double inv_s, log_s;
-    if (s64 < sd.tbl_n) { inv_s = sd.invk[s64]; log_s = sd.logk[s64]; }
-    else { inv_s = 1.0 / (double)s64; log_s = log((double)s64); }
-    const double qic = 1.0 + (acc * inv_s - log_s) * inv_log3;
-    return (q1 < q2 || q1 < q3) ? -qic : qic;
-}
-
 // Ranks are walked in blocks of consecutive values: the block's first rank is un-ranked once (f64 sqrt / cbrt,
 // ~300 instructions), every other rank of the block from it: rank = C(d,4) + C(c,3) + (C(b,2) + a), so adding `off`
 // to the pair rank and carrying into c (and d) is enough; unrank2 is a float sqrt and two corrections.
@@ -109,118 +87,114 @@ __device__ __forceinline__ QuartetRef classify(const ScoreDevice &sd, uint64_t l
     return r;
 }
 
-// ---- pass 1 -----------------------------------------------------------------------------
-// A workgroup walks kP1Iters * 256 consecutive ranks. Consecutive ranks vary the smallest id a,
-// and along a the owning node pair is piecewise constant, so (1) each wave first reduces its
-// runs of equal keys with a segmented scan (shuffles), (2) the run tails add into a small
-// open-addressing hash table in LDS (ds atomics), (3) the table is flushed once with global
-// atomics. This cuts the global atomics from 4 per quartet to 4 per distinct pair per workgroup.
-constexpr int kP1Iters = 16;      // passes of 256 ranks per workgroup (pass 2, raw QIC; lower bound for pass 1)
-constexpr int kP1ItersMax = 64;   // pass 1 on large tables: 4x fewer hash flushes (global atomics) per quartet
-constexpr int kP1Slots = 1024; // power of two
+// ---- pass 1 / pass 2: one scan of the table -------------------------------------------------
+// The round-1 kernels gave every lane one rank at a time: un-rank, three LCA lookups, a device QIC with four 8-byte
+// gathers from the log tables (64 different cache lines per wave instruction), then a segmented scan over the wave and
+// an LDS hash -- about 310 wave instructions per 64 quartets, 28 ms for the 34 GB table of 512 taxa (1.2 TB/s).
+// This kernel walks the ranks lane-SEQUENTIALLY: a lane owns kSK consecutive ranks of a chunk and keeps its quartet
+// (a,b,c,d) in registers, incrementing a. Ranks are consecutive in a, and along a row (b,c,d fixed) the reference
+// topology and the owning node pair only change where lca(a,b) changes -- at the precomputed breakpoints ref_next[b][a]
+// (lca(a,b) climbs down b's ancestor chain as a approaches b; about one change per 11 quartets at 512 taxa). Between
+// two changes a quartet costs its tuple, the count permutation, the device QIC and four adds: no un-ranking, no LCA
+// lookup, no cross-lane operation; a finished run goes to the workgroup's LDS hash (pass 1) in one insert. log(k) of
+// the integer arguments comes from a copy of the table in LDS (<= 15744 entries = every count of up to 15743 trees; 126
+// KB), which is why a workgroup is 1024 threads: one per CU, 16 waves. A workgroup takes rounds of 16 x 512 consecutive
+// ranks and flushes the hash to memory after each round (the keys of 8192 consecutive ranks fit its 1024 slots).
+constexpr int kSK = 8;                              // consecutive ranks per lane and chunk
+constexpr int kSThreads = 1024;                     // 16 waves
+constexpr int kSChunk = kWave * kSK;                // ranks per wave and round (512)
+constexpr int kSRound = (kSThreads / kWave) * kSChunk; // ranks per workgroup and round (8192)
+constexpr int kSSlots = 1024;                       // hash slots (power of two) = one per thread at the flush
 constexpr uint32_t kKeyEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kScanMaxLdsLog = 15744;          // (160 KB - 36 KB hash - slack) / 8
 
-struct P1Lds {
-    uint32_t key[kP1Slots];
-    unsigned long long sum[kP1Slots * 3];
-    long long mn[kP1Slots];
+// log(k) of the four integer arguments of one quartet's QIC. Usual case: all below lds_n, four LDS reads behind ONE
+// range check; otherwise (counts beyond the LDS copy) the global table, beyond that libm's log -- out of line.
+struct Logs4 { double l1, l2, l3, ls; };
+__device__ __noinline__ Logs4 scan_logs_slow(const double *__restrict__ logk, uint32_t tbl_n, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t s) {
+    Logs4 r;
+    r.l1 = q1 < tbl_n ? logk[q1] : log((double)q1);
+    r.l2 = q2 < tbl_n ? logk[q2] : log((double)q2);
+    r.l3 = q3 < tbl_n ? logk[q3] : log((double)q3);
+    r.ls = s < tbl_n ? logk[s] : log((double)s);
+    if (q1 == 0) r.l1 = 0.0;   // 0 log 0 = 0 (the table stores 0 at k = 0)
+    if (q2 == 0) r.l2 = 0.0;
+    if (q3 == 0) r.l3 = 0.0;
+    return r;
+}
+// QuartetScoreComputer.hpp:135-159, device evaluation (orders candidates only; the host re-evaluates the near-minimal
+// ones with libm). sum_i (q_i/s) log(q_i/s) = (sum_i q_i log q_i) / s - log s with integer arguments <= number of trees.
+// 1/s: v_rcp_f64 + two Newton steps (the same code in both passes, so the values they compare agree).
+__device__ __forceinline__ double scan_qic(const double *__restrict__ lds_logk, const ScoreDevice &sd, uint32_t q1, uint32_t q2, uint32_t q3) {
+    if ((q1 | q2 | q3) == 0) return 0.0;
+    const uint64_t s64 = (uint64_t)q1 + q2 + q3;
+    const uint32_t s32 = (uint32_t)min(s64, (uint64_t)0xFFFFFFFFu); // (three u32 counts summing beyond 2^32: only ordering is at stake)
+    const double inv_log3 = 0.91023922662683739361;
+    Logs4 L;
+    if (s32 < sd.lds_n) { L.l1 = lds_logk[q1]; L.l2 = lds_logk[q2]; L.l3 = lds_logk[q3]; L.ls = lds_logk[s32]; } // q_i <= s
+    else L = scan_logs_slow(sd.logk, sd.tbl_n, q1, q2, q3, s32);
+    double acc = (double)q1 * L.l1;
+    acc += (double)q2 * L.l2;
+    acc += (double)q3 * L.l3;
+    const double sd_ = (double)s32;
+    double r = __builtin_amdgcn_rcp(sd_);
+    r = fma(fma(-sd_, r, 1.0), r, r);
+    r = fma(fma(-sd_, r, 1.0), r, r);
+    const double qic = 1.0 + (acc * r - L.ls) * inv_log3;
+    return (q1 < q2 || q1 < q3) ? -qic : qic;
+}
+
+struct ScanSeg { uint32_t key; uint32_t code; uint32_t end; }; // node pair, count permutation (3 = unresolved), first a of the next run
+// classification of the run that starts at (a,b,c,d): the same decision as classify() above
+__device__ __forceinline__ ScanSeg scan_classify(const ScoreDevice &sd, uint32_t a, uint32_t b, uint32_t e12, uint32_t e23) {
+    ScanSeg r;
+    const uint32_t e01 = sd.ref_lca[(size_t)b * sd.n + a];
+    r.end = sd.ref_next[(size_t)b * sd.n + a];
+    const uint32_t d01 = e01 >> 16, d12 = e12 >> 16, d23 = e23 >> 16;
+    const uint32_t mx = max(d01, d23);
+    uint32_t j1 = 0, j2 = 0;
+    if (d12 < mx) {        // ab|cd
+        r.code = 0;
+        j1 = (d01 > d12) ? (e01 & 0xFFFFu) : (e12 & 0xFFFFu);
+        j2 = (d23 > d12) ? (e23 & 0xFFFFu) : (e12 & 0xFFFFu);
+    } else if (d12 > mx) { // ad|bc
+        r.code = sd.frame == 0 ? 1u : 2u;
+        j1 = e12 & 0xFFFFu;
+        j2 = (d01 >= d23) ? (e01 & 0xFFFFu) : (e23 & 0xFFFFu);
+    } else r.code = 3;
+    r.key = r.code == 3 ? kKeyEmpty : min(j1, j2) * sd.n_inner + max(j1, j2);
+    return r;
+}
+
+struct ScanLds {
+    uint32_t key[kSSlots];
+    unsigned long long sum[kSSlots * 3];
+    long long mn[kSSlots];
 };
 
-__device__ __forceinline__ void p1_global_add(const ScoreDevice &sd, uint32_t key, unsigned long long s1,
-                                              unsigned long long s2, unsigned long long s3, long long mn) {
+__device__ __forceinline__ void scan_global_add(const ScoreDevice &sd, uint32_t key, unsigned long long s1, unsigned long long s2,
+                                                unsigned long long s3, long long mn) {
     atomicAdd(&sd.pair_sums[(size_t)key * 3 + 0], s1);
     atomicAdd(&sd.pair_sums[(size_t)key * 3 + 1], s2);
     atomicAdd(&sd.pair_sums[(size_t)key * 3 + 2], s3);
     atomicMin(&sd.pair_min[key], mn);
 }
-
-// lane l <- lane l - k of the same 16-lane row (DPP row_shr:k, CTRL = 0x110 + k); lanes without a source get `old`
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_shr(uint32_t old, uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
-}
-template <int CTRL> __device__ __forceinline__ unsigned long long dpp_shr64(unsigned long long v) {
-    const uint32_t lo = dpp_shr<CTRL>(0u, (uint32_t)v), hi = dpp_shr<CTRL>(0u, (uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <int CTRL>
-__device__ __forceinline__ void seg_step(uint32_t run, unsigned long long &s1, unsigned long long &s2, unsigned long long &s3,
-                                         long long &mn) {
-    const uint32_t orun = dpp_shr<CTRL>(0xFFFFFFFFu, run);
-    const unsigned long long o1 = dpp_shr64<CTRL>(s1), o2 = dpp_shr64<CTRL>(s2), o3 = dpp_shr64<CTRL>(s3);
-    const long long om = (long long)dpp_shr64<CTRL>((unsigned long long)mn);
-    if (orun == run) { s1 += o1; s2 += o2; s3 += o3; mn = om < mn ? om : mn; }
-}
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <int SRC>
-__device__ __forceinline__ void seg_carry(uint32_t lane, uint32_t run, unsigned long long &s1, unsigned long long &s2,
-                                          unsigned long long &s3, long long &mn) {
-    const uint32_t crun = (uint32_t)__builtin_amdgcn_readlane((int)run, SRC);
-    const unsigned long long c1 = readlane64(s1, SRC), c2 = readlane64(s2, SRC), c3 = readlane64(s3, SRC);
-    const long long cm = (long long)readlane64((unsigned long long)mn, SRC);
-    if (lane > (uint32_t)SRC && lane <= (uint32_t)SRC + 16 && run == crun) { s1 += c1; s2 += c2; s3 += c3; mn = cm < mn ? cm : mn; }
-}
-
-template <typename CT>
-__global__ __launch_bounds__(256) void score_pass1_kernel(ScoreDevice sd, int iters) {
-    __shared__ P1Lds lds;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    for (uint32_t i = tid; i < kP1Slots; i += 256) {
-        lds.key[i] = kKeyEmpty;
-        lds.sum[3 * i] = lds.sum[3 * i + 1] = lds.sum[3 * i + 2] = 0;
-        lds.mn[i] = kSortableMax;
-    }
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * (256ull * iters);
-    Ids4 base_ids;
-    unrank4(base + sd.rank_lo, base_ids.a, base_ids.b, base_ids.c, base_ids.d);
-    for (int it = 0; it < iters; ++it) {
-        const uint64_t r = base + (uint64_t)it * 256 + tid;
-        QuartetRef q;
-        q.resolved = false; q.key = kKeyEmpty; q.q1 = q.q2 = q.q3 = 0;
-        if (r < sd.n_tuples) q = classify<CT>(sd, r, decode_near(base_ids, (uint32_t)it * 256 + tid));
-        const uint32_t key = q.resolved ? q.key : kKeyEmpty;
-        unsigned long long s1 = q.q1, s2 = q.q2, s3 = q.q3;
-        long long mn = q.resolved ? f64_to_sortable(dev_log_score(sd, q.q1, q.q2, q.q3)) : kSortableMax;
-        // runs of equal keys inside the wave
-        const uint32_t prev = __shfl_up(key, 1, 64);
-        const bool head = (lane == 0) || (prev != key);
-        const unsigned long long heads = __ballot(head);
-        const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
-        // segmented inclusive scan over the runs: inside each row of 16 lanes with DPP row shifts (VALU, no LDS
-        // traffic; the ds_bpermute version of this scan was what bounded the kernel), then the last lane of each
-        // row is carried into the lanes of the next row that continue its run (3 readlane steps)
-        seg_step<0x111>(run, s1, s2, s3, mn);
-        seg_step<0x112>(run, s1, s2, s3, mn);
-        seg_step<0x114>(run, s1, s2, s3, mn);
-        seg_step<0x118>(run, s1, s2, s3, mn);
-        seg_carry<15>(lane, run, s1, s2, s3, mn);
-        seg_carry<31>(lane, run, s1, s2, s3, mn);
-        seg_carry<47>(lane, run, s1, s2, s3, mn);
-        const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
-        if (tail && key != kKeyEmpty) {
-            uint32_t slot = (key * 2654435761u) >> 22; // 10 bits
-            bool done = false;
-            for (int probe = 0; probe < 32 && !done; ++probe) {
-                const uint32_t old = atomicCAS(&lds.key[slot], kKeyEmpty, key);
-                if (old == kKeyEmpty || old == key) {
-                    atomicAdd(&lds.sum[3 * slot + 0], s1);
-                    atomicAdd(&lds.sum[3 * slot + 1], s2);
-                    atomicAdd(&lds.sum[3 * slot + 2], s3);
-                    atomicMin(&lds.mn[slot], mn);
-                    done = true;
-                }
-                slot = (slot + 1) & (kP1Slots - 1);
-            }
-            if (!done) p1_global_add(sd, key, s1, s2, s3, mn); // table crowded: go straight to memory
+__device__ __forceinline__ void scan_flush(ScanLds &h, const ScoreDevice &sd, uint32_t key, unsigned long long s1, unsigned long long s2,
+                                           unsigned long long s3, long long mn) {
+    uint32_t slot = (key * 2654435761u) >> 22; // 10 bits
+#pragma unroll 1
+    for (int probe = 0; probe < 8; ++probe) {
+        const uint32_t old = atomicCAS(&h.key[slot], kKeyEmpty, key);
+        if (old == kKeyEmpty || old == key) {
+            atomicAdd(&h.sum[3 * slot + 0], s1);
+            atomicAdd(&h.sum[3 * slot + 1], s2);
+            atomicAdd(&h.sum[3 * slot + 2], s3);
+            atomicMin(&h.mn[slot], mn);
+            return;
         }
+        slot = (slot + 1) & (kSSlots - 1);
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < kP1Slots; i += 256)
-        if (lds.key[i] != kKeyEmpty) p1_global_add(sd, lds.key[i], lds.sum[3 * i], lds.sum[3 * i + 1], lds.sum[3 * i + 2], lds.mn[i]);
+    scan_global_add(sd, key, s1, s2, s3, mn); // crowded neighbourhood: straight to memory
 }
 
 __device__ __forceinline__ uint32_t gcd_u32(uint32_t x, uint32_t y) {
@@ -235,39 +209,123 @@ __device__ __forceinline__ uint32_t gcd_u32(uint32_t x, uint32_t y) {
     }
     return x << sh;
 }
-
-template <typename CT>
-__global__ __launch_bounds__(256) void score_pass2_kernel(ScoreDevice sd, double tol) {
-    const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
-    Ids4 base_ids;
-    unrank4(base + sd.rank_lo, base_ids.a, base_ids.b, base_ids.c, base_ids.d);
-    for (int it = 0; it < kP1Iters; ++it) {
-        const uint64_t r = base + (uint64_t)it * 256 + threadIdx.x;
-        if (r >= sd.n_tuples) return;
-        const QuartetRef q = classify<CT>(sd, r, decode_near(base_ids, (uint32_t)it * 256 + threadIdx.x));
-        if (!q.resolved) continue;
-        const double sc = dev_log_score(sd, q.q1, q.q2, q.q3);
-        const double mn = sortable_to_f64(sd.pair_min[q.key]);
-        if (!(sc <= mn + tol)) continue;
-        uint32_t g = gcd_u32(gcd_u32(q.q1, q.q2), q.q3);
-        if (g == 0) g = 1;
-        const uint32_t a = q.q1 / g, b = q.q2 / g, c = q.q3 / g;
-        if ((a | b | c) >> 21) { atomicOr(&sd.flags[0], 2u); continue; }
-        const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
-        unsigned long long *slots = sd.pair_cand + (size_t)q.key * kCand;
-        // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
-        bool placed = false;
-        for (int s = 0; s < kCand && !placed; ++s) {
-            unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == packed) placed = true;
-            else if (cur == kCandEmpty) {
-                unsigned long long old = atomicCAS(&slots[s], kCandEmpty, packed);
-                if (old == kCandEmpty || old == packed) placed = true;
-            }
+// pass 2: record the gcd-reduced triple of a near-minimal quartet (log_score(k q) is bit-identical to log_score(q))
+__device__ __noinline__ void scan_candidate(const ScoreDevice &sd, uint32_t key, uint32_t q1, uint32_t q2, uint32_t q3) {
+    uint32_t g = gcd_u32(gcd_u32(q1, q2), q3);
+    if (g == 0) g = 1;
+    const uint32_t a = q1 / g, b = q2 / g, c = q3 / g;
+    unsigned long long *slots = sd.pair_cand + (size_t)key * kCand;
+    if ((a | b | c) >> 21) {   // does not fit the packed slot: this node pair is finished by qs_score_overflow
+        atomicOr(&sd.flags[0], 2u);
+        __hip_atomic_store(&slots[kCand - 1], kCandOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
+    // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
+    for (int s = 0; s < kCand; ++s) {
+        unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == packed || cur == kCandOverflow) return;
+        if (cur == kCandEmpty) {
+            const unsigned long long old = atomicCAS(&slots[s], kCandEmpty, packed);
+            if (old == kCandEmpty || old == packed) return;
+            if (old == kCandOverflow) return;
         }
-        if (!placed) atomicOr(&sd.flags[0], 1u);
+    }
+    // more than kCand distinct near-minimal triples: mark the pair, qs_score_overflow lists its quartets
+    atomicOr(&sd.flags[0], 1u);
+    __hip_atomic_store(&slots[kCand - 1], kCandOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename CT> __device__ __forceinline__ void scan_load_tuple(const CT *p, uint32_t &n0, uint32_t &n1, uint32_t &n2) {
+    if (sizeof(CT) == 4) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+        const u32x3 v = *reinterpret_cast<const u32x3_a4 *>(p);
+        n0 = v.x; n1 = v.y; n2 = v.z;
+    } else { n0 = p[0]; n1 = p[1]; n2 = p[2]; }
+}
+
+template <typename CT, int PASS>
+__global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, uint32_t rounds_per_wg, double tol) {
+    extern __shared__ __align__(16) unsigned char scan_smem[];
+    ScanLds &hash = *reinterpret_cast<ScanLds *>(scan_smem);                   // used by pass 1 only
+    double *lds_logk = reinterpret_cast<double *>(scan_smem + (PASS == 1 ? sizeof(ScanLds) : 0));
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    for (uint32_t i = tid; i < sd.lds_n; i += kSThreads) lds_logk[i] = sd.logk[i];
+    if (PASS == 1) {
+        hash.key[tid] = kKeyEmpty;
+        hash.sum[3 * tid] = hash.sum[3 * tid + 1] = hash.sum[3 * tid + 2] = 0;
+        hash.mn[tid] = kSortableMax;
+    }
+    __syncthreads();
+    const CT *table = reinterpret_cast<const CT *>(sd.table);
+    const uint64_t wg_base = (uint64_t)blockIdx.x * rounds_per_wg * kSRound;
+    Ids4 st;
+    bool have = false;
+    for (uint32_t round = 0; round < rounds_per_wg; ++round) {
+        const uint64_t round_base = wg_base + (uint64_t)round * kSRound;
+        if (round_base >= sd.n_tuples) break;                                   // uniform over the workgroup
+        const uint64_t r0 = round_base + (uint64_t)wave * kSChunk + (uint64_t)lane * kSK;
+        const uint32_t cnt = r0 < sd.n_tuples ? (uint32_t)min((uint64_t)kSK, sd.n_tuples - r0) : 0u;
+        if (cnt > 0) {
+            if (!have) { unrank4(r0 + sd.rank_lo, st.a, st.b, st.c, st.d); have = true; }
+            else st = decode_near(st, kSRound);
+            uint32_t a = st.a, b = st.b, c = st.c, d = st.d;
+            uint32_t e12 = sd.ref_lca[(size_t)c * sd.n + b], e23 = sd.ref_lca[(size_t)d * sd.n + c];
+            ScanSeg seg = scan_classify(sd, a, b, e12, e23);
+            unsigned long long s1 = 0, s2 = 0, s3 = 0;
+            long long mn = kSortableMax;
+            double thr = 0.0;
+            if (PASS == 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
+            // the lane's kSK consecutive tuples, one ahead (the loop is NOT unrolled: the run-end block exists once)
+            const CT *tp = table + r0 * 3;
+            uint32_t n0, n1, n2, p0 = 0, p1 = 0, p2 = 0;
+            scan_load_tuple<CT>(tp, n0, n1, n2);
+#pragma unroll 1
+            for (uint32_t i = 0; i < cnt; ++i) {
+                if (i + 1 < cnt) scan_load_tuple<CT>(tp + (i + 1) * 3, p0, p1, p2);
+                if (a == seg.end) {       // the run ends here: next breakpoint of lca(a,b), or the end of the row
+                    if (PASS == 1 && seg.code != 3) scan_flush(hash, sd, seg.key, s1, s2, s3, mn);
+                    if (a == b) {         // next row: ranks carry a -> b -> c -> d
+                        a = 0; ++b;
+                        if (b == c) { b = 1; ++c; if (c == d) { c = 2; ++d; } }
+                        e12 = sd.ref_lca[(size_t)c * sd.n + b]; e23 = sd.ref_lca[(size_t)d * sd.n + c];
+                    }
+                    seg = scan_classify(sd, a, b, e12, e23);
+                    s1 = s2 = s3 = 0; mn = kSortableMax;
+                    if (PASS == 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
+                }
+                if (seg.code != 3) {
+                    const uint32_t q1 = seg.code == 0 ? n0 : n2;
+                    const uint32_t q2 = seg.code == 2 ? n0 : n1;
+                    const uint32_t q3 = seg.code == 0 ? n2 : (seg.code == 1 ? n0 : n1);
+                    const double qic = scan_qic(lds_logk, sd, q1, q2, q3);
+                    if (PASS == 1) {
+                        s1 += q1; s2 += q2; s3 += q3;
+                        const long long sq = f64_to_sortable(qic);
+                        mn = sq < mn ? sq : mn;
+                    } else if (qic <= thr) scan_candidate(sd, seg.key, q1, q2, q3);
+                }
+                ++a;
+                n0 = p0; n1 = p1; n2 = p2;
+            }
+            if (PASS == 1 && seg.code != 3) scan_flush(hash, sd, seg.key, s1, s2, s3, mn);
+        }
+        if (PASS == 1) {   // the hash holds the node pairs of this round's 8192 ranks: one slot per thread to memory
+            __syncthreads();
+            const uint32_t k = hash.key[tid];
+            if (k != kKeyEmpty) {
+                scan_global_add(sd, k, hash.sum[3 * tid], hash.sum[3 * tid + 1], hash.sum[3 * tid + 2], hash.mn[tid]);
+                hash.key[tid] = kKeyEmpty;
+                hash.sum[3 * tid] = hash.sum[3 * tid + 1] = hash.sum[3 * tid + 2] = 0;
+                hash.mn[tid] = kSortableMax;
+            }
+            __syncthreads();
+        }
     }
 }
+
+constexpr int kP1Iters = 16;      // passes of 256 ranks per workgroup (raw QIC)
 
 template <typename CT>
 __global__ __launch_bounds__(256) void raw_qic_kernel(ScoreDevice sd, uint64_t r0, uint64_t nq, uint8_t *__restrict__ topo,
@@ -285,25 +343,29 @@ __global__ __launch_bounds__(256) void raw_qic_kernel(ScoreDevice sd, uint64_t r
     }
 }
 
-hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
+template <typename CT, int PASS> static hipError_t launch_scan(hipStream_t s, const ScoreDevice &sd, double tol) {
     if (sd.n_tuples == 0) return hipSuccess;
-    // as many passes per workgroup as still leave >= 8192 workgroups (128 taxa: 16, from ~230 taxa on: 64)
-    const int iters = (int)std::min<uint64_t>(kP1ItersMax, std::max<uint64_t>(kP1Iters, sd.n_tuples / (256ull * 8192)));
-    const uint64_t per_block = 256ull * iters;
-    dim3 block(256), grid((unsigned)((sd.n_tuples + per_block - 1) / per_block));
-    if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass1_kernel<uint32_t>, grid, block, 0, s, sd, iters);
-    else hipLaunchKernelGGL(score_pass1_kernel<uint16_t>, grid, block, 0, s, sd, iters);
+    const uint64_t rounds = (sd.n_tuples + kSRound - 1) / kSRound;
+    // as many rounds per workgroup as still leave >= 2048 workgroups (a workgroup's first rank is un-ranked once)
+    const uint32_t rpw = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, rounds / 2048));
+    const size_t lds = (PASS == 1 ? sizeof(ScanLds) : 0) + (size_t)sd.lds_n * 8;
+    dim3 block(kSThreads), grid((unsigned)((rounds + rpw - 1) / rpw));
+    auto k = score_scan_kernel<CT, PASS>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, block, lds, s, sd, rpw, tol);
     return hipGetLastError();
 }
 
-hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) {
-    if (sd.n_tuples == 0) return hipSuccess;
-    const uint64_t per_block = 256ull * kP1Iters;
-    dim3 block(256), grid((unsigned)((sd.n_tuples + per_block - 1) / per_block));
-    if (sd.count_bits == 32) hipLaunchKernelGGL(score_pass2_kernel<uint32_t>, grid, block, 0, s, sd, tol);
-    else hipLaunchKernelGGL(score_pass2_kernel<uint16_t>, grid, block, 0, s, sd, tol);
-    return hipGetLastError();
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
+    return sd.count_bits == 32 ? launch_scan<uint32_t, 1>(s, sd, 0.0) : launch_scan<uint16_t, 1>(s, sd, 0.0);
 }
+
+hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) {
+    return sd.count_bits == 32 ? launch_scan<uint32_t, 2>(s, sd, tol) : launch_scan<uint16_t, 2>(s, sd, tol);
+}
+
+uint32_t score_scan_max_lds_log() { return kScanMaxLdsLog; }
 
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
                           unsigned long long *q_dev) {

@@ -1,20 +1,23 @@
-"""Wall time of the phases of qs_score (pass 1, pass 2, copies, host finalisation) at 128 and 256 taxa; run on a GPU box."""
+"""Wall time of the phases of qs_score (pass 1, pass 2, copies, host finalisation); run on a GPU box:
+    python tools/score_phases.py [taxa:trees ...]      default 128:1000 256:2000 512:10000"""
+import os
 import sys
 import time
 
 import torch
-import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from quartetscores_amd import engine, flatten, synth
-cases = [(int(a), 64) for a in sys.argv[1:]] or [(128, 1000), (256, 2000)]
+from quartetscores_amd import engine, flatten, native_ingest
+cases = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(128, 1000), (256, 2000), (512, 10000)]
 for n, m in cases:
-    ref_nw = synth.reference_tree(n, 2000)
-    trees = synth.tree_set(n, m, 2001)
+    ref_nw = native_ingest.synth_trees(n, 1, 2000).decode().strip()
     ref = flatten.flatten_reference(ref_nw)
-    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    batch, _ = native_ingest.ingest_text(ref_nw, native_ingest.synth_trees(n, m, 2001), want_ranges=False)
     ctx = engine.Context(n, 32)
     ctx.table_alloc()
-    ctx.count_trees(batch)
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    ctx.count_batch(hb)
+    ctx.sync()
+
     def t(f, reps=5):
         torch.cuda.synchronize(); best = 1e9
         for _ in range(reps):
@@ -29,4 +32,6 @@ for n, m in cases:
     sh, ch = sums.cpu().numpy(), cand.cpu().numpy()[None, :]
     ms3, _ = t(lambda: ctx.score_finish(ref, sh, ch))
     msd, _ = t(lambda: (sums.cpu(), cand.cpu()))
-    print(f"n={n}: qs_score {ms_all:.3f} ms | pass1 call {ms1:.3f} pass2 call {ms2:.3f} d2h {msd:.3f} finish {ms3:.3f}  P={P}")
+    gb = ctx.table_bytes / 1e9
+    print(f"n={n} m={m}: qs_score {ms_all:.3f} ms | pass1 {ms1:.3f} ({gb / ms1:.2f} TB/s) pass2 {ms2:.3f} ({gb / ms2:.2f} TB/s) d2h {msd:.3f} finish {ms3:.3f}  P={P} table {gb:.2f} GB")
+    ctx.close()
