@@ -150,6 +150,8 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_TILE_ORDER 4u        /* launch order of the count kernel's tiles: 0 = (d,c)-major (the order of the table);
                                       * chunk | cblock << 16 = (a,b)-major: b-block, chunks of `chunk` a-blocks, blocks of
                                       * `cblock` values of c, d-blocks (default 4 | 16 << 16) */
+#define QS_TUNE_SCORE_CAND_SLOTS 5u   /* candidate slots score pass 2 fills per node pair, 1..8 (default 8; tests force overflows) */
+#define QS_TUNE_SCORE_TOL_EXP 6u      /* pass 2 keeps count triples whose device QIC is within 10^-value of the pair's minimum (default 12) */
 #define QS_IMPL_AUTO 0u
 #define QS_IMPL_SWAR 1u
 #define QS_IMPL_BITSLICE 2u
@@ -238,8 +240,14 @@ int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, 
  *                    -> reduce over shards: SUM on sums_dev, MIN on min_dev (plain int64 reductions)
  *   qs_score_pass2 : cand_dev[QS_SCORE_CAND_SLOTS*P] = distinct gcd-reduced count triples of this context
  *                    whose QIC is within 1e-12 of min_dev (-1 = empty slot) -> all-gather over shards
- *   qs_score_finish: pure host arithmetic on the reduced sums and the n_cand_parts gathered candidate
- *                    arrays (each QS_SCORE_CAND_SLOTS*P long, concatenated) -> the three score vectors.
+ *                    A node pair with more than 8 such triples (or one whose reduced counts need more than 21
+ *                    bits) is MARKED in cand_dev instead of failing the run:
+ *   qs_score_overflow: lists every near-minimal quartet (key, q1, q2, q3; 4 int64 per entry, sorted, distinct) of
+ *                    this context's marked pairs into a malloc'ed host array (*list_out, free with qs_free_host;
+ *                    NULL / 0 when nothing was marked -- the usual case) -> concatenate over the shards
+ *   qs_score_finish: pure host arithmetic on the reduced sums, the n_cand_parts gathered candidate arrays (each
+ *                    QS_SCORE_CAND_SLOTS*P long, concatenated) and the n_extra listed quartets (may be NULL / 0)
+ *                    -> the three score vectors. ctx may be NULL (no device is touched).
  */
 #define QS_SCORE_CAND_SLOTS 8
 uint64_t qs_score_pair_slots(const qs_ref_tree *ref);
@@ -250,9 +258,12 @@ uint64_t qs_score_pair_slots(const qs_ref_tree *ref);
 int qs_score_set_view(qs_ctx *ctx, const void *table_dev, uint32_t count_bits, uint64_t rank_lo, uint64_t n_tuples);
 int qs_score_pass1(qs_ctx *ctx, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev);
 int qs_score_pass2(qs_ctx *ctx, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev);
+int qs_score_overflow(qs_ctx *ctx, const qs_ref_tree *ref, const int64_t *min_dev, const int64_t *cand_dev,
+                      int64_t **list_out, uint64_t *n_out);
+void qs_free_host(void *p);
 int qs_score_finish(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,
-                    const int64_t *cand_host, uint32_t n_cand_parts, double *lqic, double *qpic, double *eqpic,
-                    int *is_bifurcating);
+                    const int64_t *cand_host, uint32_t n_cand_parts, const int64_t *extra_host, uint64_t n_extra,
+                    double *lqic, double *qpic, double *eqpic, int *is_bifurcating);
 
 /*
  * Raw per-quartet QIC (numeric part of printRawQICScores): for ranks [r0, r0+nq) of this

@@ -18,6 +18,7 @@ QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
 QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
+QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP = 5, 6
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares
@@ -26,7 +27,7 @@ EXPORTS = [
     "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_wire_attach", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
-    "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags",
+    "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host",
 ]
 
 
@@ -123,7 +124,11 @@ def load():
     L.qs_score_pass2.restype = i32
     L.qs_score_pass2.argtypes = [vp, C.POINTER(RefTreeC), vp, vp]
     L.qs_score_finish.restype = i32
-    L.qs_score_finish.argtypes = [vp, C.POINTER(RefTreeC), u32, vp, vp, u32, vp, vp, vp, C.POINTER(i32)]
+    L.qs_score_finish.argtypes = [vp, C.POINTER(RefTreeC), u32, vp, vp, u32, vp, u64, vp, vp, vp, C.POINTER(i32)]
+    L.qs_score_overflow.restype = i32
+    L.qs_score_overflow.argtypes = [vp, C.POINTER(RefTreeC), vp, vp, C.POINTER(vp), C.POINTER(u64)]
+    L.qs_free_host.restype = None
+    L.qs_free_host.argtypes = [vp]
     L.qs_raw_qic.restype = i32
     L.qs_raw_qic.argtypes = [vp, C.POINTER(RefTreeC), u64, u64, vp, vp]
     L.qs_last_count_ms.restype = i32

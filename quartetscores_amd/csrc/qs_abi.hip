@@ -8,6 +8,7 @@
 #include "qs_internal.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -70,6 +71,8 @@ struct qs_ctx {
     uint64_t tune_slice_bytes = 0; // 0 = automatic
     uint32_t tune_gather_impl = 0; // QS_IMPL_*
     uint32_t tune_panel_kernel = 0;
+    uint32_t tune_cand_slots = kCand;  // candidate slots pass 2 fills per node pair (tests force overflows with fewer)
+    double tune_score_tol = 1e-12;     // pass 2 keeps triples whose device QIC is within this of the pair's minimum
     double *dev_logk = nullptr;    // log(k) table of the device QIC (qs_score.hip), tbl_n entries
     uint32_t tbl_n = 0;
     // scoring view (qs_score_set_view): tuples [view_rank_lo, view_rank_lo + view_n) in caller-owned device memory
@@ -201,6 +204,12 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
 extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
     if (!c) return QS_ERR_ARG;
     switch (key) {
+        case QS_TUNE_SCORE_CAND_SLOTS:
+            if (value < 1 || value > (uint64_t)kCand) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_CAND_SLOTS takes 1..8");
+            c->tune_cand_slots = (uint32_t)value; return QS_OK;
+        case QS_TUNE_SCORE_TOL_EXP:
+            if (value < 1 || value > 15) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_TOL_EXP takes 1..15 (tolerance 10^-value)");
+            c->tune_score_tol = std::pow(10.0, -(double)value); return QS_OK;
         case QS_TUNE_TILE_ORDER:
             QS_HIP(c, hipSetDevice(c->device));
             QS_HIP(c, hipStreamSynchronize(c->stream));
@@ -954,6 +963,7 @@ static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t 
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
     if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
+    sd.cand_limit = c->tune_cand_slots; sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
     sd.frame = R.bifurcating ? 0 : 1;
 }
 
@@ -1010,20 +1020,76 @@ extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *
     ScoreDevice sd;
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_min = (long long *)min_dev; sd.pair_cand = (unsigned long long *)cand_dev;
-    QS_HIP(c, launch_score_pass2(c->stream, sd, 1e-12));
+    QS_HIP(c, launch_score_pass2(c->stream, sd, c->tune_score_tol));
+    return QS_OK;   // asynchronous; node pairs whose slots did not suffice are marked in cand_dev (qs_score_overflow)
+}
+
+// Node pairs that pass 2 could not finish in their 8 packed slots (more than 8 distinct near-minimal triples, or a
+// gcd-reduced count >= 2^21) carry kCandOverflow in their last slot. For those pairs the table is scanned once more
+// and EVERY near-minimal quartet's (key, q1, q2, q3) is listed; the list is sorted and de-duplicated on the host and
+// handed to qs_score_finish, which takes the exact minimum over it. The reference evaluates log_score for every
+// quartet (QuartetScoreComputer.hpp:417-469), so any superset of the minimisers gives its result.
+extern "C" int qs_score_overflow(qs_ctx *c, const qs_ref_tree *ref, const int64_t *min_dev, const int64_t *cand_dev,
+                                 int64_t **list_out, uint64_t *n_out) {
+    if (!c || !min_dev || !cand_dev || !list_out || !n_out) return fail(c, QS_ERR_ARG, "qs_score_overflow: NULL");
+    *list_out = nullptr; *n_out = 0;
+    QS_HIP(c, hipSetDevice(c->device));
     uint32_t fl = 0;
     QS_HIP(c, hipMemcpyAsync(&fl, c->dev_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
     QS_HIP(c, hipStreamSynchronize(c->stream));
-    if (fl & 1u) return fail(c, QS_ERR_OVERFLOW, "qs_score: more than 8 distinct near-minimal count triples for one node pair");
-    if (fl & 2u) return fail(c, QS_ERR_UNSUPPORTED, "qs_score: reduced count triple does not fit 21 bits per component");
+    if ((fl & 3u) == 0) return QS_OK;
+    const RefHost *Rp = nullptr;
+    int rc = get_ref(c, ref, true, &Rp);
+    if (rc != QS_OK) return rc;
+    ScoreDevice sd;
+    fill_score_device(c, *Rp, c->ref_lca_dev, sd);
+    sd.pair_min = (long long *)const_cast<int64_t *>(min_dev); sd.pair_cand = (unsigned long long *)const_cast<int64_t *>(cand_dev);
+    DevPtr cnt, list;
+    QS_HIP(c, hipMalloc(&cnt.p, 8));
+    uint64_t cap = 1ull << 20;
+    std::vector<unsigned long long> host;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (list.p) { (void)hipFree(list.p); list.p = nullptr; }
+        if (hipMalloc(&list.p, cap * 32) != hipSuccess) return fail(c, QS_ERR_OOM, "qs_score_overflow: list of " + std::to_string(cap) + " quartets does not fit");
+        QS_HIP(c, hipMemsetAsync(cnt.p, 0, 8, c->stream));
+        sd.list = (unsigned long long *)list.p; sd.list_count = (unsigned long long *)cnt.p; sd.list_cap = cap;
+        QS_HIP(c, launch_score_overflow_list(c->stream, sd, c->tune_score_tol));
+        unsigned long long got = 0;
+        QS_HIP(c, hipMemcpyAsync(&got, cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+        QS_HIP(c, hipStreamSynchronize(c->stream));
+        if (got <= cap) {
+            host.resize(got * 4);
+            if (got) QS_HIP(c, hipMemcpy(host.data(), list.p, got * 32, hipMemcpyDeviceToHost));
+            break;
+        }
+        if (attempt == 1 || got > (1ull << 28)) return fail(c, QS_ERR_OVERFLOW, "qs_score_overflow: " + std::to_string(got) + " near-minimal quartets");
+        cap = got;
+    }
+    // sort + unique the 4-word records
+    const size_t n = host.size() / 4;
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; ++i) idx[i] = i;
+    auto less = [&](size_t x, size_t y) { return std::lexicographical_compare(&host[4 * x], &host[4 * x] + 4, &host[4 * y], &host[4 * y] + 4); };
+    std::sort(idx.begin(), idx.end(), less);
+    std::vector<unsigned long long> uniq;
+    for (size_t i = 0; i < n; ++i)
+        if (i == 0 || less(idx[i - 1], idx[i])) uniq.insert(uniq.end(), &host[4 * idx[i]], &host[4 * idx[i]] + 4);
+    if (!uniq.empty()) {
+        int64_t *out = (int64_t *)malloc(uniq.size() * 8);
+        if (!out) return fail(c, QS_ERR_OOM, "qs_score_overflow: host list");
+        memcpy(out, uniq.data(), uniq.size() * 8);
+        *list_out = out; *n_out = uniq.size() / 4;
+    }
     return QS_OK;
 }
+
+extern "C" void qs_free_host(void *p) { free(p); }
 
 // Pure host: log_score of the O(#node pairs) candidates and sums with the host libm
 // (QuartetScoreComputer.hpp:135-159), then the min-propagation along path(u,v) (:448-454, :472-489).
 extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,
-                               const int64_t *cand_host, uint32_t n_cand_parts, double *lqic, double *qpic, double *eqpic,
-                               int *is_bifurcating) {
+                               const int64_t *cand_host, uint32_t n_cand_parts, const int64_t *extra_host, uint64_t n_extra,
+                               double *lqic, double *qpic, double *eqpic, int *is_bifurcating) {
     if (!sums_host || !cand_host || !lqic || n_cand_parts == 0) return fail(c, QS_ERR_ARG, "qs_score_finish: NULL");
     RefHost local;          // ctx == NULL: pure host use (no device, no cache)
     const RefHost *Rp = &local;
@@ -1035,6 +1101,13 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
     const size_t np = (size_t)R.n_inner * R.n_inner;
     const unsigned long long *sums = (const unsigned long long *)sums_host;
     const unsigned long long *cand = (const unsigned long long *)cand_host;
+    // extra candidates (qs_score_overflow lists, any order): key -> range in a sorted copy
+    std::vector<std::array<unsigned long long, 4>> extra;
+    if (extra_host && n_extra) {
+        extra.resize(n_extra);
+        memcpy(extra.data(), extra_host, n_extra * 32);
+        std::sort(extra.begin(), extra.end());
+    }
     const double inf = std::numeric_limits<double>::infinity();
     const uint32_t N = R.n_nodes;
     for (uint32_t v = 0; v < N; ++v) {
@@ -1056,9 +1129,17 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
                 for (uint32_t part = 0; part < n_cand_parts; ++part) {
                     const unsigned long long *cs = cand + ((size_t)part * np + key) * kCand;
                     for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
+                        if (cs[s] == kCandOverflow) continue;   // marker: this pair's full list is in `extra`
                         const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
                         const double v = host_log_score(q1, q2, q3);
                         lqmin = std::min(lqmin, v);
+                        any = true;
+                    }
+                }
+                if (!extra.empty()) {
+                    const std::array<unsigned long long, 4> lo_key = {(unsigned long long)key, 0, 0, 0};
+                    for (auto it = std::lower_bound(extra.begin(), extra.end(), lo_key); it != extra.end() && (*it)[0] == key; ++it) {
+                        lqmin = std::min(lqmin, host_log_score((*it)[1], (*it)[2], (*it)[3]));
                         any = true;
                     }
                 }
@@ -1133,11 +1214,16 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     if (rc != QS_OK) return rc;
     rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);
     if (rc != QS_OK) return rc;
+    int64_t *extra = nullptr;
+    uint64_t n_extra = 0;
+    rc = qs_score_overflow(c, ref, (const int64_t *)mn.p, (const int64_t *)cand.p, &extra, &n_extra);
+    if (rc != QS_OK) return rc;
+    struct FreeHost { int64_t *p; ~FreeHost() { free(p); } } free_extra{extra};
     std::vector<int64_t> hs(np * 3), hc(np * kCand);
     QS_HIP(c, hipMemcpyAsync(hs.data(), sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
     QS_HIP(c, hipMemcpyAsync(hc.data(), cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
     QS_HIP(c, hipStreamSynchronize(c->stream));
-    return qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, lqic, qpic, eqpic, is_bifurcating);
+    return qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, extra, n_extra, lqic, qpic, eqpic, is_bifurcating);
 }
 
 extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q) {

@@ -89,7 +89,10 @@ struct ScoreDevice {
     unsigned long long *pair_sums; // n_inner*n_inner*3
     long long *pair_min;           // n_inner*n_inner (f64_to_sortable of the device QIC)
     unsigned long long *pair_cand; // n_inner*n_inner*kCand
-    uint32_t *flags;               // [0] candidate overflow
+    uint32_t cand_limit;           // candidate slots pass 2 may fill per node pair (kCand; smaller in tests)
+    unsigned long long *list;      // pass 3 (qs_score_overflow): 4 words (key, q1, q2, q3) per near-minimal quartet of a marked pair
+    unsigned long long *list_count, list_cap;
+    uint32_t *flags;               // [0] bit 0: a pair's candidate slots overflowed, bit 1: a reduced triple did not fit the packed slot
     const uint16_t *ref_next; // n*n: for a < b the first a' > a with lca(a',b) != lca(a,b), b if there is none
     const double *logk;            // log(k) (0 at k = 0) for k < tbl_n: integer arguments of the device QIC
     uint32_t tbl_n;
@@ -103,6 +106,7 @@ constexpr unsigned long long kCandOverflow = ~0ull - 1; // in the LAST slot of a
 uint32_t score_scan_max_lds_log();
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd);
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol);
+hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol);
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
                           unsigned long long *q_dev);
 

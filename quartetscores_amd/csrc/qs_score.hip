@@ -222,7 +222,7 @@ __device__ __noinline__ void scan_candidate(const ScoreDevice &sd, uint32_t key,
     }
     const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
     // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
-    for (int s = 0; s < kCand; ++s) {
+    for (uint32_t s = 0; s < sd.cand_limit; ++s) {
         unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == packed || cur == kCandOverflow) return;
         if (cur == kCandEmpty) {
@@ -276,7 +276,9 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
             unsigned long long s1 = 0, s2 = 0, s3 = 0;
             long long mn = kSortableMax;
             double thr = 0.0;
-            if (PASS == 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
+            bool marked = false;   // pass 3: this node pair's candidate slots overflowed in pass 2
+            if (PASS >= 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
+            if (PASS == 3 && seg.code != 3) marked = sd.pair_cand[(size_t)seg.key * kCand + kCand - 1] == kCandOverflow;
             // the lane's kSK consecutive tuples, one ahead (the loop is NOT unrolled: the run-end block exists once)
             const CT *tp = table + r0 * 3;
             uint32_t n0, n1, n2, p0 = 0, p1 = 0, p2 = 0;
@@ -293,7 +295,8 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
                     }
                     seg = scan_classify(sd, a, b, e12, e23);
                     s1 = s2 = s3 = 0; mn = kSortableMax;
-                    if (PASS == 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
+                    if (PASS >= 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
+                    if (PASS == 3) marked = seg.code != 3 && sd.pair_cand[(size_t)seg.key * kCand + kCand - 1] == kCandOverflow;
                 }
                 if (seg.code != 3) {
                     const uint32_t q1 = seg.code == 0 ? n0 : n2;
@@ -304,7 +307,14 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
                         s1 += q1; s2 += q2; s3 += q3;
                         const long long sq = f64_to_sortable(qic);
                         mn = sq < mn ? sq : mn;
-                    } else if (qic <= thr) scan_candidate(sd, seg.key, q1, q2, q3);
+                    } else if (PASS == 2) { if (qic <= thr) scan_candidate(sd, seg.key, q1, q2, q3); }
+                    else if (marked && qic <= thr) {   // pass 3: (key, q1, q2, q3) of every near-minimal quartet of a marked pair
+                        const unsigned long long at = atomicAdd(sd.list_count, 1ull);
+                        if (at < sd.list_cap) {
+                            unsigned long long *e = sd.list + at * 4;
+                            e[0] = seg.key; e[1] = q1; e[2] = q2; e[3] = q3;
+                        }
+                    }
                 }
                 ++a;
                 n0 = p0; n1 = p1; n2 = p2;
@@ -363,6 +373,10 @@ hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
 
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) {
     return sd.count_bits == 32 ? launch_scan<uint32_t, 2>(s, sd, tol) : launch_scan<uint16_t, 2>(s, sd, tol);
+}
+
+hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol) {
+    return sd.count_bits == 32 ? launch_scan<uint32_t, 3>(s, sd, tol) : launch_scan<uint16_t, 3>(s, sd, tol);
 }
 
 uint32_t score_scan_max_lds_log() { return kScanMaxLdsLog; }

@@ -249,10 +249,14 @@ def score_sharded(ctx, ref, flags: int = 0, group=None, device=None):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
     ctx.score_pass2(ref, mins, cand)
+    extra = ctx.score_overflow(ref, mins, cand)     # (k, 4) near-minimal quartets of overflowed node pairs; k = 0 almost always
     if multi:
         parts = [torch.empty_like(cand) for _ in range(dist.get_world_size(group))]
         dist.all_gather(parts, cand, group=group)
         cand_host = np.stack([p.cpu().numpy() for p in parts])
+        lists = [None] * dist.get_world_size(group)
+        dist.all_gather_object(lists, extra, group=group)
+        extra = np.concatenate(lists) if any(len(x) for x in lists) else extra
     else:
         cand_host = cand.cpu().numpy()[None, :]
-    return ctx.score_finish(ref, sums.cpu().numpy(), cand_host, flags)
+    return ctx.score_finish(ref, sums.cpu().numpy(), cand_host, flags, extra=extra)

@@ -227,9 +227,25 @@ class Context:
         s, keep = self._ref_struct(ref)
         self._chk(self.L.qs_score_pass2(self.h, C.byref(s), C.c_void_p(mins.data_ptr()), C.c_void_p(cand.data_ptr())))
 
-    def score_finish(self, ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32):
-        """sums_host: int64[3P]; cand_host: int64[parts, 8P] (gathered over the shards)."""
-        return score_finish_host(ref, sums_host, cand_host, flags, _ctx=self)
+    def score_overflow(self, ref: flatten.RefTree, mins, cand) -> np.ndarray:
+        """qs_score_overflow: (k, 4) int64 rows (key, q1, q2, q3) = every near-minimal quartet of the node pairs whose
+        candidate slots did not suffice in score_pass2 (k = 0 almost always)."""
+        s, keep = self._ref_struct(ref)
+        p = C.c_void_p()
+        k = C.c_uint64(0)
+        self._chk(self.L.qs_score_overflow(self.h, C.byref(s), C.c_void_p(mins.data_ptr()), C.c_void_p(cand.data_ptr()), C.byref(p), C.byref(k)))
+        if not k.value:
+            return np.zeros((0, 4), dtype=np.int64)
+        try:
+            buf = (C.c_int64 * (4 * k.value)).from_address(p.value)
+            return np.frombuffer(buf, dtype=np.int64).reshape(-1, 4).copy()
+        finally:
+            self.L.qs_free_host(p)
+
+    def score_finish(self, ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32, extra=None):
+        """sums_host: int64[3P]; cand_host: int64[parts, 8P] (gathered over the shards); extra: (k, 4) rows of
+        score_overflow (concatenated over the shards) or None."""
+        return score_finish_host(ref, sums_host, cand_host, flags, extra=extra, _ctx=self)
 
     def raw_qic(self, ref: flatten.RefTree, r0: int, nq: int):
         s, keep = self._ref_struct(ref)
@@ -240,7 +256,7 @@ class Context:
         return topo, q
 
 
-def score_finish_host(ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32, _ctx=None):
+def score_finish_host(ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np.ndarray, flags=QS_SCORE_QP_WRAP32, extra=None, _ctx=None):
     """qs_score_finish: pure host arithmetic on the reduced per-node-pair sums and the gathered candidates (no device
     needed; `_ctx` only lends its cached reference tree). sums_host: int64[3P]; cand_host: int64[parts, 8P]."""
     L = _lib.load()
@@ -251,7 +267,9 @@ def score_finish_host(ref: flatten.RefTree, sums_host: np.ndarray, cand_host: np
     lq = np.zeros(ref.n_nodes); qp = np.zeros(ref.n_nodes); eqp = np.zeros(ref.n_nodes)
     bif = C.c_int(0)
     h = _ctx.h if _ctx is not None else None
+    ex = np.ascontiguousarray(extra, dtype=np.int64).reshape(-1, 4) if extra is not None and len(extra) else None
     rc = L.qs_score_finish(h, C.byref(s), flags, sums_host.ctypes.data_as(C.c_void_p), cand_host.ctypes.data_as(C.c_void_p), parts,
+                           ex.ctypes.data_as(C.c_void_p) if ex is not None else None, len(ex) if ex is not None else 0,
                            lq.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p), eqp.ctypes.data_as(C.c_void_p), C.byref(bif))
     if rc != 0:
         raise QSError(rc, L.qs_last_error(h).decode())

@@ -157,6 +157,46 @@ class ScoreEmu:
             slots[free[0]] = packed
         cand.copy_(__import__("torch").from_numpy(out))
 
-    def score_finish(self, ref, sums_host, cand_host, flags=0):
+    def score_overflow(self, ref, mins, cand):
+        return np.zeros((0, 4), dtype=np.int64)   # the emulation asserts instead of overflowing
+
+    def score_finish(self, ref, sums_host, cand_host, flags=0, extra=None):
         from quartetscores_amd.engine import score_finish_host
-        return score_finish_host(ref, sums_host, cand_host, flags)
+        return score_finish_host(ref, sums_host, cand_host, flags, extra=extra)
+
+
+def scores_from_table(ref, T, qp_exact64=False):
+    """LQ-/QP-/EQP-IC per child node from a whole count table, by the closed form of SURVEY.md 3.3 in plain Python (exact
+    log_score on every quartet, 32-bit wrap of the QP sums): the expected values for tables the oracle cannot produce by
+    counting (hand-made tables with huge counts). Bifurcating references with a degree-3 root."""
+    from quartetscores_amd.engine import log_score
+    emu = ScoreEmu(ref, T, 0)
+    N = ref.n_nodes
+    inf = float("inf")
+    lq = [inf] * N; qp = [inf] * N; eqp = [inf] * N
+    per = {}
+    for key, q, qic in emu._classified():
+        s = per.setdefault(key, [0, 0, 0, inf])
+        s[0] += q[0]; s[1] += q[1]; s[2] += q[2]
+        s[3] = min(s[3], qic)
+    inner_nodes = [v for v in range(N) if emu.inner_id[v] >= 0]
+    par, depth = ref.parent, emu.depth
+    for key in sorted(per):
+        iu, iv = divmod(key, emu.n_inner)
+        p1, p2, p3, lqmin = per[key]
+        if not qp_exact64:
+            p1 &= 0xFFFFFFFF; p2 &= 0xFFFFFFFF; p3 &= 0xFFFFFFFF
+        val = log_score(p1, p2, p3)
+        x, y = inner_nodes[iu], inner_nodes[iv]
+        edges = []
+        while x != y:
+            if depth[x] >= depth[y]:
+                edges.append(x); x = int(par[x])
+            else:
+                edges.append(y); y = int(par[y])
+        for e in edges:
+            lq[e] = min(lq[e], lqmin)
+            eqp[e] = min(eqp[e], val)
+        if len(edges) == 1:
+            qp[edges[0]] = val
+    return np.array(lq), np.array(qp), np.array(eqp)

@@ -215,3 +215,30 @@ def test_header_is_plain_c(tmp_path):
     import torch
     if not torch.cuda.is_available():       # no device here: the C caller sees the loud failure too
         assert "|-6|" in p.stdout and "no HIP device" in p.stdout
+
+
+def test_python_closed_form_scores_match_the_oracle():
+    """tests/emulate.scores_from_table (used as the expected value for hand-made tables on the GPU) against the oracle."""
+    import emulate
+    from oracle_api import Oracle
+    from quartetscores_amd import flatten, newick, synth
+    n = 12
+    ref_nw = synth.reference_tree(n, 51)
+    trees = synth.tree_set(n, 30, 52, collapse=0.2)
+    ref = flatten.flatten_reference(ref_nw)
+    o = Oracle(ref_nw)
+    o.count("\n".join(trees))
+    o.score()
+    want = o.scores_by_bipartition()
+    lq, qp, eqp = emulate.scores_from_table(ref, o.counts())
+    names = ref.names
+    seen = 0
+    for e in range(ref.n_nodes - 1):
+        below = frozenset(x.name for x in newick.preorder(ref.nodes[e + 1]) if x.is_leaf)
+        if len(below) <= 1 or len(below) >= n - 1:
+            continue
+        other = frozenset(names) - below
+        key = below if (len(below) < len(other) or (len(below) == len(other) and min(names) not in below)) else other
+        assert (lq[e + 1], qp[e + 1], eqp[e + 1]) == want[key]
+        seen += 1
+    assert seen == len(want)
