@@ -163,7 +163,8 @@ const char *qs_version(void);
 uint64_t qs_table_tuples(const qs_ctx *ctx); /* number of 4-sets owned = C(d_hi,4)-C(d_lo,4) */
 uint64_t qs_table_bytes(const qs_ctx *ctx);  /* tuples * 3 * count_bits/8 (compare quartet_lookup_table.hpp:69-71) */
 int qs_table_alloc(qs_ctx *ctx);             /* hipMalloc + zero; QS_ERR_OOM if it does not fit */
-int qs_table_attach(qs_ctx *ctx, void *device_ptr, uint64_t bytes); /* caller-owned device memory, e.g. a torch tensor */
+int qs_table_attach(qs_ctx *ctx, void *device_ptr, uint64_t bytes); /* caller-owned device memory, e.g. a torch tensor: 4-byte
+                                              * aligned, at least qs_table_bytes() rounded up to a multiple of 4 */
 void *qs_table_device_ptr(const qs_ctx *ctx);
 int qs_table_clear(qs_ctx *ctx);
 int qs_table_download(qs_ctx *ctx, void *host_dst, uint64_t bytes);

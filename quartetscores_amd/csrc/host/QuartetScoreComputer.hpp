@@ -42,8 +42,9 @@ struct EvalFile {
     std::string path, text;
     std::vector<std::pair<size_t, size_t>> spans;
 };
-inline std::shared_ptr<const EvalFile> loadEvalFile(const std::string &evalTreesPath) {
+inline std::shared_ptr<const EvalFile> loadEvalFile(const std::string &evalTreesPath, bool drop = false) {
     static std::shared_ptr<const EvalFile> cache;
+    if (drop) { auto last = cache; cache.reset(); return last; }   // the counter is done with the file: release the text
     if (!cache || cache->path != evalTreesPath) {
         auto f = std::make_shared<EvalFile>();
         f->path = evalTreesPath;
@@ -93,9 +94,17 @@ public:
         } catch (...) { host_err = std::current_exception(); }
         gpu_init.join();
         if (rc_create != QS_OK) throw std::runtime_error(create_err);
-        if (rc_alloc != QS_OK) fail();
-        if (host_err) std::rethrow_exception(host_err);
-        countQuartets(ef, std::move(first), m, opt);
+        try {   // the destructor does not run when a constructor throws: release the context here
+            if (rc_alloc != QS_OK) fail();
+            if (host_err) std::rethrow_exception(host_err);
+            countQuartets(ef, std::move(first), m, opt);
+        } catch (...) {
+            qs_destroy(ctx_);
+            ctx_ = nullptr;
+            throw;
+        }
+        ef.reset();
+        loadEvalFile(std::string(), true);   // drop the cached evaluation file (tens of MB of Newick text)
         std::cout << "lookup table size in bytes: " << qs_table_bytes(ctx_) << "\n"; // QCL:268-272
     }
     ~QuartetCounterLookup() { qs_destroy(ctx_); }
@@ -153,6 +162,9 @@ private:
                 hb.adj_depth = b.adj_depth.data();
                 hb.node_off = want_ranges ? b.node_off.data() : nullptr; hb.rng_off = want_ranges ? b.rng_off.data() : nullptr;
                 hb.ranges = b.ranges.data();
+                // at most two device batches alive: the one being counted and the one being uploaded. The upload's
+                // copy synchronises with the stream anyway, so the batch counted two iterations ago is finished.
+                if (in_flight.size() == 2) { qs_batch_free(ctx_, in_flight.front()); in_flight.erase(in_flight.begin()); }
                 qs_device_batch *db = nullptr;
                 if (qs_batch_upload(ctx_, &hb, &db) != QS_OK) fail();  // synchronous copy: `b` may go away
                 in_flight.push_back(db);

@@ -10,6 +10,7 @@
 // --save-table / --load-table write / read the raw count table (resume without recounting).
 #include "QuartetScoreComputer.hpp"
 
+#include <cerrno>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -54,6 +55,20 @@ int parse(int argc, char **argv, Args &a) {
         }
         return argv[++i];
     };
+    // numeric flag values: a malformed one is reported like the other argument errors (tclap: "Couldn't read argument
+    // value from string"), not an uncaught std::invalid_argument
+    auto number = [&](const char *text, const char *flag, unsigned long &out) {
+        char *end = nullptr;
+        errno = 0;
+        const unsigned long val = std::strtoul(text, &end, 10);
+        if (end == text || *end != '\0' || errno != 0 || text[0] == '-') {
+            std::cerr << "ERROR: Couldn't read argument value from string '" << text << "' for arg " << flag << std::endl;
+            return false;
+        }
+        out = val;
+        return true;
+    };
+    unsigned long num = 0;
     for (int i = 1; i < argc; ++i) {
         std::string f = argv[i];
         const char *v = nullptr;
@@ -61,10 +76,10 @@ int parse(int argc, char **argv, Args &a) {
         else if (f == "-e" || f == "--eval") { if (!(v = need(i, "-e (--eval)"))) return 1; a.eval = v; }
         else if (f == "-o" || f == "--output") { if (!(v = need(i, "-o (--output)"))) return 1; a.out = v; }
         else if (f == "-q" || f == "--qic") { if (!(v = need(i, "-q (--qic)"))) return 1; a.raw = v; }
-        else if (f == "-t" || f == "--threads") { if (!(v = need(i, "-t (--threads)"))) return 1; a.threads = std::stoul(v); }
+        else if (f == "-t" || f == "--threads") { if (!(v = need(i, "-t (--threads)")) || !number(v, "-t (--threads)", num)) return 1; a.threads = num; }
         else if (f == "-v" || f == "--verbose") a.verbose = true;
         else if (f == "-s" || f == "--savemem") a.savemem = true;
-        else if (f == "--device") { if (!(v = need(i, "--device"))) return 1; a.dev.device = std::stoi(v); }
+        else if (f == "--device") { if (!(v = need(i, "--device")) || !number(v, "--device", num)) return 1; a.dev.device = (int)num; }
         else if (f == "--algo") {
             if (!(v = need(i, "--algo"))) return 1;
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;

@@ -38,17 +38,25 @@ inline std::vector<std::pair<size_t, size_t>> split_trees(const std::string &s) 
             start = stop + 1;
             continue;
         }
-        // slow path for this tree: a ';' inside quotes or comments does not end it
-        bool in_quote = false, in_comment = false, content = false, closed = false;
+        // slow path for this tree: a ';' inside quotes or comments does not end it. A quote opens a quoted label only
+        // where a label can start -- after '(' ',' ')' or at the start of the tree (white space and comments skipped),
+        // as in the parsers (parse_flat / NewickReader::label); an apostrophe inside an unquoted label (O'Brien) is an
+        // ordinary character.
+        bool in_quote = false, in_comment = false, content = false, closed = false, label_may_start = true;
         size_t i = start;
         for (; i < n; ++i) {
             const char ch = base[i];
             if (in_comment) { if (ch == ']') in_comment = false; continue; }
-            if (in_quote) { if (ch == '\'') in_quote = false; continue; }
+            if (in_quote) {
+                if (ch == '\'') { if (i + 1 < n && base[i + 1] == '\'') ++i; else in_quote = false; } // '' = escaped quote
+                continue;
+            }
             if (ch == '[') { in_comment = true; continue; }
-            if (ch == '\'') { in_quote = true; content = true; continue; }
+            if (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r') continue;
+            if (ch == '\'' && label_may_start) { in_quote = true; content = true; label_may_start = false; continue; }
             if (ch == ';') { closed = true; break; }
-            if (ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') content = true;
+            content = true;
+            label_may_start = (ch == '(' || ch == ',' || ch == ')');
         }
         if (content) spans.emplace_back(start, closed ? i + 1 : n); // the last tree may lack its ';'
         start = i + 1;

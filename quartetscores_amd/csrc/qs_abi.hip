@@ -340,7 +340,10 @@ extern "C" int qs_table_alloc(qs_ctx *c) {
 
 extern "C" int qs_table_attach(qs_ctx *c, void *device_ptr, uint64_t bytes) {
     if (!c || !device_ptr) return fail(c, QS_ERR_ARG, "qs_table_attach: NULL");
-    if (bytes < qs_table_bytes(c)) return fail(c, QS_ERR_ARG, "qs_table_attach: buffer smaller than qs_table_bytes()");
+    // 16-bit cells are updated through their 32-bit word (packed half-word atomics of the scatter kernel, word-wise
+    // collectives): the buffer must cover whole words
+    const uint64_t need = (qs_table_bytes(c) + 3) & ~3ull;
+    if (bytes < need) return fail(c, QS_ERR_ARG, "qs_table_attach: buffer smaller than qs_table_bytes() rounded up to a multiple of 4");
     if ((uintptr_t)device_ptr & 3) return fail(c, QS_ERR_ARG, "qs_table_attach: pointer must be 4-byte aligned");
     if (c->table && c->table_owned) (void)hipFree(c->table);
     c->table = device_ptr;

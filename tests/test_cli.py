@@ -37,6 +37,10 @@ def test_cli_argument_errors(d1_files, tmp_path):
     assert p.returncode == 1 and "ERROR: The specified output file already exists." in p.stdout
     p = run("--version")
     assert p.returncode == 0 and "1.0.1" in p.stdout
+    # malformed numeric values end like the other argument errors, not in std::terminate
+    for flag in ("-t", "--device"):
+        p = run("-r", r, "-e", e, "-o", str(tmp_path / "o.nwk"), flag, "four")
+        assert p.returncode == 1 and "ERROR" in p.stderr and flag in p.stderr, (flag, p.returncode, p.stderr)
 
 
 def test_cpp_host_flattening_matches_python_host(tmp_path):
@@ -155,6 +159,23 @@ def test_native_ingest_on_decorated_newick(tmp_path):
         assert total == len(trees) == got.n_trees
         for f in ("leaf_off", "leaf_ids", "adj_depth", "node_off", "rng_off", "ranges"):
             assert np.array_equal(getattr(got, f), getattr(want, f)), f
+
+
+def test_apostrophes_inside_unquoted_labels_do_not_merge_trees(tmp_path):
+    """A quote opens a quoted label only where a label can start; O'Brien is an ordinary unquoted label, so the ';'
+    behind it still ends its tree (the splitter once swallowed it and merged the trees)."""
+    import numpy as np
+    from quartetscores_amd import flatten, native_ingest
+    ref_nw = "((O'Brien,b),(c,d),(e,(f,'g;h')));"
+    trees = ["((O'Brien,c),(b,d),(e,(f,'g;h')))", "(('g;h',b),(c,O'Brien),(e,(f,d)))", "((e,b),(c,d),(O'Brien,(f,'g;h')))"]
+    text = ";\n".join(trees) + ";\n"
+    ref = flatten.flatten_reference(ref_nw)
+    assert "O'Brien" in ref.names and "g;h" in ref.names
+    want = flatten.flatten_eval_trees([t + ";" for t in trees], ref.name_to_id)
+    got, total = native_ingest.ingest_text(ref_nw, text)
+    assert total == 3 and got.n_trees == 3
+    for f in ("leaf_off", "leaf_ids", "adj_depth", "node_off", "rng_off", "ranges"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
 
 
 def test_cli_fails_loudly_without_gpu(d1_files, tmp_path):
