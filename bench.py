@@ -200,7 +200,7 @@ def run_cpu_baseline(ref_nw, eval_text, n, m, nq, budget_s):
 # ---------------------------------------------------------------------------------------------------------------
 def kernel_source_sha():
     h = hashlib.sha256()
-    for fn in ("qs_count.hip", "qs_common.hpp", "qs_internal.hpp"):
+    for fn in ("qs_count.hip", "qs_common.hpp"):
         with open(os.path.join(ROOT, "quartetscores_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

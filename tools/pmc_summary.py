@@ -51,7 +51,7 @@ except (OSError, ValueError):
     pass
 if bench:
     h = hashlib.sha256()
-    for fn in ("qs_count.hip", "qs_common.hpp", "qs_internal.hpp"):
+    for fn in ("qs_count.hip", "qs_common.hpp"):
         with open(os.path.join(root, "quartetscores_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     kname = bench["roofline"]["kernel"]
