@@ -85,6 +85,13 @@ enum {
 /* qs_score flags */
 #define QS_SCORE_QP_WRAP32 0u   /* reference-compatible: QP sums kept mod 2^32 (QuartetScoreComputer.hpp:382) */
 #define QS_SCORE_QP_EXACT64 1u  /* 64-bit sums */
+/* Reference tree with a degree-2 root (rooted Newick). Default: what the reference computes -- it takes the subtrees
+ * beside a node pair with next() / next().next() on the link cycle, and on the root's two-link cycle that reaches back
+ * to the subtree of v itself (QuartetScoreComputer.hpp:393-396): the pairs (root, v) get sums over
+ * (other side) x (v's whole side) x (v's two child subtrees), which set the QP-IC of the two root edges and enter the
+ * EQP-IC minima below them. With QS_SCORE_ROOT_AS_EDGE the root is treated as a
+ * subdivision of one edge instead: both root edges carry the scores of the unrooted internode. */
+#define QS_SCORE_ROOT_AS_EDGE 2u
 
 /*
  * A batch of evaluation trees, flattened by the host (see quartetscores_amd/csrc/host
@@ -116,8 +123,8 @@ typedef struct {
  * The reference tree, flattened. Nodes 0..n_nodes-1, parent[root] = -1. leaf_node[i] is
  * the node of the taxon with lookup id i; lookup ids must be in depth-first order (every
  * node's leaves form one contiguous id interval), which qs_score verifies. A degree-2
- * root is treated as an edge subdivision (SURVEY.md quirk Q5 is NOT reproduced; see
- * DESIGN.md).
+ * root is scored like the reference does unless QS_SCORE_ROOT_AS_EDGE
+ * is given.
  */
 typedef struct {
     uint32_t n_nodes;

@@ -14,7 +14,7 @@ QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER = 0, 1, 2
 QS_COUNT_OVERWRITE = 0x100
 QS_COUNT_TIMED = 0x200
 QS_COUNT_WIRE16X2 = 0x400
-QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64 = 0, 1
+QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64, QS_SCORE_ROOT_AS_EDGE = 0, 1, 2
 QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4

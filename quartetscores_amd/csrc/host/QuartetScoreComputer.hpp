@@ -63,6 +63,7 @@ struct DeviceOptions {
     size_t batch_trees = 8192;   // trees per device batch
     unsigned ingest_threads = 0; // host threads that parse + flatten (0 = hardware concurrency); the CLI's -t
     bool qp_exact64 = false;
+    bool root_as_edge = false;   // QS_SCORE_ROOT_AS_EDGE: a degree-2 root as a subdivision of one edge (not the reference's quirk Q5)
     std::string load_table, save_table; // count-table persistence
 };
 
@@ -221,7 +222,8 @@ public:
         rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
         std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
         int bif = 0;
-        if (qs_score(quartetCounterLookup->context(), &rt, opt.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32,
+        if (qs_score(quartetCounterLookup->context(), &rt,
+                     (opt.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u),
                      lq.data(), qp.data(), eqp.data(), &bif) != QS_OK)
             throw std::runtime_error(qs_last_error(quartetCounterLookup->context()));
         // edge e = edge above node e+1 (preorder)

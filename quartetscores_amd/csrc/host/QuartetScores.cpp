@@ -41,6 +41,8 @@ void usage(std::ostream &os) {
           "   --device N     HIP device ordinal (default 0)\n"
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
+          "   --root-as-edge rooted reference tree: score the two root edges as one internode (the reference's\n"
+          "                  own handling of a degree-2 root is the default)\n"
           "   --save-table F write the count table to F after counting\n"
           "   --load-table F read the count table from F instead of counting (-e is still needed for m)\n"
           "   --qic-binary F raw per-quartet QIC as a binary file (topology byte + double per quartet, in rank order)\n";
@@ -84,6 +86,7 @@ int parse(int argc, char **argv, Args &a) {
             if (!(v = need(i, "--algo"))) return 1;
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
+        else if (f == "--root-as-edge") a.dev.root_as_edge = true;
         else if (f == "--save-table") { if (!(v = need(i, "--save-table"))) return 1; a.dev.save_table = v; }
         else if (f == "--qic-binary") { if (!(v = need(i, "--qic-binary"))) return 1; a.raw_bin = v; }
         else if (f == "--load-table") { if (!(v = need(i, "--load-table"))) return 1; a.dev.load_table = v; }

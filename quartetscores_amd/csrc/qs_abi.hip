@@ -32,7 +32,11 @@ struct RefHost {
     std::vector<uint32_t> lca; // n*n
     std::vector<uint16_t> next; // n*n: for a < b the first a' > a with lca(a',b) != lca(a,b) (b if none): run ends of the score scan
     std::vector<uint32_t> leaf_node_in; // the caller's leaf_node array (cache key)
+    std::vector<uint32_t> leaf_lo, leaf_cnt; // per node: its leaves are the lookup ids [leaf_lo, leaf_lo + leaf_cnt)
     bool bifurcating = false;
+    bool root_deg2 = false;             // rooted Newick: the root has exactly two children
+    std::vector<RootPairHost> root_pairs; // the node pairs (root, v) of such a tree, as the reference enumerates them
+    uint64_t root_items = 0;
 };
 
 struct qs_ctx {
@@ -86,6 +90,7 @@ struct qs_ctx {
     RefHost *ref_cache = nullptr;
     uint32_t *ref_lca_dev = nullptr;
     uint16_t *ref_next_dev = nullptr;
+    void *root_pairs_dev = nullptr;
 };
 
 static std::string g_create_err;
@@ -311,6 +316,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->ref_lca_dev) (void)hipFree(c->ref_lca_dev);
     if (c->ref_next_dev) (void)hipFree(c->ref_next_dev);
+    if (c->root_pairs_dev) (void)hipFree(c->root_pairs_dev);
     delete c->ref_cache;
     delete c;
 }
@@ -876,6 +882,8 @@ static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
         if (deg >= 1) max_rank = std::max(max_rank, deg - 1);
     }
     R.bifurcating = (max_rank == 2);
+    R.leaf_lo = lo; R.leaf_cnt = cnt;
+    R.root_deg2 = R.nchild[R.root] == 2;
     R.inner_id.assign(N, 0xFFFFFFFFu);
     R.inner_node.clear();
     for (uint32_t v = 0; v < N; ++v)
@@ -900,6 +908,27 @@ static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
             R.lca[(size_t)j * n + i] = e;
         }
     }
+    if (R.bifurcating && R.root_deg2) {
+        // QuartetScoreComputer.hpp:390-410 for u = root: S1 = the root's other child subtree, S2 = the child subtree that
+        // holds v, S3 / S4 = v's child subtrees in depth-first order; all of them intervals of lookup ids
+        std::vector<std::vector<uint32_t>> kids(N);
+        for (uint32_t v = 0; v < N; ++v) if (R.parent[v] >= 0) kids[(uint32_t)R.parent[v]].push_back(v);
+        for (auto &k : kids) std::sort(k.begin(), k.end(), [&](uint32_t p_, uint32_t q_) { return lo[p_] < lo[q_]; });
+        const uint32_t rx = kids[R.root][0], ry = kids[R.root][1];
+        for (uint32_t v = 0; v < N; ++v) {
+            if (v == R.root || R.nchild[v] != 2) continue;
+            const bool in_x = lo[v] >= lo[rx] && lo[v] < lo[rx] + cnt[rx];
+            const uint32_t mine = in_x ? rx : ry, other = in_x ? ry : rx;
+            RootPairHost P{};
+            P.s1_lo = lo[other]; P.s1_n = cnt[other]; P.s2_lo = lo[mine]; P.s2_n = cnt[mine];
+            P.s3_lo = lo[kids[v][0]]; P.s3_n = cnt[kids[v][0]]; P.s4_lo = lo[kids[v][1]]; P.s4_n = cnt[kids[v][1]];
+            const uint32_t ir = R.inner_id[R.root], iv = R.inner_id[v];
+            P.key = std::min(ir, iv) * R.n_inner + std::max(ir, iv);
+            P.first = R.root_items;
+            R.root_items += (uint64_t)P.s1_n * P.s2_n * P.s3_n * P.s4_n;
+            R.root_pairs.push_back(P);
+        }
+    }
     R.next.assign((size_t)n * n, 0);
     for (uint32_t b = 1; b < n; ++b) {
         R.next[(size_t)b * n + (b - 1)] = (uint16_t)b;
@@ -922,7 +951,7 @@ static int get_ref(qs_ctx *c, const qs_ref_tree *ref, bool want_dev, const RefHo
         int rc = build_ref(c, ref, *fresh);
         if (rc != QS_OK) { delete fresh; return rc; }
         fresh->leaf_node_in.assign(ref->leaf_node, ref->leaf_node + ref->n_taxa);
-        if (c->ref_lca_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ref_lca_dev); (void)hipFree(c->ref_next_dev); c->ref_lca_dev = nullptr; c->ref_next_dev = nullptr; }
+        if (c->ref_lca_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ref_lca_dev); (void)hipFree(c->ref_next_dev); (void)hipFree(c->root_pairs_dev); c->ref_lca_dev = nullptr; c->ref_next_dev = nullptr; c->root_pairs_dev = nullptr; }
         delete c->ref_cache;
         c->ref_cache = R = fresh;
     }
@@ -931,6 +960,10 @@ static int get_ref(qs_ctx *c, const qs_ref_tree *ref, bool want_dev, const RefHo
         QS_HIP(c, hipMalloc(&c->ref_next_dev, R->next.size() * 2));
         QS_HIP(c, hipMemcpyAsync(c->ref_lca_dev, R->lca.data(), R->lca.size() * 4, hipMemcpyHostToDevice, c->stream));
         QS_HIP(c, hipMemcpyAsync(c->ref_next_dev, R->next.data(), R->next.size() * 2, hipMemcpyHostToDevice, c->stream));
+        if (!R->root_pairs.empty()) {
+            QS_HIP(c, hipMalloc(&c->root_pairs_dev, R->root_pairs.size() * sizeof(RootPairHost)));
+            QS_HIP(c, hipMemcpyAsync(c->root_pairs_dev, R->root_pairs.data(), R->root_pairs.size() * sizeof(RootPairHost), hipMemcpyHostToDevice, c->stream));
+        }
     }
     *out = R;
     return QS_OK;
@@ -1005,6 +1038,8 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
     QS_HIP(c, launch_score_pass1(c->stream, sd));
+    // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
+    if (c->root_pairs_dev) QS_HIP(c, launch_root_pair_sums(c->stream, sd, c->root_pairs_dev, (uint32_t)R.root_pairs.size(), R.root_items));
     return QS_OK;   // asynchronous on the context's stream
 }
 
@@ -1099,6 +1134,7 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
     int rc = c ? get_ref(c, ref, false, &Rp) : build_ref(nullptr, ref, local);
     if (rc != QS_OK) return rc;
     const RefHost &R = *Rp;
+    const bool root_as_edge = (flags & QS_SCORE_ROOT_AS_EDGE) != 0;
     if (is_bifurcating) *is_bifurcating = R.bifurcating ? 1 : 0;
     if (R.bifurcating && (!qpic || !eqpic)) return fail(c, QS_ERR_ARG, "qs_score: qpic/eqpic required for a bifurcating reference");
     const size_t np = (size_t)R.n_inner * R.n_inner;
@@ -1163,7 +1199,7 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
                     ++path_edges;
                 }
                 if (R.bifurcating) {
-                    const bool through_deg2_root = path_edges == 2 && x == R.root && R.nchild[R.root] == 2;
+                    const bool through_deg2_root = root_as_edge && path_edges == 2 && x == R.root && R.nchild[R.root] == 2;
                     if (path_edges == 1) { out.qp[last_edge_a] = qp; out.qp_set[last_edge_a] = 1; }
                     else if (through_deg2_root) { out.qp[last_edge_a] = qp; out.qp[last_edge_b] = qp; out.qp_set[last_edge_a] = out.qp_set[last_edge_b] = 1; }
                 }
@@ -1171,7 +1207,7 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned workers = R.n_inner >= 128 ? std::min(8u, hw) : 1u;
-    std::vector<Local> parts(workers);
+    std::vector<Local> parts(workers + 1);
     if (workers == 1) fold(0, R.n_inner, parts[0]);
     else {
         // ranges of iu with about the same number of pairs (row iu has n_inner - 1 - iu of them)
@@ -1188,6 +1224,23 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
         for (unsigned k = 0; k < workers; ++k) pool.emplace_back([&, k] { fold(cut[k], cut[k + 1], parts[k]); });
         for (auto &th : pool) th.join();
     }
+    if (R.bifurcating && R.root_deg2 && !root_as_edge) {
+        // Reference-compatible handling of a degree-2 root (quirk Q5, QuartetScoreComputer.hpp:393-396,472-489): every
+        // pair (root, v) has its own sums (root_pair_sums_kernel); QP-IC of the edge if v is a child of the root, EQP-IC
+        // minimum along the path. (Pairs are visited with u = root first in the reference: these come before all others.)
+        Local &L = parts[workers];
+        L.lq.assign(N, inf); L.qp.assign(N, inf); L.eqp.assign(N, inf); L.qp_set.assign(N, 0);
+        for (const RootPairHost &P : R.root_pairs) {
+            uint64_t p1 = sums[(size_t)P.key * 3], p2 = sums[(size_t)P.key * 3 + 1], p3 = sums[(size_t)P.key * 3 + 2];
+            if (!(flags & QS_SCORE_QP_EXACT64)) { p1 &= 0xFFFFFFFFull; p2 &= 0xFFFFFFFFull; p3 &= 0xFFFFFFFFull; }
+            const double qp = host_log_score(p1, p2, p3);
+            const uint32_t iu = P.key / R.n_inner, iv = P.key % R.n_inner;
+            uint32_t v = R.inner_node[iu] == R.root ? R.inner_node[iv] : R.inner_node[iu];
+            if ((uint32_t)R.parent[v] == R.root) { L.qp[v] = qp; L.qp_set[v] = 1; }
+            for (uint32_t x = v; x != R.root; x = (uint32_t)R.parent[x]) L.eqp[x] = std::min(L.eqp[x], qp);
+        }
+        std::rotate(parts.begin(), parts.begin() + workers, parts.end());   // merged first
+    } else parts.pop_back();
     for (const Local &L : parts) // in range order
         for (uint32_t v = 0; v < N; ++v) {
             lqic[v] = std::min(lqic[v], L.lq[v]);

@@ -107,6 +107,9 @@ uint32_t score_scan_max_lds_log();
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd);
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol);
 hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol);
+// sums of the node pairs (degree-2 root, v): pairs_dev = RootPairHost records (qs_abi.hip), total = number of (v,a,b,c,d) items
+struct RootPairHost { uint32_t s1_lo, s1_n, s2_lo, s2_n, s3_lo, s3_n, s4_lo, s4_n, key, pad; unsigned long long first; };
+hipError_t launch_root_pair_sums(hipStream_t s, const ScoreDevice &sd, const void *pairs_dev, uint32_t n_pairs, uint64_t total);
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
                           unsigned long long *q_dev);
 

@@ -379,6 +379,81 @@ hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, doub
     return sd.count_bits == 32 ? launch_scan<uint32_t, 3>(s, sd, tol) : launch_scan<uint16_t, 3>(s, sd, tol);
 }
 
+// ---- node pairs (root, v) of a reference tree with a degree-2 root --------
+// processNodePair takes the two subtrees beside the path with next() / next().next() on the link cycle
+// (QuartetScoreComputer.hpp:393-396). The root of a rooted Newick tree has only TWO links, so for a pair (root, v)
+// next().next() is the link towards v itself: S1 = the leaves on the other side of the root, S2 = ALL leaves on v's
+// side (v's own subtrees included), S3, S4 = v's two child subtrees. The reference then sums
+// countQuartetOccurrences(a,b,c,d) over S1 x S2 x S3 x S4 -- an argument that occurs twice reads cells of the n^4 table
+// that are never incremented, i.e. (0,0,0) -- and writes log_score of the sums to the QP-IC of the edge (root, v) if v is a
+// child of the root and to the EQP-IC minimum of every edge on the path. (Its per-quartet LQ-IC update goes to the path
+// between lca(b,v) and v, which the pair that really owns the quartet updates with the same value: LQ-IC is unaffected.)
+// This kernel produces those sums: item = (v, a, b, c, d); a workgroup reduces its items of one v and adds them to
+// pair_sums[key(root, v)]. Quartets outside this context's table shard / view contribute 0 (each rank adds its part).
+struct RootPair { uint32_t s1_lo, s1_n, s2_lo, s2_n, s3_lo, s3_n, s4_lo, s4_n, key, pad; unsigned long long first; }; // first = index of its first item
+template <typename CT>
+__global__ __launch_bounds__(256) void root_pair_sums_kernel(ScoreDevice sd, const RootPair *__restrict__ pairs, uint32_t n_pairs,
+                                                             unsigned long long total, uint32_t items_per_thread) {
+    __shared__ unsigned long long red[3][4];
+    const unsigned long long wg_first = (unsigned long long)blockIdx.x * 256ull * items_per_thread;
+    if (wg_first >= total) return;
+    // the pair that holds this workgroup's first item (uniform binary search); a workgroup that runs past the end of a
+    // pair flushes and moves on
+    uint32_t lo = 0, hi = n_pairs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pairs[mid].first <= wg_first) lo = mid; else hi = mid; }
+    uint32_t pi = lo;
+    const CT *table = reinterpret_cast<const CT *>(sd.table);
+    unsigned long long item = wg_first + threadIdx.x;
+    const unsigned long long wg_end = min(total, wg_first + 256ull * items_per_thread);
+    while (wg_first < wg_end) {   // (loop over the pairs this workgroup touches; usually one)
+        const RootPair P = pairs[pi];
+        const unsigned long long pair_end = (pi + 1 < n_pairs) ? pairs[pi + 1].first : total;
+        const unsigned long long stop = min(wg_end, pair_end);
+        unsigned long long s1 = 0, s2 = 0, s3 = 0;
+        for (; item < stop; item += 256) {
+            unsigned long long r = item - P.first;
+            const uint32_t d = P.s4_lo + (uint32_t)(r % P.s4_n); r /= P.s4_n;
+            const uint32_t c = P.s3_lo + (uint32_t)(r % P.s3_n); r /= P.s3_n;
+            const uint32_t b = P.s2_lo + (uint32_t)(r % P.s2_n); r /= P.s2_n;
+            const uint32_t a = P.s1_lo + (uint32_t)r;
+            if (b == c || b == d) continue;   // a repeated argument: (0,0,0)
+            uint32_t lo1 = min(a, b), hi1 = max(a, b), lo2 = min(c, d), hi2 = max(c, d);
+            uint32_t m0 = min(lo1, lo2), m3 = max(hi1, hi2);
+            uint32_t x1 = max(lo1, lo2), x2 = min(hi1, hi2);
+            uint32_t m1 = min(x1, x2), m2 = max(x1, x2);
+            const uint64_t rank = rank4(m0, m1, m2, m3);
+            if (rank < sd.rank_lo || rank - sd.rank_lo >= sd.n_tuples) continue;
+            const uint64_t cell = (rank - sd.rank_lo) * 3;
+            s1 += table[cell + slot_of_pairing(a, b, c, d)];
+            s2 += table[cell + slot_of_pairing(a, c, b, d)];
+            s3 += table[cell + slot_of_pairing(a, d, b, c)];
+        }
+        // workgroup reduction: waves by DPP-free shuffles, then LDS
+        for (int off = 32; off > 0; off >>= 1) {
+            s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); s3 += __shfl_down(s3, off, 64);
+        }
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();
+        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = s3; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const unsigned long long v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+            if (v) atomicAdd(&sd.pair_sums[(size_t)P.key * 3 + threadIdx.x], v);
+        }
+        if (stop >= wg_end) break;
+        ++pi;
+    }
+}
+
+hipError_t launch_root_pair_sums(hipStream_t s, const ScoreDevice &sd, const void *pairs_dev, uint32_t n_pairs, uint64_t total) {
+    if (total == 0 || n_pairs == 0) return hipSuccess;
+    const uint32_t ipt = 64;
+    dim3 block(256), grid((unsigned)((total + 256ull * ipt - 1) / (256ull * ipt)));
+    if (sd.count_bits == 32) hipLaunchKernelGGL(root_pair_sums_kernel<uint32_t>, grid, block, 0, s, sd, (const RootPair *)pairs_dev, n_pairs, (unsigned long long)total, ipt);
+    else hipLaunchKernelGGL(root_pair_sums_kernel<uint16_t>, grid, block, 0, s, sd, (const RootPair *)pairs_dev, n_pairs, (unsigned long long)total, ipt);
+    return hipGetLastError();
+}
+
 uint32_t score_scan_max_lds_log() { return kScanMaxLdsLog; }
 
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib, flatten, newick
 from ._lib import (QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_COUNT_OVERWRITE, QS_COUNT_TIMED, QS_COUNT_WIRE16X2, QS_SCORE_QP_EXACT64,  # noqa: F401
-                   QS_SCORE_QP_WRAP32)
+                   QS_SCORE_QP_WRAP32, QS_SCORE_ROOT_AS_EDGE)
 
 
 class QSError(RuntimeError):
@@ -331,7 +331,7 @@ class QuartetScoreComputer:
     edge; edge e is the edge above node e+1 of the reference tree in preorder."""
 
     def __init__(self, refTree: Union[str, flatten.RefTree], evalTreesPath, m: Optional[int] = None, verboseOutput: bool = False,
-                 enforceSmallMem: bool = False, *, qp_exact64: bool = False, log=None, **kw):
+                 enforceSmallMem: bool = False, *, qp_exact64: bool = False, root_as_edge: bool = False, log=None, **kw):
         self.ref = refTree if isinstance(refTree, flatten.RefTree) else flatten.flatten_reference(refTree)
         say = log or (lambda s: None)
         n = self.ref.n_taxa
@@ -341,7 +341,9 @@ class QuartetScoreComputer:
         say(f"lookup table size in bytes: {self.quartetCounterLookup.lookup_table_bytes}")
         say("Finished counting quartets.")
         ctx = self.quartetCounterLookup.ctx
-        lq, qp, eqp, bif = ctx.score(self.ref, QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32)
+        # root_as_edge: a degree-2 root as a subdivision of one edge instead of the reference's handling (quirk Q5)
+        lq, qp, eqp, bif = ctx.score(self.ref, (QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32) |
+                                     (QS_SCORE_ROOT_AS_EDGE if root_as_edge else 0))
         self.bifurcating = bif
         say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
         self._lq, self._qp, self._eqp = lq[1:], (qp[1:] if bif else None), (eqp[1:] if bif else None)

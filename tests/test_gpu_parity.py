@@ -536,11 +536,81 @@ def test_table_sharded_counting_and_scoring(eng, count_bits):
     assert assert_scores_equal(got, osc) == 0
 
 
-def test_rooted_reference_is_unrooted_for_scoring(eng, golden):
-    """Documented divergence from reference quirk Q5: a degree-2 root is an edge subdivision;
-    both root edges carry the scores the unrooted tree gives that internode."""
+def test_rooted_reference_matches_the_reference_quirk_D4(eng, golden):
+    """Default handling of a degree-2 root = the reference's (quirk Q5, QuartetScoreComputer.hpp:393-396): Appendix D4."""
     g4, g1 = golden["D4"], golden["D1"]
     qsc = eng.QuartetScoreComputer(g4["ref"], g1["eval"])
+    found = {}
+    names = frozenset(qsc.ref.names)
+    for e in range(qsc.ref.n_nodes - 1):
+        below = qsc.edge_leafset(e)
+        if 1 < len(below) < len(names) - 1:
+            found[below] = (qsc.getLQICScores()[e], qsc.getQPICScores()[e], qsc.getEQPICScores()[e])
+    for k, v in g4["scores_changed"].items():
+        kk = key_of(k)
+        got = found.get(kk) or found.get(names - kk)
+        assert list(got) == v, (k, got, v)
+    for k, v in g1["scores"].items():
+        if k in g4["scores_changed"]:
+            continue
+        kk = key_of(k)
+        got = found.get(kk) or found.get(names - kk)
+        assert list(got) == v, k
+
+
+@pytest.mark.parametrize("n,seed", [(9, 71), (24, 72), (41, 73)])
+def test_rooted_reference_random_matches_oracle(eng, n, seed):
+    """Rooted random references (degree-2 root) against the oracle, which follows the reference's link arithmetic;
+    also through table shards (every shard adds its part of the (root, v) sums) with wrap32 and 64-bit sums."""
+    import torch
+    rng = np.random.default_rng(seed)
+    ref_nw = synth.random_tree(n, rng, rooted=True)
+    trees = synth.tree_set(n, 60, seed + 100, collapse=0.1)
+    o = oracle_counts(ref_nw, trees)
+    for exact in (False, True):
+        o.score(qp_exact64=exact)
+        want = o.scores_by_bipartition()
+        qsc = eng.QuartetScoreComputer(ref_nw, trees, qp_exact64=exact)
+        got = qsc.scores_by_bipartition()
+        assert set(got) == set(want)
+        for k in got:
+            assert got[k] == want[k], (exact, sorted(k), got[k], want[k])
+    # three table shards
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctxs = []
+    for d_lo, d_hi in ((0, n // 2), (n // 2, n - 2), (n - 2, n)):
+        c = eng.Context(n, 32, d_lo=d_lo, d_hi=d_hi)
+        c.table_alloc()
+        c.count_trees(batch)
+        ctxs.append(c)
+    P = ctxs[0].score_pair_slots(ref)
+    sums = torch.zeros(3 * P, dtype=torch.int64, device="cuda")
+    mins = torch.full((P,), 2 ** 62, dtype=torch.int64, device="cuda")
+    parts = []
+    for c in ctxs:
+        s_ = torch.empty_like(sums); m_ = torch.empty_like(mins)
+        c.score_pass1(ref, s_, m_)
+        torch.cuda.synchronize()
+        sums += s_
+        mins = torch.minimum(mins, m_)
+    for c in ctxs:
+        cd = torch.empty(8 * P, dtype=torch.int64, device="cuda")
+        c.score_pass2(ref, mins, cd)
+        torch.cuda.synchronize()
+        parts.append(cd.cpu().numpy())
+    lq, qp, eqp, _ = ctxs[0].score_finish(ref, sums.cpu().numpy(), np.stack(parts), eng.QS_SCORE_QP_EXACT64)
+    whole = eng.QuartetScoreComputer(ref_nw, trees, qp_exact64=True)
+    assert (lq[1:] == np.array(whole.getLQICScores())).all()
+    assert (qp[1:] == np.array(whole.getQPICScores())).all()
+    assert (eqp[1:] == np.array(whole.getEQPICScores())).all()
+
+
+def test_rooted_reference_as_edge_subdivision(eng, golden):
+    """QS_SCORE_ROOT_AS_EDGE: a degree-2 root is an edge subdivision; both root edges carry the scores the unrooted
+    tree gives that internode (not what the reference prints: quirk Q5)."""
+    g4, g1 = golden["D4"], golden["D1"]
+    qsc = eng.QuartetScoreComputer(g4["ref"], g1["eval"], root_as_edge=True)
     found = {qsc.edge_leafset(e): (qsc.getLQICScores()[e], qsc.getQPICScores()[e], qsc.getEQPICScores()[e])
              for e in range(qsc.ref.n_nodes - 1)}
     want = g1["scores"]["t1,t3,t4,t5,t6"]
