@@ -280,6 +280,10 @@ int qs_score_finish(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, const i
  * q[3*i..] = (q1,q2,q3) in the reference's argument order for log_score.
  */
 int qs_raw_qic(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q);
+/* The same for the quartets number [i0, i0+nq) in LEXICOGRAPHIC order of their sorted lookup ids (a < b < c < d with a
+ * outermost, d innermost) -- the line order of the reference's -q file, which walks its Euler-tour leaf order with four
+ * nested loops (QuartetScoreComputer.hpp:626-630). Whole-table contexts only. */
+int qs_raw_qic_lex(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t i0, uint64_t nq, uint8_t *topo, uint64_t *q);
 
 /* ---- measurement hooks ------------------------------------------------------------------ */
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "qs_table_attach", "qs_table_pack16", "qs_table_pack16x2", "qs_wire_attach", "qs_unpack16x2", "qs_table_device_ptr", "qs_table_clear", "qs_table_download", "qs_table_upload",
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
-    "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host",
+    "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
 ]
 
 
@@ -131,6 +131,8 @@ def load():
     L.qs_free_host.argtypes = [vp]
     L.qs_raw_qic.restype = i32
     L.qs_raw_qic.argtypes = [vp, C.POINTER(RefTreeC), u64, u64, vp, vp]
+    L.qs_raw_qic_lex.restype = i32
+    L.qs_raw_qic_lex.argtypes = [vp, C.POINTER(RefTreeC), u64, u64, vp, vp]
     L.qs_last_count_ms.restype = i32
     L.qs_last_count_ms.argtypes = [vp, C.POINTER(C.c_float * 3)]
     L.qs_set_tuning.restype = i32

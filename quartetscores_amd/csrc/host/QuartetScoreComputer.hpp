@@ -248,8 +248,10 @@ public:
     // QuartetScoreComputer.hpp:623-690: "(a,b|c,d): qic" per quartet resolved in the reference tree.
     // The GPU classifies and looks up a chunk of ranks (qs_raw_qic); the host formats the chunk with all
     // ingest threads into per-thread buffers and writes them in order (the reference
-    // formats C(n,4) lines on one thread). Line order = table rank order; the reference's order is its
-    // Euler-tour loop order, the set of lines is the same.
+    // formats C(n,4) lines on one thread). Line order: the reference's own -- four nested loops over its Euler-tour
+    // leaves = lexicographic in the sorted lookup ids (:626-630; qs_raw_qic_lex) -- or, with raw_rank_order, the
+    // table's rank order (coalesced table reads; same set of lines).
+    bool raw_rank_order = false;
     void printRawQICScores(Tree const &refTree, const std::string &rawPath) {
         std::ofstream outfile(rawPath, std::ios::binary);
         const RefFlat &rf = quartetCounterLookup->reference();
@@ -264,13 +266,20 @@ public:
         std::vector<std::string> bufs(threads);
         for (uint64_t r = 0; r < total; r += chunk) {
             const uint64_t nq = std::min(chunk, total - r);
-            if (qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+            if ((raw_rank_order ? qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) : qs_raw_qic_lex(ctx, &rt, r, nq, topo.data(), q.data())) != QS_OK)
+                throw std::runtime_error(qs_last_error(ctx));
+            const uint32_t n = rt.n_taxa;
             auto work = [&](unsigned w) {
                 const uint64_t lo = nq * w / threads, hi = nq * (w + 1) / threads;
                 std::string &out = bufs[w];
                 out.clear();
                 uint32_t s0, s1, s2, s3;
-                unrank(r + lo, s0, s1, s2, s3);
+                if (raw_rank_order) unrank(r + lo, s0, s1, s2, s3);
+                else {   // lexicographic index -> ids through the mirrored set's rank (see qs_raw_qic_lex)
+                    uint32_t m0, m1, m2, m3;
+                    unrank(total - 1 - (r + lo), m0, m1, m2, m3);
+                    s0 = n - 1 - m3; s1 = n - 1 - m2; s2 = n - 1 - m1; s3 = n - 1 - m0;
+                }
                 char num[64];
                 for (uint64_t i = lo; i < hi; ++i) {
                     if (topo[i] != 255) {
@@ -282,7 +291,8 @@ public:
                         else { out += A; out += ','; out += D; out += '|'; out += B; out += ','; out += C; }
                         out += "): "; out += num; out += '\n';
                     }
-                    if (++s0 == s1) { s0 = 0; if (++s1 == s2) { s1 = 1; if (++s2 == s3) { s2 = 2; ++s3; } } } // next rank
+                    if (raw_rank_order) { if (++s0 == s1) { s0 = 0; if (++s1 == s2) { s1 = 1; if (++s2 == s3) { s2 = 2; ++s3; } } } } // next rank
+                    else if (++s3 == n) { if (++s2 == n - 1) { if (++s1 == n - 2) { ++s0; s1 = s0 + 1; } s2 = s1 + 1; } s3 = s2 + 1; } // next 4-subset in lexicographic order
                 }
             };
             if (threads == 1) work(0);

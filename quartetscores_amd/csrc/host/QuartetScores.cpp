@@ -25,7 +25,7 @@ namespace {
 struct Args {
     std::string ref, eval, out, raw, raw_bin;
     size_t threads = 0;
-    bool verbose = false, savemem = false;
+    bool verbose = false, savemem = false, raw_rank_order = false;
     DeviceOptions dev;
 };
 
@@ -41,6 +41,7 @@ void usage(std::ostream &os) {
           "   --device N     HIP device ordinal (default 0)\n"
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
+          "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
           "   --root-as-edge rooted reference tree: score the two root edges as one internode (the reference's\n"
           "                  own handling of a degree-2 root is the default)\n"
           "   --save-table F write the count table to F after counting\n"
@@ -87,6 +88,7 @@ int parse(int argc, char **argv, Args &a) {
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
         else if (f == "--root-as-edge") a.dev.root_as_edge = true;
+        else if (f == "--qic-rank-order") a.raw_rank_order = true;
         else if (f == "--save-table") { if (!(v = need(i, "--save-table"))) return 1; a.dev.save_table = v; }
         else if (f == "--qic-binary") { if (!(v = need(i, "--qic-binary"))) return 1; a.raw_bin = v; }
         else if (f == "--load-table") { if (!(v = need(i, "--load-table"))) return 1; a.dev.load_table = v; }
@@ -107,6 +109,7 @@ void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double>
     qpic = qsc.getQPICScores();
     eqpic = qsc.getEQPICScores();
     qsc.raw_threads = a.dev.ingest_threads;
+    qsc.raw_rank_order = a.raw_rank_order;
     if (!a.raw.empty()) qsc.printRawQICScores(referenceTree, a.raw);
     if (!a.raw_bin.empty()) qsc.printRawQICBinary(referenceTree, a.raw_bin);
 }

@@ -1282,9 +1282,10 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     return qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, extra, n_extra, lqic, qpic, eqpic, is_bifurcating);
 }
 
-extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q) {
+static int raw_qic_impl(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q, bool lex) {
     if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_raw_qic: no table");
     if (r0 + nq > c->n_tuples) return fail(c, QS_ERR_ARG, "qs_raw_qic: rank range outside this context's table");
+    if (lex && (c->d_lo != 0 || c->d_hi != c->n)) return fail(c, QS_ERR_UNSUPPORTED, "qs_raw_qic_lex: needs the whole table (not a shard)");
     if (nq == 0) return QS_OK;
     QS_HIP(c, hipSetDevice(c->device));
     const RefHost *Rp = nullptr;
@@ -1299,11 +1300,18 @@ extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64
     ScoreDevice sd;
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.frame = 1; // printRawQICScores uses the multifurcating loop's argument order
-    e = launch_raw_qic(c->stream, sd, r0, nq, dt, dq);
+    e = lex ? launch_raw_qic_lex(c->stream, sd, r0, nq, dt, dq) : launch_raw_qic(c->stream, sd, r0, nq, dt, dq);
     if (e == hipSuccess) e = hipMemcpyAsync(topo, dt, nq, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(q, dq, nq * 24, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(dt); (void)hipFree(dq);
     if (e != hipSuccess) return fail(c, QS_ERR_HIP, std::string("qs_raw_qic: ") + hipGetErrorString(e));
     return QS_OK;
+}
+
+extern "C" int qs_raw_qic(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q) {
+    return raw_qic_impl(c, ref, r0, nq, topo, q, false);
+}
+extern "C" int qs_raw_qic_lex(qs_ctx *c, const qs_ref_tree *ref, uint64_t i0, uint64_t nq, uint8_t *topo, uint64_t *q) {
+    return raw_qic_impl(c, ref, i0, nq, topo, q, true);
 }

@@ -112,5 +112,7 @@ struct RootPairHost { uint32_t s1_lo, s1_n, s2_lo, s2_n, s3_lo, s3_n, s4_lo, s4_
 hipError_t launch_root_pair_sums(hipStream_t s, const ScoreDevice &sd, const void *pairs_dev, uint32_t n_pairs, uint64_t total);
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
                           unsigned long long *q_dev);
+hipError_t launch_raw_qic_lex(hipStream_t s, const ScoreDevice &sd, uint64_t i0, uint64_t nq, uint8_t *topo_dev,
+                              unsigned long long *q_dev);
 
 } // namespace qs

@@ -456,6 +456,43 @@ hipError_t launch_root_pair_sums(hipStream_t s, const ScoreDevice &sd, const voi
 
 uint32_t score_scan_max_lds_log() { return kScanMaxLdsLog; }
 
+// The same per quartet, but item i = the i-th 4-subset in LEXICOGRAPHIC order of its sorted lookup ids (a outermost, d
+// innermost): the order in which printRawQICScores walks the reference's Euler-tour leaves
+// (QuartetScoreComputer.hpp:626-630). Lexicographic index i <-> rank r' = C(n,4)-1-i of the mirrored set
+// {n-1-d, n-1-c, n-1-b, n-1-a} in the table's own (colexicographic) order, so the block's ids come from one un-ranking
+// plus decode_near; the tuple is read at rank(a,b,c,d) (scattered reads: the dump is bound by its text output anyway).
+template <typename CT>
+__global__ __launch_bounds__(256) void raw_qic_lex_kernel(ScoreDevice sd, uint64_t i0, uint64_t nq, uint64_t total, uint8_t *__restrict__ topo,
+                                                          unsigned long long *__restrict__ qout) {
+    const uint64_t base = (uint64_t)blockIdx.x * (256ull * kP1Iters);
+    if (base >= nq) return;
+    const uint64_t len = min((uint64_t)256 * kP1Iters, nq - base);
+    Ids4 low;   // mirrored ids of the block's LAST item (smallest mirrored rank)
+    const uint64_t r_min = total - 1 - (i0 + base + len - 1);
+    unrank4(r_min, low.a, low.b, low.c, low.d);
+    for (int it = 0; it < kP1Iters; ++it) {
+        const uint64_t t = (uint64_t)it * 256 + threadIdx.x;
+        if (t >= len) return;
+        const Ids4 m = decode_near(low, (uint32_t)(len - 1 - t));
+        Ids4 ids;
+        ids.a = sd.n - 1 - m.d; ids.b = sd.n - 1 - m.c; ids.c = sd.n - 1 - m.b; ids.d = sd.n - 1 - m.a;
+        const QuartetRef q = classify<CT>(sd, rank4(ids.a, ids.b, ids.c, ids.d) - sd.rank_lo, ids);
+        const uint64_t i = base + t;
+        topo[i] = q.topo;
+        qout[3 * i] = q.q1; qout[3 * i + 1] = q.q2; qout[3 * i + 2] = q.q3;
+    }
+}
+
+hipError_t launch_raw_qic_lex(hipStream_t s, const ScoreDevice &sd, uint64_t i0, uint64_t nq, uint8_t *topo_dev,
+                              unsigned long long *q_dev) {
+    if (nq == 0) return hipSuccess;
+    const uint64_t per_block = 256ull * kP1Iters, total = binom4(sd.n);
+    dim3 block(256), grid((unsigned)((nq + per_block - 1) / per_block));
+    if (sd.count_bits == 32) hipLaunchKernelGGL(raw_qic_lex_kernel<uint32_t>, grid, block, 0, s, sd, i0, nq, total, topo_dev, q_dev);
+    else hipLaunchKernelGGL(raw_qic_lex_kernel<uint16_t>, grid, block, 0, s, sd, i0, nq, total, topo_dev, q_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_raw_qic(hipStream_t s, const ScoreDevice &sd, uint64_t r0, uint64_t nq, uint8_t *topo_dev,
                           unsigned long long *q_dev) {
     if (nq == 0) return hipSuccess;

@@ -247,11 +247,14 @@ class Context:
         score_overflow (concatenated over the shards) or None."""
         return score_finish_host(ref, sums_host, cand_host, flags, extra=extra, _ctx=self)
 
-    def raw_qic(self, ref: flatten.RefTree, r0: int, nq: int):
+    def raw_qic(self, ref: flatten.RefTree, r0: int, nq: int, lex: bool = False):
+        """topology + count triple of nq quartets from rank r0 on (lex=False) or from the r0-th 4-subset in lexicographic
+        order of the sorted ids on (lex=True: the reference's -q line order)."""
         s, keep = self._ref_struct(ref)
         topo = np.zeros(nq, dtype=np.uint8)
         q = np.zeros((nq, 3), dtype=np.uint64)
-        self._chk(self.L.qs_raw_qic(self.h, C.byref(s), r0, nq, topo.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)))
+        f = self.L.qs_raw_qic_lex if lex else self.L.qs_raw_qic
+        self._chk(f(self.h, C.byref(s), r0, nq, topo.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)))
         del keep
         return topo, q
 
@@ -380,23 +383,23 @@ class QuartetScoreComputer:
         return out
 
     def printRawQICScores(self, rawPath: str, chunk: int = 1 << 20):
-        """-q file: "(a,b|c,d): qic" per quartet resolved in the reference, in rank order.
-        (The reference prints in its Euler-tour loop order, QuartetScoreComputer.hpp:627-630; the set of
-        lines is the same.) QIC via the host libm; %g like operator<<(double)."""
+        """-q file: "(a,b|c,d): qic" per quartet resolved in the reference, in the reference's own line order: four
+        nested loops over its Euler-tour leaves = lexicographic in the sorted lookup ids
+        (QuartetScoreComputer.hpp:626-690). QIC via the host libm; %g like operator<<(double)."""
+        import itertools
         ctx = self.quartetCounterLookup.ctx
         names = self.ref.names
         total = ctx.table_tuples
-        from .ranks import unrank4_np
+        combos = itertools.combinations(range(len(names)), 4)     # lexicographic
         with open(rawPath, "w") as f:
             for r0 in range(0, total, chunk):
                 nq = min(chunk, total - r0)
-                topo, q = ctx.raw_qic(self.ref, r0, nq)
-                ids = unrank4_np(np.arange(r0, r0 + nq, dtype=np.int64))
+                topo, q = ctx.raw_qic(self.ref, r0, nq, lex=True)
                 for i in range(nq):
+                    a, b, c, d = next(combos)
                     t = topo[i]
                     if t == 255:
                         continue
-                    a, b, c, d = (int(x) for x in ids[i])
                     if t == 0:
                         lab = (names[a], names[b], names[c], names[d])
                     else:

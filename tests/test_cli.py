@@ -250,6 +250,11 @@ def test_cli_end_to_end_matches_oracle(d1_files, tmp_path, golden):
             d[frozenset([frozenset(l.split(",")), frozenset(rr.split(","))])] = val
         return d
     assert canon(str(raw)) == canon(str(ora_raw)) and len(canon(str(raw))) == 70
+    assert raw.read_text() == ora_raw.read_text()      # byte-identical: the reference's line and label order
+    raw2 = tmp_path / "raw_rank.txt"                      # table-rank order: the same lines in another order
+    p = run("-r", r, "-e", e, "-o", str(tmp_path / "o_rank.nwk"), "-q", str(raw2), "--qic-rank-order")
+    assert p.returncode == 0, p.stderr
+    assert sorted(raw2.read_text().splitlines()) == sorted(raw.read_text().splitlines()) and raw2.read_text() != raw.read_text()
     # binary sidecar of the raw QIC dump: same quartets, same topologies, QIC equal to the printed %g value
     import struct
     import numpy as np

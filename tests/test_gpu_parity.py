@@ -644,6 +644,9 @@ def test_raw_qic_lines_match_oracle(eng, tmp_path):
     # same quartet, same topology; the printed QIC may differ only in the p2/p3 argument order
     same = sum(a[k] == b[k] for k in a)
     assert same == len(a)
+    # and the FILE is the reference's: same line order (its four nested loops over the Euler-tour leaves), same order of
+    # the labels inside a line
+    assert open(p1).read() == open(p2).read()
 
 
 # ---- BASELINE configs[1] at full size: size-independent properties -----------------------------
