@@ -192,6 +192,122 @@ private:
     }
 };
 
+    // rank -> sorted ids (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0)
+inline void raw_unrank(uint64_t r, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3) {
+        auto c4 = [](uint64_t x) { return x < 4 ? 0 : x * (x - 1) * (x - 2) * (x - 3) / 24; };
+        auto c3 = [](uint64_t x) { return x < 3 ? 0 : x * (x - 1) * (x - 2) / 6; };
+        auto c2 = [](uint64_t x) { return x * (x - 1) / 2; };
+        uint64_t d = 3; while (c4(d + 1) <= r) ++d;
+        r -= c4(d);
+        uint64_t c = 2; while (c3(c + 1) <= r) ++c;
+        r -= c3(c);
+        uint64_t b = 1; while (c2(b + 1) <= r) ++b;
+        r -= c2(b);
+        s0 = (uint32_t)r; s1 = (uint32_t)b; s2 = (uint32_t)c; s3 = (uint32_t)d;
+    }
+
+    // QuartetScoreComputer.hpp:135-159 with the host libm
+inline double raw_log_score(size_t q1, size_t q2, size_t q3) {
+        if (q1 == 0 && q2 == 0 && q3 == 0) return 0;
+        size_t sum = q1 + q2 + q3;
+        double p1 = (double)q1 / sum, p2 = (double)q2 / sum, p3 = (double)q3 / sum;
+        double qic = 1;
+        if (p1 != 0) qic += p1 * std::log(p1) / std::log(3);
+        if (p2 != 0) qic += p2 * std::log(p2) / std::log(3);
+        if (p3 != 0) qic += p3 * std::log(p3) / std::log(3);
+        return (q1 < q2 || q1 < q3) ? qic * -1 : qic;
+    }
+
+
+    // QuartetScoreComputer.hpp:623-690: "(a,b|c,d): qic" per quartet resolved in the reference tree.
+    // The GPU classifies and looks up a chunk of ranks (qs_raw_qic); the host formats the chunk with all
+    // ingest threads into per-thread buffers and writes them in order (SURVEY.md 8(f) rank 2: the reference
+    // formats C(n,4) lines on one thread). Line order: the reference's own -- four nested loops over its Euler-tour
+    // leaves = lexicographic in the sorted lookup ids (:626-630; qs_raw_qic_lex) -- or, with raw_rank_order, the
+    // table's rank order (coalesced table reads; same set of lines).
+inline void print_raw_qic_scores(qs_ctx *ctx, const RefFlat &rf, Tree const &refTree, const std::string &rawPath, unsigned raw_threads, bool raw_rank_order) {
+        std::ofstream outfile(rawPath, std::ios::binary);
+        qs_ref_tree rt;
+        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
+        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
+        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 22;
+        std::vector<uint8_t> topo(chunk);
+        std::vector<uint64_t> q(chunk * 3);
+        const unsigned threads = std::max(1u, raw_threads ? raw_threads : std::thread::hardware_concurrency());
+        std::vector<std::string> bufs(threads);
+        for (uint64_t r = 0; r < total; r += chunk) {
+            const uint64_t nq = std::min(chunk, total - r);
+            if ((raw_rank_order ? qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) : qs_raw_qic_lex(ctx, &rt, r, nq, topo.data(), q.data())) != QS_OK)
+                throw std::runtime_error(qs_last_error(ctx));
+            const uint32_t n = rt.n_taxa;
+            auto work = [&](unsigned w) {
+                const uint64_t lo = nq * w / threads, hi = nq * (w + 1) / threads;
+                std::string &out = bufs[w];
+                out.clear();
+                uint32_t s0, s1, s2, s3;
+                if (raw_rank_order) raw_unrank(r + lo, s0, s1, s2, s3);
+                else {   // lexicographic index -> ids through the mirrored set's rank (see qs_raw_qic_lex)
+                    uint32_t m0, m1, m2, m3;
+                    raw_unrank(total - 1 - (r + lo), m0, m1, m2, m3);
+                    s0 = n - 1 - m3; s1 = n - 1 - m2; s2 = n - 1 - m1; s3 = n - 1 - m0;
+                }
+                char num[64];
+                for (uint64_t i = lo; i < hi; ++i) {
+                    if (topo[i] != 255) {
+                        const std::string &A = rf.names[s0], &B = rf.names[s1], &C = rf.names[s2], &D = rf.names[s3];
+                        // operator<<(double) with default precision == "%g"
+                        snprintf(num, sizeof num, "%g", raw_log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]));
+                        out += '(';
+                        if (topo[i] == 0) { out += A; out += ','; out += B; out += '|'; out += C; out += ','; out += D; }
+                        else { out += A; out += ','; out += D; out += '|'; out += B; out += ','; out += C; }
+                        out += "): "; out += num; out += '\n';
+                    }
+                    if (raw_rank_order) { if (++s0 == s1) { s0 = 0; if (++s1 == s2) { s1 = 1; if (++s2 == s3) { s2 = 2; ++s3; } } } } // next rank
+                    else if (++s3 == n) { if (++s2 == n - 1) { if (++s1 == n - 2) { ++s0; s1 = s0 + 1; } s2 = s1 + 1; } s3 = s2 + 1; } // next 4-subset in lexicographic order
+                }
+            };
+            if (threads == 1) work(0);
+            else {
+                std::vector<std::thread> pool;
+                for (unsigned w = 0; w < threads; ++w) pool.emplace_back(work, w);
+                for (auto &th : pool) th.join();
+            }
+            for (auto &b : bufs) outfile.write(b.data(), (std::streamsize)b.size());
+        }
+        outfile.close();
+    }
+    // Binary sidecar of the -q dump (SURVEY.md 8(f) rank 2): no text formatting, 9 bytes per quartet instead of ~35.
+    //   char magic[8] = "QSQIC01"; u32 n_taxa; u32 reserved; u64 n_quartets;
+    //   n_taxa x { u32 length; bytes }            taxon names in lookup-id order
+    //   u8  topo[n_quartets]                      per rank (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0 of the sorted lookup ids):
+    //                                             0 = s0 s1 | s2 s3, 2 = s0 s3 | s1 s2, 255 = not resolved in the reference
+    //   f64 qic[n_quartets]                       raw QIC of the reference topology (NaN where topo = 255)
+inline void print_raw_qic_binary(qs_ctx *ctx, const RefFlat &rf, Tree const &refTree, const std::string &path) {
+        std::ofstream out(path, std::ios::binary);
+        if (!out) throw std::runtime_error("cannot write " + path);
+        qs_ref_tree rt;
+        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
+        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
+        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 22;
+        const char magic[8] = {'Q', 'S', 'Q', 'I', 'C', '0', '1', 0};
+        const uint32_t n32 = rt.n_taxa, zero = 0;
+        out.write(magic, 8); out.write((const char *)&n32, 4); out.write((const char *)&zero, 4); out.write((const char *)&total, 8);
+        for (const std::string &nm : rf.names) { const uint32_t len = (uint32_t)nm.size(); out.write((const char *)&len, 4); out.write(nm.data(), len); }
+        const std::streamoff topo_at = out.tellp(), qic_at = topo_at + (std::streamoff)total;
+        std::vector<uint8_t> topo(chunk);
+        std::vector<uint64_t> q(chunk * 3);
+        std::vector<double> qic(chunk);
+        for (uint64_t r = 0; r < total; r += chunk) {
+            const uint64_t nq = std::min(chunk, total - r);
+            if (qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+            for (uint64_t i = 0; i < nq; ++i)
+                qic[i] = topo[i] == 255 ? std::numeric_limits<double>::quiet_NaN() : raw_log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+            out.seekp(topo_at + (std::streamoff)r); out.write((const char *)topo.data(), (std::streamsize)nq);
+            out.seekp(qic_at + (std::streamoff)(r * 8)); out.write((const char *)qic.data(), (std::streamsize)(nq * 8));
+        }
+        if (!out) throw std::runtime_error("error writing " + path);
+    }
+
 template <typename CINT> class QuartetScoreComputer {
 public:
     QuartetScoreComputer(Tree const &refTree, const std::string &evalTreesPath, size_t m, bool verboseOutput,
@@ -245,126 +361,15 @@ public:
     std::vector<double> getQPICScores() { return QPICScores; }
     std::vector<double> getEQPICScores() { return EQPICScores; }
 
-    // QuartetScoreComputer.hpp:623-690: "(a,b|c,d): qic" per quartet resolved in the reference tree.
-    // The GPU classifies and looks up a chunk of ranks (qs_raw_qic); the host formats the chunk with all
-    // ingest threads into per-thread buffers and writes them in order (SURVEY.md 8(f) rank 2: the reference
-    // formats C(n,4) lines on one thread). Line order: the reference's own -- four nested loops over its Euler-tour
-    // leaves = lexicographic in the sorted lookup ids (:626-630; qs_raw_qic_lex) -- or, with raw_rank_order, the
-    // table's rank order (coalesced table reads; same set of lines).
+    // -q dump and its binary sidecar (print_raw_qic_scores / print_raw_qic_binary above)
     bool raw_rank_order = false;
     void printRawQICScores(Tree const &refTree, const std::string &rawPath) {
-        std::ofstream outfile(rawPath, std::ios::binary);
-        const RefFlat &rf = quartetCounterLookup->reference();
-        qs_ctx *ctx = quartetCounterLookup->context();
-        qs_ref_tree rt;
-        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
-        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
-        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 22;
-        std::vector<uint8_t> topo(chunk);
-        std::vector<uint64_t> q(chunk * 3);
-        const unsigned threads = std::max(1u, raw_threads ? raw_threads : std::thread::hardware_concurrency());
-        std::vector<std::string> bufs(threads);
-        for (uint64_t r = 0; r < total; r += chunk) {
-            const uint64_t nq = std::min(chunk, total - r);
-            if ((raw_rank_order ? qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) : qs_raw_qic_lex(ctx, &rt, r, nq, topo.data(), q.data())) != QS_OK)
-                throw std::runtime_error(qs_last_error(ctx));
-            const uint32_t n = rt.n_taxa;
-            auto work = [&](unsigned w) {
-                const uint64_t lo = nq * w / threads, hi = nq * (w + 1) / threads;
-                std::string &out = bufs[w];
-                out.clear();
-                uint32_t s0, s1, s2, s3;
-                if (raw_rank_order) unrank(r + lo, s0, s1, s2, s3);
-                else {   // lexicographic index -> ids through the mirrored set's rank (see qs_raw_qic_lex)
-                    uint32_t m0, m1, m2, m3;
-                    unrank(total - 1 - (r + lo), m0, m1, m2, m3);
-                    s0 = n - 1 - m3; s1 = n - 1 - m2; s2 = n - 1 - m1; s3 = n - 1 - m0;
-                }
-                char num[64];
-                for (uint64_t i = lo; i < hi; ++i) {
-                    if (topo[i] != 255) {
-                        const std::string &A = rf.names[s0], &B = rf.names[s1], &C = rf.names[s2], &D = rf.names[s3];
-                        // operator<<(double) with default precision == "%g"
-                        snprintf(num, sizeof num, "%g", log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]));
-                        out += '(';
-                        if (topo[i] == 0) { out += A; out += ','; out += B; out += '|'; out += C; out += ','; out += D; }
-                        else { out += A; out += ','; out += D; out += '|'; out += B; out += ','; out += C; }
-                        out += "): "; out += num; out += '\n';
-                    }
-                    if (raw_rank_order) { if (++s0 == s1) { s0 = 0; if (++s1 == s2) { s1 = 1; if (++s2 == s3) { s2 = 2; ++s3; } } } } // next rank
-                    else if (++s3 == n) { if (++s2 == n - 1) { if (++s1 == n - 2) { ++s0; s1 = s0 + 1; } s2 = s1 + 1; } s3 = s2 + 1; } // next 4-subset in lexicographic order
-                }
-            };
-            if (threads == 1) work(0);
-            else {
-                std::vector<std::thread> pool;
-                for (unsigned w = 0; w < threads; ++w) pool.emplace_back(work, w);
-                for (auto &th : pool) th.join();
-            }
-            for (auto &b : bufs) outfile.write(b.data(), (std::streamsize)b.size());
-        }
-        outfile.close();
+        print_raw_qic_scores(quartetCounterLookup->context(), quartetCounterLookup->reference(), refTree, rawPath, raw_threads, raw_rank_order);
     }
-    // Binary sidecar of the -q dump (SURVEY.md 8(f) rank 2): no text formatting, 9 bytes per quartet instead of ~35.
-    //   char magic[8] = "QSQIC01"; u32 n_taxa; u32 reserved; u64 n_quartets;
-    //   n_taxa x { u32 length; bytes }            taxon names in lookup-id order
-    //   u8  topo[n_quartets]                      per rank (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0 of the sorted lookup ids):
-    //                                             0 = s0 s1 | s2 s3, 2 = s0 s3 | s1 s2, 255 = not resolved in the reference
-    //   f64 qic[n_quartets]                       raw QIC of the reference topology (NaN where topo = 255)
     void printRawQICBinary(Tree const &refTree, const std::string &path) {
-        std::ofstream out(path, std::ios::binary);
-        if (!out) throw std::runtime_error("cannot write " + path);
-        const RefFlat &rf = quartetCounterLookup->reference();
-        qs_ctx *ctx = quartetCounterLookup->context();
-        qs_ref_tree rt;
-        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)rf.names.size();
-        rt.parent = rf.parent.data(); rt.leaf_node = rf.leaf_node.data();
-        const uint64_t total = qs_table_tuples(ctx), chunk = 1u << 22;
-        const char magic[8] = {'Q', 'S', 'Q', 'I', 'C', '0', '1', 0};
-        const uint32_t n32 = rt.n_taxa, zero = 0;
-        out.write(magic, 8); out.write((const char *)&n32, 4); out.write((const char *)&zero, 4); out.write((const char *)&total, 8);
-        for (const std::string &nm : rf.names) { const uint32_t len = (uint32_t)nm.size(); out.write((const char *)&len, 4); out.write(nm.data(), len); }
-        const std::streamoff topo_at = out.tellp(), qic_at = topo_at + (std::streamoff)total;
-        std::vector<uint8_t> topo(chunk);
-        std::vector<uint64_t> q(chunk * 3);
-        std::vector<double> qic(chunk);
-        for (uint64_t r = 0; r < total; r += chunk) {
-            const uint64_t nq = std::min(chunk, total - r);
-            if (qs_raw_qic(ctx, &rt, r, nq, topo.data(), q.data()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-            for (uint64_t i = 0; i < nq; ++i)
-                qic[i] = topo[i] == 255 ? std::numeric_limits<double>::quiet_NaN() : log_score(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
-            out.seekp(topo_at + (std::streamoff)r); out.write((const char *)topo.data(), (std::streamsize)nq);
-            out.seekp(qic_at + (std::streamoff)(r * 8)); out.write((const char *)qic.data(), (std::streamsize)(nq * 8));
-        }
-        if (!out) throw std::runtime_error("error writing " + path);
+        print_raw_qic_binary(quartetCounterLookup->context(), quartetCounterLookup->reference(), refTree, path);
     }
     unsigned raw_threads = 0; // threads that format the -q file (0 = hardware concurrency)
-
-    // rank -> sorted ids (rank = C(s3,4)+C(s2,3)+C(s1,2)+s0)
-    static void unrank(uint64_t r, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3) {
-        auto c4 = [](uint64_t x) { return x < 4 ? 0 : x * (x - 1) * (x - 2) * (x - 3) / 24; };
-        auto c3 = [](uint64_t x) { return x < 3 ? 0 : x * (x - 1) * (x - 2) / 6; };
-        auto c2 = [](uint64_t x) { return x * (x - 1) / 2; };
-        uint64_t d = 3; while (c4(d + 1) <= r) ++d;
-        r -= c4(d);
-        uint64_t c = 2; while (c3(c + 1) <= r) ++c;
-        r -= c3(c);
-        uint64_t b = 1; while (c2(b + 1) <= r) ++b;
-        r -= c2(b);
-        s0 = (uint32_t)r; s1 = (uint32_t)b; s2 = (uint32_t)c; s3 = (uint32_t)d;
-    }
-
-    // QuartetScoreComputer.hpp:135-159 with the host libm
-    static double log_score(size_t q1, size_t q2, size_t q3) {
-        if (q1 == 0 && q2 == 0 && q3 == 0) return 0;
-        size_t sum = q1 + q2 + q3;
-        double p1 = (double)q1 / sum, p2 = (double)q2 / sum, p3 = (double)q3 / sum;
-        double qic = 1;
-        if (p1 != 0) qic += p1 * std::log(p1) / std::log(3);
-        if (p2 != 0) qic += p2 * std::log(p2) / std::log(3);
-        if (p3 != 0) qic += p3 * std::log(p3) / std::log(3);
-        return (q1 < q2 || q1 < q3) ? qic * -1 : qic;
-    }
 
 private:
     Tree referenceTree;

@@ -9,6 +9,7 @@
 // GPU table is always the compact C(n,4)x3 layout with semantic (1x) counts.
 // --save-table / --load-table write / read the raw count table (resume without recounting).
 #include "QuartetScoreComputer.hpp"
+#include "multi_gpu.hpp"
 
 #include <cerrno>
 #include <chrono>
@@ -26,6 +27,7 @@ struct Args {
     std::string ref, eval, out, raw, raw_bin;
     size_t threads = 0;
     bool verbose = false, savemem = false, raw_rank_order = false;
+    int gpus = 0;   // 0 = the single-GPU path; N >= 1 = trees split over N GPUs of this node + one RCCL collective (multi_gpu.hpp)
     DeviceOptions dev;
 };
 
@@ -39,6 +41,8 @@ void usage(std::ostream &os) {
           "   -v, --verbose  Verbose mode\n"
           "   -s, --savemem  Consume less memory (accepted; the GPU table is always the compact one)\n"
           "   --device N     HIP device ordinal (default 0)\n"
+          "   --gpus N       split the evaluation trees over N GPUs of this node (devices --device .. --device+N-1) and\n"
+          "                  combine the count tables with one RCCL collective over xGMI\n"
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
           "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
@@ -82,6 +86,7 @@ int parse(int argc, char **argv, Args &a) {
         else if (f == "-t" || f == "--threads") { if (!(v = need(i, "-t (--threads)")) || !number(v, "-t (--threads)", num)) return 1; a.threads = num; }
         else if (f == "-v" || f == "--verbose") a.verbose = true;
         else if (f == "-s" || f == "--savemem") a.savemem = true;
+        else if (f == "--gpus") { if (!(v = need(i, "--gpus")) || !number(v, "--gpus", num)) return 1; a.gpus = (int)num; }
         else if (f == "--device") { if (!(v = need(i, "--device")) || !number(v, "--device", num)) return 1; a.dev.device = (int)num; }
         else if (f == "--algo") {
             if (!(v = need(i, "--algo"))) return 1;
@@ -101,9 +106,21 @@ int parse(int argc, char **argv, Args &a) {
     return 0;
 }
 
+// --gpus N: trees split over N GPUs, one collective on the table, sharded scoring (multi_gpu.hpp)
+void run_multi(const Tree &referenceTree, const Args &a, size_t m, uint32_t count_bits, std::vector<double> &lqic,
+               std::vector<double> &qpic, std::vector<double> &eqpic) {
+    if (!a.dev.load_table.empty() || !a.dev.save_table.empty()) throw std::runtime_error("--save-table / --load-table work on one GPU (omit --gpus)");
+    const bool need_full = !a.raw.empty() || !a.raw_bin.empty();   // the -q dump walks the whole table on one GPU
+    MultiGpuQuartetScoreComputer mg(referenceTree, a.eval, m, count_bits, a.gpus, need_full, a.dev);
+    lqic = mg.scores.lq; qpic = mg.scores.qp; eqpic = mg.scores.eqp;
+    if (!a.raw.empty()) print_raw_qic_scores(mg.context0(), mg.reference(), referenceTree, a.raw, a.dev.ingest_threads, a.raw_rank_order);
+    if (!a.raw_bin.empty()) print_raw_qic_binary(mg.context0(), mg.reference(), referenceTree, a.raw_bin);
+}
+
 template <typename CINT>
 void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double> &lqic, std::vector<double> &qpic,
          std::vector<double> &eqpic) {
+    if (a.gpus > 0) return run_multi(referenceTree, a, m, sizeof(CINT) <= 2 ? 16u : 32u, lqic, qpic, eqpic);
     QuartetScoreComputer<CINT> qsc(referenceTree, a.eval, m, a.verbose, a.savemem, a.dev);
     lqic = qsc.getLQICScores();
     qpic = qsc.getQPICScores();

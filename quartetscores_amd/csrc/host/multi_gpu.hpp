@@ -1,0 +1,241 @@
+// multi_gpu.hpp -- the C++ host on N GPUs of one node (`QuartetScores --gpus N`).
+//
+// The reference has no counterpart (one process, OpenMP). Evaluation trees are independent and counts
+// add (QuartetCounterLookup.hpp:196-238 walks them one by one), so the trees are split over the GPUs:
+//   1. one host thread + one C-ABI context per GPU; thread g parses, flattens and counts the trees
+//      [g m / N, (g + 1) m / N) into its own full table (the table lives in memory this file allocates, qs_table_attach,
+//      padded to N equal chunks);
+//   2. ONE RCCL collective on the tables over xGMI (single process: ncclCommInitAll + a group call):
+//        reduce-scatter (default): GPU g ends with tuples [g T, (g + 1) T) of the summed table, half the bytes per link
+//        of an all-reduce, and scores that shard in place (qs_score_set_view);
+//        all-reduce (when the -q dump needs the whole table on one GPU): GPU 0 scores alone (qs_score);
+//   3. sharded scoring: qs_score_pass1 on every GPU, the per-node-pair sums / minima (a few MB) are added / minimised on
+//      the host and the minima handed back, qs_score_pass2 + qs_score_overflow on every GPU, qs_score_finish on the host.
+// u16 tables travel as packed 32-bit words: every total stays below 2^16 (m < 65536 is what selects u16), so no carry
+// crosses a half-word. Same scores as one GPU (tests/test_cli.py runs --gpus 1 through this path against the oracle).
+#pragma once
+
+#include "QuartetScoreComputer.hpp"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <mutex>
+
+namespace qsh {
+
+#define QSM_HIP(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+#define QSM_NCCL(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r__ = (expr);                                                                         \
+        if (r__ != ncclSuccess) throw std::runtime_error(std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+    } while (0)
+
+struct MultiGpuScores {
+    std::vector<double> lq, qp, eqp; // per edge (edge e = edge above node e + 1), qp / eqp empty for a multifurcating reference
+    bool bifurcating = false;
+};
+
+class MultiGpuQuartetScoreComputer {
+public:
+    // count_bits 16 | 32 (by m like QuartetScores.cpp:115-147); need_full_table: all-reduce instead of reduce-scatter
+    MultiGpuQuartetScoreComputer(Tree const &refTree, const std::string &evalTreesPath, size_t m, uint32_t count_bits, int n_gpus,
+                                 bool need_full_table, DeviceOptions opt)
+        : ref_(flatten_reference(refTree)), opt_(opt), bits_(count_bits), full_(need_full_table) {
+        int ndev = 0;
+        QSM_HIP(hipGetDeviceCount(&ndev));
+        if (n_gpus < 1 || n_gpus > ndev) throw std::runtime_error("--gpus " + std::to_string(n_gpus) + ": " + std::to_string(ndev) + " device(s) visible");
+        G_ = n_gpus;
+        std::cout << "There are " << m << " evaluation trees.\n";
+        std::cout << "The reference tree has " << ref_.names.size() << " taxa.\n";
+        std::cout << "Counting on " << G_ << " GPU(s): trees split over the GPUs, one RCCL " << (full_ ? "all-reduce" : "reduce-scatter") << " of the count table.\n";
+        const auto t0 = std::chrono::steady_clock::now();
+        ctx_.assign(G_, nullptr);
+        table_.assign(G_, nullptr);
+        try {
+            count(evalTreesPath, m);
+            reduce();
+            const auto t1 = std::chrono::steady_clock::now();
+            std::cout << "Finished counting quartets.\nIt took: " << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << " microseconds." << std::endl;
+            score(refTree);
+            const auto t2 = std::chrono::steady_clock::now();
+            std::cout << (scores.bifurcating ? "The reference tree is bifurcating.\n" : "The reference tree is multifurcating.\n");
+            std::cout << "Finished computing scores.\nIt took: " << std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count() << " microseconds." << std::endl;
+        } catch (...) {
+            release();
+            throw;
+        }
+    }
+    ~MultiGpuQuartetScoreComputer() { release(); }
+    MultiGpuQuartetScoreComputer(const MultiGpuQuartetScoreComputer &) = delete;
+    MultiGpuQuartetScoreComputer &operator=(const MultiGpuQuartetScoreComputer &) = delete;
+
+    MultiGpuScores scores;
+    qs_ctx *context0() const { return ctx_[0]; }        // holds the whole table after an all-reduce (-q)
+    const RefFlat &reference() const { return ref_; }
+
+private:
+    RefFlat ref_;
+    DeviceOptions opt_;
+    uint32_t bits_;
+    bool full_;
+    int G_ = 1;
+    std::vector<qs_ctx *> ctx_;
+    std::vector<void *> table_;
+    uint64_t tuples_ = 0, chunk_tuples_ = 0, chunk_words_ = 0;
+
+    void release() {
+        for (int g = 0; g < (int)ctx_.size(); ++g) {
+            if (ctx_[g]) qs_destroy(ctx_[g]);
+            if (table_[g]) { (void)hipSetDevice(opt_.device + g); (void)hipFree(table_[g]); }
+        }
+        ctx_.clear(); table_.clear();
+    }
+
+    void count(const std::string &evalTreesPath, size_t m) {
+        auto ef = loadEvalFile(evalTreesPath);
+        const auto &spans = ef->spans;
+        if (spans.size() != m) throw std::runtime_error("evaluation file changed while running");
+        const uint32_t n = (uint32_t)ref_.names.size();
+        std::vector<std::exception_ptr> errs(G_);
+        std::mutex io;
+        // geometry of the padded table: N chunks of T tuples (T even: whole 32-bit words for u16 cells too)
+        tuples_ = (uint64_t)n * (n - 1) * (n - 2) * (n - 3) / 24;
+        chunk_tuples_ = (tuples_ + G_ - 1) / G_;
+        chunk_tuples_ += chunk_tuples_ & 1;
+        chunk_words_ = chunk_tuples_ * 3 * (bits_ / 8) / 4;
+        const unsigned host_threads = std::max(1u, (opt_.ingest_threads ? opt_.ingest_threads : std::thread::hardware_concurrency()) / (unsigned)G_);
+        auto worker = [&](int g) {
+            try {
+                const int dev = opt_.device + g;
+                if (qs_create(&ctx_[g], n, bits_, QS_FLAG_NONE, dev, nullptr, 0, 0) != QS_OK) throw std::runtime_error(qs_last_error(nullptr));
+                QSM_HIP(hipSetDevice(dev));
+                const size_t bytes = (size_t)chunk_words_ * 4 * G_;
+                if (hipMalloc(&table_[g], bytes) != hipSuccess) throw std::runtime_error("Insufficient memory!");
+                QSM_HIP(hipMemset(table_[g], 0, bytes));
+                if (qs_table_attach(ctx_[g], table_[g], bytes) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                const size_t lo = spans.size() * g / G_, hi = spans.size() * (g + 1) / G_;
+                const bool want_ranges = (opt_.algo & 0xFFu) == QS_ALGO_SCATTER;
+                std::vector<qs_device_batch *> in_flight;
+                try {
+                    for (size_t i0 = lo; i0 < hi; i0 += opt_.batch_trees) {
+                        const size_t i1 = std::min(hi, i0 + opt_.batch_trees);
+                        BatchFlat b = flatten_parallel(ef->text, spans, i0, i1, ref_.name_to_id, host_threads, want_ranges);
+                        qs_tree_batch hb;
+                        hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data(); hb.adj_depth = b.adj_depth.data();
+                        hb.node_off = want_ranges ? b.node_off.data() : nullptr; hb.rng_off = want_ranges ? b.rng_off.data() : nullptr;
+                        hb.ranges = b.ranges.data();
+                        if (in_flight.size() == 2) { qs_batch_free(ctx_[g], in_flight.front()); in_flight.erase(in_flight.begin()); }
+                        qs_device_batch *db = nullptr;
+                        if (qs_batch_upload(ctx_[g], &hb, &db) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                        in_flight.push_back(db);
+                        if (qs_count_batch(ctx_[g], db, opt_.algo) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                    }
+                    if (qs_sync(ctx_[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                } catch (...) {
+                    (void)qs_sync(ctx_[g]);
+                    for (auto *db : in_flight) qs_batch_free(ctx_[g], db);
+                    throw;
+                }
+                for (auto *db : in_flight) qs_batch_free(ctx_[g], db);
+                std::lock_guard<std::mutex> lk(io);
+                std::cout << "GPU " << dev << ": counted trees [" << lo << ", " << hi << ")" << std::endl;
+            } catch (...) { errs[g] = std::current_exception(); }
+        };
+        std::vector<std::thread> pool;
+        for (int g = 0; g < G_; ++g) pool.emplace_back(worker, g);
+        for (auto &th : pool) th.join();
+        for (auto &e : errs) if (e) std::rethrow_exception(e);
+        loadEvalFile(std::string(), true);
+        std::cout << "lookup table size in bytes: " << tuples_ * 3 * (bits_ / 8) << "\n";
+    }
+
+    // one collective over all GPUs of this process
+    void reduce() {
+        std::vector<int> devs(G_);
+        for (int g = 0; g < G_; ++g) devs[g] = opt_.device + g;
+        std::vector<ncclComm_t> comms(G_);
+        QSM_NCCL(ncclCommInitAll(comms.data(), G_, devs.data()));
+        try {
+            QSM_NCCL(ncclGroupStart());
+            for (int g = 0; g < G_; ++g) {
+                QSM_HIP(hipSetDevice(devs[g]));
+                uint32_t *buf = (uint32_t *)table_[g];
+                if (full_) QSM_NCCL(ncclAllReduce(buf, buf, chunk_words_ * G_, ncclUint32, ncclSum, comms[g], nullptr));
+                else QSM_NCCL(ncclReduceScatter(buf, buf + (size_t)g * chunk_words_, chunk_words_, ncclUint32, ncclSum, comms[g], nullptr));
+            }
+            QSM_NCCL(ncclGroupEnd());
+            for (int g = 0; g < G_; ++g) { QSM_HIP(hipSetDevice(devs[g])); QSM_HIP(hipDeviceSynchronize()); }
+        } catch (...) {
+            for (auto &cm : comms) (void)ncclCommDestroy(cm);
+            throw;
+        }
+        for (auto &cm : comms) (void)ncclCommDestroy(cm);
+    }
+
+    void score(Tree const &refTree) {
+        qs_ref_tree rt;
+        rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)ref_.names.size();
+        rt.parent = ref_.parent.data(); rt.leaf_node = ref_.leaf_node.data();
+        const uint32_t flags = (opt_.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt_.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u);
+        std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
+        int bif = 0;
+        if (full_) {   // every GPU holds the whole table: GPU 0 scores alone
+            if (qs_score(ctx_[0], &rt, flags, lq.data(), qp.data(), eqp.data(), &bif) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[0]));
+        } else {
+            const size_t P = (size_t)qs_score_pair_slots(&rt);
+            if (P == 0) throw std::runtime_error("bad reference tree");
+            std::vector<int64_t *> d_sums(G_, nullptr), d_min(G_, nullptr), d_cand(G_, nullptr);
+            std::vector<int64_t> sums(P * 3, 0), mins(P, INT64_MAX), cand((size_t)G_ * P * QS_SCORE_CAND_SLOTS), extra;
+            auto free_all = [&]() {
+                for (int g = 0; g < G_; ++g) { (void)hipSetDevice(opt_.device + g); (void)hipFree(d_sums[g]); (void)hipFree(d_min[g]); (void)hipFree(d_cand[g]); }
+            };
+            try {
+                std::vector<int64_t> part_s(P * 3), part_m(P);
+                for (int g = 0; g < G_; ++g) {   // pass 1 on every GPU (asynchronous), on its shard of the reduced table
+                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipMalloc((void **)&d_sums[g], P * 3 * 8)); QSM_HIP(hipMalloc((void **)&d_min[g], P * 8)); QSM_HIP(hipMalloc((void **)&d_cand[g], P * QS_SCORE_CAND_SLOTS * 8));
+                    const uint64_t lo = std::min<uint64_t>((uint64_t)g * chunk_tuples_, tuples_), cnt = std::min<uint64_t>(lo + chunk_tuples_, tuples_) - lo;
+                    const char *shard = (const char *)table_[g] + (size_t)g * chunk_words_ * 4;
+                    if (qs_score_set_view(ctx_[g], shard, bits_, lo, cnt) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                    if (qs_score_pass1(ctx_[g], &rt, d_sums[g], d_min[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                }
+                for (int g = 0; g < G_; ++g) {   // SUM / MIN over the shards on the host (a few MB)
+                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipMemcpy(part_s.data(), d_sums[g], P * 3 * 8, hipMemcpyDeviceToHost));
+                    QSM_HIP(hipMemcpy(part_m.data(), d_min[g], P * 8, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < P * 3; ++i) sums[i] = (int64_t)((uint64_t)sums[i] + (uint64_t)part_s[i]);
+                    for (size_t i = 0; i < P; ++i) mins[i] = std::min(mins[i], part_m[i]);
+                }
+                for (int g = 0; g < G_; ++g) {
+                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipMemcpy(d_min[g], mins.data(), P * 8, hipMemcpyHostToDevice));
+                    if (qs_score_pass2(ctx_[g], &rt, d_min[g], d_cand[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                }
+                for (int g = 0; g < G_; ++g) {
+                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    int64_t *list = nullptr;
+                    uint64_t k = 0;
+                    if (qs_score_overflow(ctx_[g], &rt, d_min[g], d_cand[g], &list, &k) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                    if (k) { extra.insert(extra.end(), list, list + 4 * k); qs_free_host(list); }
+                    QSM_HIP(hipMemcpy(cand.data() + (size_t)g * P * QS_SCORE_CAND_SLOTS, d_cand[g], P * QS_SCORE_CAND_SLOTS * 8, hipMemcpyDeviceToHost));
+                    (void)qs_score_set_view(ctx_[g], nullptr, 0, 0, 0);
+                }
+            } catch (...) { free_all(); throw; }
+            free_all();
+            if (qs_score_finish(ctx_[0], &rt, flags, sums.data(), cand.data(), (uint32_t)G_, extra.empty() ? nullptr : extra.data(), extra.size() / 4,
+                                lq.data(), qp.data(), eqp.data(), &bif) != QS_OK)
+                throw std::runtime_error(qs_last_error(ctx_[0]));
+        }
+        scores.bifurcating = bif != 0;
+        scores.lq.assign(lq.begin() + 1, lq.end());
+        if (bif) { scores.qp.assign(qp.begin() + 1, qp.end()); scores.eqp.assign(eqp.begin() + 1, eqp.end()); }
+    }
+};
+
+} // namespace qsh

@@ -314,3 +314,31 @@ def test_multi_gpu_driver_single_process_matches_the_cli(d1_files, tmp_path):
     q = subprocess.run([sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", r, "-e", e, "-o", str(ref_out)],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert q.returncode == 1 and "already exists" in q.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trees,rooted", [(300, False), (70000, False), (120, True)])
+def test_cpp_cli_gpus_path_matches_single_gpu(tmp_path, trees, rooted):
+    """QuartetScores --gpus 1 runs the multi-GPU host (multi_gpu.hpp: per-GPU threads, table in attached memory padded
+    to N chunks, ncclCommInitAll + reduce-scatter / all-reduce over RCCL, sharded scoring reduced on the host) on one
+    device: annotated tree and -q file identical to the single-GPU path; u16 (packed words) and u32 tables."""
+    import numpy as np
+    from quartetscores_amd import native_ingest, synth
+    n = 14
+    ref_nw = synth.random_tree(n, np.random.default_rng(901), rooted=rooted)
+    text = native_ingest.synth_trees(n, trees, 902)
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_bytes(text)
+    o1, o2, o3 = tmp_path / "o1.nwk", tmp_path / "o2.nwk", tmp_path / "o3.nwk"
+    q1, q3 = tmp_path / "q1.txt", tmp_path / "q3.txt"
+    p = run("-r", str(r), "-e", str(e), "-o", str(o1), "-q", str(q1))
+    assert p.returncode == 0, p.stderr
+    p = run("-r", str(r), "-e", str(e), "-o", str(o2), "--gpus", "1")                      # reduce-scatter + sharded scoring
+    assert p.returncode == 0, p.stderr
+    assert "reduce-scatter" in p.stdout and o2.read_text() == o1.read_text()
+    p = run("-r", str(r), "-e", str(e), "-o", str(o3), "--gpus", "1", "-q", str(q3))        # all-reduce, GPU 0 scores and dumps
+    assert p.returncode == 0, p.stderr
+    assert "all-reduce" in p.stdout and o3.read_text() == o1.read_text() and q3.read_text() == q1.read_text()
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "o4.nwk"), "--gpus", "9")
+    assert p.returncode == 1 and "device(s) visible" in p.stderr
