@@ -834,7 +834,9 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 template <typename CT> struct Tuple3 { uint32_t a, b, c; };
 template <typename CT> __device__ __forceinline__ Tuple3<CT> load_tuple(const CT *p) {
     Tuple3<CT> t;
-    if (sizeof(CT) == 4) { const qs_u32x3 v = *reinterpret_cast<const qs_u32x3_a4 *>(p); t.a = v.x; t.b = v.y; t.c = v.z; }
+    // read once per launch and never again: non-temporal, so the tuples do not evict panel lines from the L2
+    // (profiles/r02_experiments.md: -1.3 % at 512 taxa, neutral at 256; non-temporal STORES measured slower)
+    if (sizeof(CT) == 4) { const qs_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const qs_u32x3_a4 *>(p)); t.a = v.x; t.b = v.y; t.c = v.z; }
     else { t.a = p[0]; t.b = p[1]; t.c = p[2]; }
     return t;
 }
