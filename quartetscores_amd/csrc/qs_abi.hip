@@ -76,6 +76,7 @@ struct qs_ctx {
     uint32_t tune_gather_impl = 0; // QS_IMPL_*
     uint32_t tune_panel_kernel = 0;
     uint32_t tune_cand_slots = kCand;  // candidate slots pass 2 fills per node pair (tests force overflows with fewer)
+    int tune_score_kernel = 0;         // 0 = bundle kernel, 1 = scan kernel (QS_TUNE_SCORE_KERNEL)
     double tune_score_tol = 1e-12;     // pass 2 keeps triples whose device QIC is within this of the pair's minimum
     double *dev_logk = nullptr;    // log(k) table of the device QIC (qs_score.hip), tbl_n entries
     uint32_t tbl_n = 0;
@@ -91,6 +92,10 @@ struct qs_ctx {
     uint32_t *ref_lca_dev = nullptr;
     uint16_t *ref_next_dev = nullptr;
     void *root_pairs_dev = nullptr;
+    BundlePlan bundle[2];              // rounds of the score bundle kernel in pass 1 / pass 2 for [bundle_r0, bundle_r1) (plan_bundles)
+    uint64_t bundle_r0[2] = {~0ull, ~0ull}, bundle_r1[2] = {~0ull, ~0ull};
+    uint32_t *bundle_dev[2] = {nullptr, nullptr};    // plo[n] | pcnt[n] | rounds[2 R]
+    int n_cu = 0;
 };
 
 static std::string g_create_err;
@@ -212,6 +217,9 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
         case QS_TUNE_SCORE_CAND_SLOTS:
             if (value < 1 || value > (uint64_t)kCand) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_CAND_SLOTS takes 1..8");
             c->tune_cand_slots = (uint32_t)value; return QS_OK;
+        case QS_TUNE_SCORE_KERNEL:
+            if (value > 1) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_KERNEL takes 0 (bundle kernel) or 1 (scan kernel)");
+            c->tune_score_kernel = (int)value; return QS_OK;
         case QS_TUNE_SCORE_TOL_EXP:
             if (value < 1 || value > 15) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_TOL_EXP takes 1..15 (tolerance 10^-value)");
             c->tune_score_tol = std::pow(10.0, -(double)value); return QS_OK;
@@ -317,6 +325,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->ref_lca_dev) (void)hipFree(c->ref_lca_dev);
     if (c->ref_next_dev) (void)hipFree(c->ref_next_dev);
     if (c->root_pairs_dev) (void)hipFree(c->root_pairs_dev);
+    for (int w = 0; w < 2; ++w) if (c->bundle_dev[w]) (void)hipFree(c->bundle_dev[w]);
     delete c->ref_cache;
     delete c;
 }
@@ -1001,6 +1010,32 @@ static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t 
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
     sd.cand_limit = c->tune_cand_slots; sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
     sd.frame = R.bifurcating ? 0 : 1;
+    sd.bundle_plo = sd.bundle_pcnt = sd.bundle_rounds = nullptr; sd.n_rounds = 0;
+}
+
+// the bundle kernel's rounds for the rank range sd covers (own table, table shard or view): planned on the host, cached
+static int ensure_bundle_plan(qs_ctx *c, ScoreDevice &sd, int pass) {
+    sd.bundle_plo = sd.bundle_pcnt = sd.bundle_rounds = nullptr; sd.n_rounds = 0;
+    if (c->tune_score_kernel == 1) return QS_OK;
+    if (c->n_cu == 0) { int v = 0; QS_HIP(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cu = std::max(1, v); }
+    const int w = pass - 1;
+    BundlePlan &plan = c->bundle[w];
+    const uint64_t r0 = sd.rank_lo, r1 = sd.rank_lo + sd.n_tuples;
+    if (c->bundle_r0[w] != r0 || c->bundle_r1[w] != r1 || !c->bundle_dev[w]) {
+        if (c->bundle_dev[w]) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->bundle_dev[w]); c->bundle_dev[w] = nullptr; }
+        plan_bundles(c->n, r0, r1, score_bundle_waves(pass), plan);
+        const size_t words = 2 * (size_t)c->n + plan.rounds.size();
+        if (hipMalloc(&c->bundle_dev[w], std::max<size_t>(words, 1) * 4) != hipSuccess) return fail(c, QS_ERR_OOM, "qs_score: round table of the bundle kernel");
+        QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w], plan.plo.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
+        QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w] + c->n, plan.pcnt.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
+        if (!plan.rounds.empty())
+            QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w] + 2 * (size_t)c->n, plan.rounds.data(), plan.rounds.size() * 4, hipMemcpyHostToDevice, c->stream));
+        QS_HIP(c, hipStreamSynchronize(c->stream));   // (the host vectors may be re-planned by the next call)
+        c->bundle_r0[w] = r0; c->bundle_r1[w] = r1;
+    }
+    sd.bundle_plo = c->bundle_dev[w]; sd.bundle_pcnt = c->bundle_dev[w] + c->n; sd.bundle_rounds = c->bundle_dev[w] + 2 * (size_t)c->n;
+    sd.n_rounds = (uint32_t)(plan.rounds.size() / 2);
+    return QS_OK;
 }
 
 extern "C" uint64_t qs_score_pair_slots(const qs_ref_tree *ref) {
@@ -1037,7 +1072,8 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     ScoreDevice sd;
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
-    QS_HIP(c, launch_score_pass1(c->stream, sd));
+    { int rc_b = ensure_bundle_plan(c, sd, 1); if (rc_b != QS_OK) return rc_b; }
+    QS_HIP(c, launch_score_pass1(c->stream, sd, c->tune_score_kernel, c->n_cu, c->bundle[0].part_lo, c->bundle[0].part_n, c->bundle[0].n_parts));
     // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
     if (c->root_pairs_dev) QS_HIP(c, launch_root_pair_sums(c->stream, sd, c->root_pairs_dev, (uint32_t)R.root_pairs.size(), R.root_items));
     return QS_OK;   // asynchronous on the context's stream
@@ -1058,7 +1094,8 @@ extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *
     ScoreDevice sd;
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_min = (long long *)min_dev; sd.pair_cand = (unsigned long long *)cand_dev;
-    QS_HIP(c, launch_score_pass2(c->stream, sd, c->tune_score_tol));
+    { int rc_b = ensure_bundle_plan(c, sd, 2); if (rc_b != QS_OK) return rc_b; }
+    QS_HIP(c, launch_score_pass2(c->stream, sd, c->tune_score_tol, c->tune_score_kernel, c->n_cu, c->bundle[1].part_lo, c->bundle[1].part_n, c->bundle[1].n_parts));
     return QS_OK;   // asynchronous; node pairs whose slots did not suffice are marked in cand_dev (qs_score_overflow)
 }
 

@@ -1,5 +1,6 @@
 // qs_internal.hpp -- launcher interface between the C-ABI layer (qs_abi.hip) and the kernels.
 #pragma once
+#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -97,6 +98,10 @@ struct ScoreDevice {
     const double *logk;            // log(k) (0 at k = 0) for k < tbl_n: integer arguments of the device QIC
     uint32_t tbl_n;
     uint32_t lds_n;                // leading entries of logk the scan kernel keeps in LDS
+    const uint32_t *bundle_plo;    // bundle kernel (plan_bundles): per b the first pair index and the number of pairs (c,d) whose rows are scored
+    const uint32_t *bundle_pcnt;
+    const uint32_t *bundle_rounds; // n_rounds x (b / 16, pair group)
+    uint32_t n_rounds;
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
                                    //    order of the multifurcating / raw-QIC loops (QSC:551-558, 661-668)
 };
@@ -104,8 +109,13 @@ constexpr int kCand = 8;
 constexpr unsigned long long kCandEmpty = ~0ull;
 constexpr unsigned long long kCandOverflow = ~0ull - 1; // in the LAST slot of a node pair: its slots did not suffice (qs_score_overflow)
 uint32_t score_scan_max_lds_log();
-hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd);
-hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol);
+// kernel: 0 = bundle kernel (a wave walks 64 rows with the same b in lockstep; needs sd.bundle_* = plan_bundles of the
+// rank range, and the partial rows at its ends, which go through the scan kernel), 1 = scan kernel (lane = 8 consecutive ranks)
+struct BundlePlan { std::vector<uint32_t> plo, pcnt, rounds; uint64_t part_lo[2], part_n[2]; int n_parts; };
+void plan_bundles(uint32_t n, uint64_t r0, uint64_t r1, uint32_t waves, BundlePlan &out);
+uint32_t score_bundle_waves(int pass);   // waves per workgroup (= consecutive b per round) of the bundle kernel in pass 1 / 2
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts);
+hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts);
 hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol);
 // sums of the node pairs (degree-2 root, v): pairs_dev = RootPairHost records (qs_abi.hip), total = number of (v,a,b,c,d) items
 struct RootPairHost { uint32_t s1_lo, s1_n, s2_lo, s2_n, s3_lo, s3_n, s4_lo, s4_n, key, pad; unsigned long long first; };

@@ -335,6 +335,269 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
     }
 }
 
+// ---- the bundle kernel: passes 1 and 2, one wave = 64 rows with the same b -------------------------
+// score_scan_kernel is bound by instruction issue (r02 counters at 512 taxa: the SIMDs issue ~80 % of the time, 180
+// instructions per 64 quartets in pass 1): its lanes sit in different rows, so in nearly every iteration SOME lane
+// reaches a run end and the whole wave walks through the re-classification and the hash insert.
+// Along a row (b,c,d fixed, a = 0..b-1) the node pair of the quartet changes only where lca(a,b) changes, and those
+// places depend on b alone. So this kernel gives the 64 lanes of a wave 64 rows WITH THE SAME b -- the rows of 64
+// consecutive pairs (c,d), b < c < d, in the table's own (d-major) order -- and walks them in lockstep:
+//   * a, the run ends (ref_next[b][a]) and lca(a,b) are wave-uniform (scalar); only lca(b,c), lca(c,d) differ per lane;
+//   * the re-classification is a uniform branch taken ~10 times per row instead of in every iteration;
+//   * per quartet a lane does: raw sums and the device QIC from a k log k table in LDS -- sum_i T[n_i] * (1/s) - log s
+//     with 1/s and log s cached per lane while the tuple sum s repeats; its row comes in chunks of 8 tuples = 96 bytes
+//     requested as six 16-byte loads back to back;
+//   * at a change of node pair the lanes that change insert their piece into the workgroup's LDS hash (neighbouring
+//     lanes mostly share the pair: same-address LDS atomics), which goes to memory after every round (the waves of a
+//     workgroup take consecutive b and the same group of pairs: ~100 distinct node pairs per round).
+// Rows are contiguous (b tuples at rank C(d,4)+C(c,3)+C(b,2)), so a lane streams its own row; a wave reads 64 streams.
+// The host plans the rounds for the rank range at hand (plan_bundles): rows that lie completely inside it; the at most
+// two partial rows at its ends (views of a reduce-scattered table) go through score_scan_kernel.
+__device__ __forceinline__ uint32_t chunk_classify(const ScoreDevice &sd, uint32_t e01, uint32_t e12, uint32_t e23, uint32_t &code) {
+    const uint32_t d01 = e01 >> 16, d12 = e12 >> 16, d23 = e23 >> 16;
+    const uint32_t mx = max(d01, d23);
+    const uint32_t n01 = e01 & 0xFFFFu, n12 = e12 & 0xFFFFu, n23 = e23 & 0xFFFFu;
+    // ab|cd: (d01 > d12 ? n01 : n12, d23 > d12 ? n23 : n12);  ad|bc: (n12, d01 >= d23 ? n01 : n23)
+    const bool abcd = d12 < mx, adbc = d12 > mx;
+    const uint32_t j1 = abcd ? (d01 > d12 ? n01 : n12) : n12;
+    const uint32_t j2 = abcd ? (d23 > d12 ? n23 : n12) : (d01 >= d23 ? n01 : n23);
+    code = abcd ? 0u : (adbc ? (sd.frame == 0 ? 1u : 2u) : 3u);
+    return (abcd || adbc) ? min(j1, j2) * sd.n_inner + max(j1, j2) : kKeyEmpty;
+}
+__device__ __forceinline__ void chunk_permute(uint32_t code, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t &q1, uint32_t &q2, uint32_t &q3) {
+    q1 = code == 0 ? n0 : n2;
+    q2 = code == 2 ? n0 : n1;
+    q3 = code == 0 ? n2 : (code == 1 ? n0 : n1);
+}
+
+// device QIC of a raw tuple, only the sign depends on which count is the reference topology's (first_is_n0)
+struct QicCache { uint32_t s; double r, ls; };
+__device__ __noinline__ double bundle_qic_slow(const double *__restrict__ logk, uint32_t tbl_n, uint32_t n0, uint32_t n1, uint32_t n2) {
+    const uint64_t s64 = (uint64_t)n0 + n1 + n2;
+    if (s64 == 0) return 0.0;
+    const double sd_ = (double)s64;
+    auto L = [&](uint64_t k) { return k == 0 ? 0.0 : (k < tbl_n ? logk[k] : log((double)k)); };
+    const double acc = (double)n0 * L(n0) + (double)n1 * L(n1) + (double)n2 * L(n2);
+    return 1.0 + (acc / sd_ - L(s64)) * 0.91023922662683739361;
+}
+__device__ __forceinline__ double bundle_qic(const double *__restrict__ t1, const ScoreDevice &sd, QicCache &qc, uint32_t n0, uint32_t n1,
+                                             uint32_t n2, bool first_is_n0) {
+    const uint32_t mx = max(max(n0, n1), n2);
+    const uint32_t s = n0 + n1 + n2;                       // (no wrap below: mx < 2^30)
+    double qic;
+    if (mx < (1u << 30) && s < sd.lds_n) {
+        const double acc = t1[n0] + t1[n1] + t1[n2];       // sum_i n_i log n_i
+        if (s != qc.s) {                                   // 1/s and log s: kept while the tuple sum repeats
+            qc.s = s;
+            if (s == 0) { qc.r = 0.0; qc.ls = 1.0986122886681098; }   // all-zero tuple: QIC 0 (QuartetScoreComputer.hpp:136)
+            else {
+                const double sd_ = (double)s;
+                double r = __builtin_amdgcn_rcp(sd_);
+                r = fma(fma(-sd_, r, 1.0), r, r);
+                r = fma(fma(-sd_, r, 1.0), r, r);
+                qc.r = r; qc.ls = t1[s] * r;
+            }
+        }
+        qic = fma(fma(acc, qc.r, -qc.ls), 0.91023922662683739361, 1.0);
+    } else qic = bundle_qic_slow(sd.logk, sd.tbl_n, n0, n1, n2);
+    const uint32_t q1 = first_is_n0 ? n0 : n2;
+    return q1 != mx ? -qic : qic;
+}
+
+// waves of a workgroup (= consecutive b of a round). A wave reads 64 streams, and a CU keeps one workgroup (LDS): more
+// waves hide more latency, but with too many streams per CU the 32 KB L1 loses a row's cache line between two of the
+// lane's accesses and the requests to the L2 multiply: the L1 sustains only ~60 outstanding misses per CU, so the kernel's
+// time is (requests to L2) x (their latency) (profiles/r02_experiments.md: 512 taxa, 12-byte loads, pass 1 / pass 2 in ms
+// at 4, 6, 8, 10, 16 waves: 15.8/15.7, 11.8/12.1, 16.6/11.2, 17.8/15.2, 19.7/18.6; with 16-byte loads of whole chunks
+// 10.3/9.4 at 8/10 waves, flat from 7 to 12).
+#ifndef QS_BUNDLE_CH
+#define QS_BUNDLE_CH 8
+#endif
+#ifndef QS_BUNDLE_W1
+#define QS_BUNDLE_W1 8
+#endif
+#ifndef QS_BUNDLE_W2
+#define QS_BUNDLE_W2 10
+#endif
+typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
+typedef qs_u32x4 qs_u32x4_a2 __attribute__((aligned(2)));   // rows start at any tuple: 4-byte (u32 cells) or 2-byte (u16 cells) aligned
+constexpr int kBundleWaves1 = QS_BUNDLE_W1, kBundleWaves2 = QS_BUNDLE_W2;
+
+template <typename CT, int PASS, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice sd, double tol) {
+    static_assert(PASS == 1 || PASS == 2, "pass 3 stays on score_scan_kernel");
+    constexpr int kBundleWaves = WAVES, kBThreads = WAVES * kWave;
+    extern __shared__ __align__(16) unsigned char scan_smem[];
+    ScanLds &hash = *reinterpret_cast<ScanLds *>(scan_smem);                   // used by pass 1 only
+    double *t1 = reinterpret_cast<double *>(scan_smem + (PASS == 1 ? sizeof(ScanLds) : 0));   // k log k
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    for (uint32_t i = tid; i < sd.lds_n; i += kBThreads) t1[i] = (double)i * sd.logk[i];
+    if (PASS == 1) {
+        for (uint32_t t = tid; t < (uint32_t)kSSlots; t += kBThreads) {
+            hash.key[t] = kKeyEmpty;
+            hash.sum[3 * t] = hash.sum[3 * t + 1] = hash.sum[3 * t + 2] = 0;
+            hash.mn[t] = kSortableMax;
+        }
+    }
+    __syncthreads();
+    const CT *table = reinterpret_cast<const CT *>(sd.table);
+    const uint32_t *__restrict__ L = sd.ref_lca;
+    const uint32_t n = sd.n;
+    const double kHuge = sortable_to_f64(kSortableMax);
+    for (uint32_t round = blockIdx.x; round < sd.n_rounds; round += gridDim.x) {
+        const uint32_t rk = sd.bundle_rounds[2 * round], rg = sd.bundle_rounds[2 * round + 1];
+        const uint32_t b = __builtin_amdgcn_readfirstlane(rk * kBundleWaves + wave);
+        const uint32_t pcnt = b < n ? sd.bundle_pcnt[b] : 0u;
+        if (pcnt > rg * kWave) {                                       // uniform over the wave
+            const bool live = rg * kWave + lane < pcnt;
+            const uint32_t p = sd.bundle_plo[b] + min(rg * kWave + lane, pcnt - 1);   // (idle lanes repeat the last row, and never hand anything in)
+            uint32_t c, d;
+            unrank2(p, c, d);
+            c += b + 1; d += b + 1;
+            const CT *row = table + (rank4(0, b, c, d) - sd.rank_lo) * 3;
+            const uint32_t e12 = L[(size_t)c * n + b], e23 = L[(size_t)d * n + c];
+            const uint32_t *__restrict__ lrow = L + (size_t)b * n;
+            const uint16_t *__restrict__ nrow = sd.ref_next + (size_t)b * n;
+            constexpr int CH = QS_BUNDLE_CH;        // tuples a lane requests at once: 96 bytes of its row, back to back, so that
+            uint32_t q[CH][3];                      // the requests for one cache line meet in the L1 while it is still pending
+            uint32_t key = kKeyEmpty, code = 3;
+            bool first_is_n0 = true;
+            unsigned long long S0 = 0, S1 = 0, S2 = 0;
+            double mn = kHuge, thr = -kHuge;
+            uint32_t h0 = 0, h1 = 0, h2 = 0;        // pass 2: the lane's previous near-minimal tuple in this run
+            bool hprev = false;
+            QicCache qc = {0xFFFFFFFFu, 0.0, 0.0};
+            uint32_t end = 0;
+            for (uint32_t a0 = 0; a0 < b; a0 += CH) {                   // uniform
+                if (a0 + CH <= b) {                                     // uniform: the whole chunk lies in the row
+                    constexpr int NV = CH * 3 * (int)sizeof(CT) / 16;   // 16-byte loads: 6 (u32 cells) / 3 (u16 cells)
+                    const qs_u32x4_a2 *src = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)a0);
+                    uint32_t w[NV * 4];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) { const qs_u32x4 v = src[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int e = 3 * u + k;                    // element index in the chunk
+                            q[u][k] = sizeof(CT) == 4 ? w[e] : ((w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+                        if (a0 + u < b) scan_load_tuple<CT>(row + 3 * (size_t)(a0 + u), q[u][0], q[u][1], q[u][2]);
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const uint32_t a = a0 + u;
+                    if (a < b) {                                        // uniform
+                        if (a == end) {                                 // uniform: lca(a,b) changes here
+                            const uint32_t e01 = __builtin_amdgcn_readfirstlane(lrow[a]);
+                            end = __builtin_amdgcn_readfirstlane((uint32_t)nrow[a]);
+                            uint32_t ncode;
+                            uint32_t nkey = chunk_classify(sd, e01, e12, e23, ncode);
+                            if (!live) { nkey = kKeyEmpty; ncode = 3; }
+                            const bool changed = nkey != key;
+                            if (PASS == 1) {
+                                const bool f = changed && key != kKeyEmpty;
+                                if (__any(f)) {
+                                    if (f) scan_flush(hash, sd, key, code == 0 ? S0 : S2, code == 2 ? S0 : S1,
+                                                      code == 0 ? S2 : (code == 1 ? S0 : S1), f64_to_sortable(mn));
+                                }
+                                if (changed) { S0 = S1 = S2 = 0; mn = kHuge; }
+                            } else if (changed) {
+                                thr = nkey != kKeyEmpty ? sortable_to_f64(sd.pair_min[nkey]) + tol : -kHuge;
+                                hprev = false;
+                            }
+                            key = nkey; code = ncode; first_is_n0 = ncode == 0;
+                        }
+                        const uint32_t n0 = q[u][0], n1 = q[u][1], n2 = q[u][2];
+                        const double qic = bundle_qic(t1, sd, qc, n0, n1, n2, first_is_n0);
+                        if (PASS == 1) {
+                            S0 += n0; S1 += n1; S2 += n2;
+                            mn = fmin(mn, qic);
+                        } else {
+                            // a near-minimal quartet; a repeat of the lane's previous one in this run -- ties such as
+                            // (m,0,0) -- is the same packed triple, nothing to record
+                            const bool near = qic <= thr;
+                            const bool hit = near && !(hprev && n0 == h0 && n1 == h1 && n2 == h2);
+                            if (__any(hit)) {
+                                if (hit) {
+                                    uint32_t q1, q2, q3;
+                                    chunk_permute(code, n0, n1, n2, q1, q2, q3);
+                                    scan_candidate(sd, key, q1, q2, q3);
+                                }
+                            }
+                            if (near) { h0 = n0; h1 = n1; h2 = n2; }
+                            hprev = near;
+                        }
+                    }
+                }
+            }
+            if (PASS == 1) {
+                const bool f = key != kKeyEmpty;
+                if (f) scan_flush(hash, sd, key, code == 0 ? S0 : S2, code == 2 ? S0 : S1, code == 0 ? S2 : (code == 1 ? S0 : S1),
+                                  f64_to_sortable(mn));
+            }
+        }
+        if (PASS == 1) {   // the hash holds the node pairs of this round: one slot per thread to memory
+            __syncthreads();
+            for (uint32_t t = tid; t < (uint32_t)kSSlots; t += kBThreads) {
+                const uint32_t k = hash.key[t];
+                if (k != kKeyEmpty) {
+                    scan_global_add(sd, k, hash.sum[3 * t], hash.sum[3 * t + 1], hash.sum[3 * t + 2], hash.mn[t]);
+                    hash.key[t] = kKeyEmpty;
+                    hash.sum[3 * t] = hash.sum[3 * t + 1] = hash.sum[3 * t + 2] = 0;
+                    hash.mn[t] = kSortableMax;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// The rounds of the bundle kernel for the rank range [r0, r1) of an n-taxon table (host). For every b the rows (b,c,d)
+// that lie completely inside the range are, in the order of their pairs (c,d) (index C(d-b-1,2) + c-b-1), one
+// contiguous stretch [plo[b], plo[b] + pcnt[b]); a round = `waves` consecutive b x one group of 64 pairs. Rounds are listed
+// from the largest b down (longest first). parts: the at most two partial rows at the ends of the range.
+void plan_bundles(uint32_t n, uint64_t r0, uint64_t r1, uint32_t waves, BundlePlan &out) {
+    const uint32_t kBundleWaves = waves;
+    out.plo.assign(n, 0); out.pcnt.assign(n, 0); out.rounds.clear(); out.n_parts = 0;
+    const uint64_t total = binom4(n);
+    if (r1 > total) r1 = total;
+    if (r0 >= r1 || n < 4) return;
+    uint32_t a0, b0, c0, d0, a1 = 0, b1 = 0, c1 = 0, d1 = 0;
+    unrank4(r0, a0, b0, c0, d0);
+    const bool open_end = r1 == total;
+    if (!open_end) unrank4(r1, a1, b1, c1, d1);
+    auto idx = [](uint32_t b, uint32_t c, uint32_t d) -> uint64_t {   // pairs (c',d') of b before (c,d)
+        const uint64_t dd = d > b + 1 ? d - b - 1 : 0, cc = c > b + 1 ? c - b - 1 : 0;
+        return dd * (dd > 0 ? dd - 1 : 0) / 2 + (dd > 0 ? std::min(cc, dd) : 0);
+    };
+    for (uint32_t b = 1; b + 2 < n; ++b) {
+        const uint64_t tp = binom2((uint64_t)n - 1 - b);
+        uint64_t lo = idx(b, c0, d0);
+        if (b < c0) { const bool inside = b > b0 || (b == b0 && a0 == 0); if (!inside) lo += 1; }
+        uint64_t hi = tp;
+        if (!open_end) { hi = idx(b, c1, d1); if (b < c1 && b < b1) hi += 1; }
+        if (hi > tp) hi = tp;
+        if (hi > lo) { out.plo[b] = (uint32_t)lo; out.pcnt[b] = (uint32_t)(hi - lo); }
+    }
+    const uint32_t blocks = (n + kBundleWaves - 1) / kBundleWaves;
+    for (uint32_t k = blocks; k-- > 0;) {
+        uint32_t groups = 0;
+        for (uint32_t b = k * kBundleWaves; b < std::min(n, (k + 1) * kBundleWaves); ++b) groups = std::max(groups, (out.pcnt[b] + kWave - 1) / kWave);
+        for (uint32_t g = 0; g < groups; ++g) { out.rounds.push_back(k); out.rounds.push_back(g); }
+    }
+    // partial rows: [r0, end of r0's row) if r0 is not a row start; [start of r1's row, r1) if r1 is not one
+    uint64_t pa_lo = 0, pa_hi = 0, pb_lo = 0, pb_hi = 0;
+    if (a0 > 0) { pa_lo = r0; pa_hi = std::min(r1, r0 + (b0 - a0)); }
+    if (!open_end && a1 > 0) { pb_lo = std::max(r0, r1 - a1); pb_hi = r1; }
+    if (pa_hi > pa_lo && pb_hi > pb_lo && pb_lo < pa_hi) { pa_hi = std::max(pa_hi, pb_hi); pb_lo = pb_hi = 0; }   // the same row
+    if (pa_hi > pa_lo) { out.part_lo[out.n_parts] = pa_lo; out.part_n[out.n_parts++] = pa_hi - pa_lo; }
+    if (pb_hi > pb_lo) { out.part_lo[out.n_parts] = pb_lo; out.part_n[out.n_parts++] = pb_hi - pb_lo; }
+}
+
 constexpr int kP1Iters = 16;      // passes of 256 ranks per workgroup (raw QIC)
 
 template <typename CT>
@@ -367,12 +630,41 @@ template <typename CT, int PASS> static hipError_t launch_scan(hipStream_t s, co
     return hipGetLastError();
 }
 
-hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd) {
-    return sd.count_bits == 32 ? launch_scan<uint32_t, 1>(s, sd, 0.0) : launch_scan<uint16_t, 1>(s, sd, 0.0);
+// bundle kernel over the planned rounds (sd.bundle_*), scan kernel over the partial rows at the ends of the range
+template <typename CT, int PASS> static hipError_t launch_bundle(hipStream_t s, const ScoreDevice &sd, double tol, int n_cu,
+                                                                 const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
+    constexpr int WAVES = PASS == 1 ? kBundleWaves1 : kBundleWaves2;
+    if (sd.n_rounds > 0) {
+        const size_t lds = (PASS == 1 ? sizeof(ScanLds) : 0) + (size_t)sd.lds_n * 8;
+        auto k = score_bundle_kernel<CT, PASS, WAVES>;
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        dim3 block(WAVES * kWave), grid(std::min<uint32_t>(sd.n_rounds, (uint32_t)std::max(1, n_cu)));
+        hipLaunchKernelGGL(k, grid, block, lds, s, sd, tol);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    for (int i = 0; i < n_parts; ++i) {
+        ScoreDevice part = sd;
+        part.table = reinterpret_cast<const unsigned char *>(sd.table) + (part_lo[i] - sd.rank_lo) * 3 * sizeof(CT);
+        part.rank_lo = part_lo[i]; part.n_tuples = part_n[i];
+        hipError_t e = launch_scan<CT, PASS>(s, part, tol);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+uint32_t score_bundle_waves(int pass) { return pass == 1 ? kBundleWaves1 : kBundleWaves2; }
+
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
+    if (kernel == 1) return sd.count_bits == 32 ? launch_scan<uint32_t, 1>(s, sd, 0.0) : launch_scan<uint16_t, 1>(s, sd, 0.0);
+    return sd.count_bits == 32 ? launch_bundle<uint32_t, 1>(s, sd, 0.0, n_cu, part_lo, part_n, n_parts)
+                               : launch_bundle<uint16_t, 1>(s, sd, 0.0, n_cu, part_lo, part_n, n_parts);
 }
 
-hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol) {
-    return sd.count_bits == 32 ? launch_scan<uint32_t, 2>(s, sd, tol) : launch_scan<uint16_t, 2>(s, sd, tol);
+hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
+    if (kernel == 1) return sd.count_bits == 32 ? launch_scan<uint32_t, 2>(s, sd, tol) : launch_scan<uint16_t, 2>(s, sd, tol);
+    return sd.count_bits == 32 ? launch_bundle<uint32_t, 2>(s, sd, tol, n_cu, part_lo, part_n, n_parts)
+                               : launch_bundle<uint16_t, 2>(s, sd, tol, n_cu, part_lo, part_n, n_parts);
 }
 
 hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol) {

@@ -1001,3 +1001,76 @@ def test_wide_reduced_counts_are_finished_from_the_list(eng):
         inner = np.isfinite(wlq)
         assert inner.sum() == n - 3
         assert (lq[inner] == wlq[inner]).all() and (qp[inner] == wqp[inner]).all() and (eqp[inner] == weqp[inner]).all()
+
+
+@pytest.mark.parametrize("n,bits,kind", [(23, 32, "binary"), (70, 16, "multif"), (134, 32, "binary"), (41, 16, "ties"),
+                                         (9, 32, "binary"), (160, 16, "ties")])
+def test_score_bundle_kernel_equals_scan_kernel(eng, n, bits, kind):
+    """Both kernels of score passes 1 and 2 (QS_TUNE_SCORE_KERNEL: 0 = bundle kernel, a wave walks 64 table rows with
+    the same second id in lockstep; 1 = scan kernel, a lane walks 8 consecutive ranks) give the same per-node-pair sums
+    bit for bit, minima that agree to the rounding of the device QIC, and the same final scores -- on random tables
+    (incl. zero tuples and long ties such as (m,0,0)), u16 and u32 cells, counts beyond the LDS copy of the log table,
+    bifurcating and multifurcating references, the whole table and ragged views of it (a view that starts and ends inside
+    a row, lies inside one row, is a few tuples long): the bundle kernel's host plan (full rows per b + partial rows)."""
+    import torch
+    import emulate
+    ref_nw = synth.reference_tree(n, 700 + n) if kind != "multif" else synth.tree_set(n, 1, 700 + n, collapse=0.3)[0]
+    ref = flatten.flatten_reference(ref_nw)
+    rng = np.random.default_rng(800 + n)
+    nq = ranks.n_quartets(n)
+    m = 5000 if bits == 16 else 200000          # beyond the LDS copy of the log table for u32
+    T = rng.multinomial(m, [0.6, 0.3, 0.1], size=nq).astype(np.uint32)
+    T = np.take_along_axis(T, rng.permuted(np.tile(np.arange(3), (nq, 1)), axis=1), axis=1)
+    T[rng.random(nq) < 0.05] = 0
+    if kind == "ties":
+        tie = rng.random(nq) < 0.7
+        T[tie] = np.array([m, 0, 0], dtype=np.uint32)[rng.permuted(np.tile(np.arange(3), (int(tie.sum()), 1)), axis=1)]
+    dt = np.uint16 if bits == 16 else np.uint32
+    ctx = eng.Context(n, bits)
+    ctx.table_alloc()
+    ctx.table_upload(T.astype(dt))
+    P = ctx.score_pair_slots(ref)
+
+    def steps(kernel):
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_KERNEL, kernel)
+        sums = torch.empty(3 * P, dtype=torch.int64, device="cuda"); mins = torch.empty(P, dtype=torch.int64, device="cuda")
+        cand = torch.empty(8 * P, dtype=torch.int64, device="cuda")
+        ctx.score_pass1(ref, sums, mins)
+        ctx.score_pass2(ref, mins, cand)
+        extra = ctx.score_overflow(ref, mins, cand)
+        sh, ch = sums.cpu().numpy(), cand.cpu().numpy()
+        return sh, mins.cpu().numpy(), ctx.score_finish(ref, sh, ch[None, :], extra=extra)
+
+    def same(x, y, what):
+        assert (x[0] == y[0]).all(), what                      # sums: exact
+        def dec(v):   # qs_common.hpp sortable_to_f64
+            v = v.astype(np.int64)
+            bits = np.where(v < 0, (np.uint64(1 << 63) - v.astype(np.uint64)).astype(np.uint64), v.astype(np.uint64))
+            return bits.view(np.float64)
+        with np.errstate(over="ignore"):
+            mx, my = dec(x[1]), dec(y[1])
+        assert (np.isclose(mx, my, rtol=0, atol=1e-12) | (x[1] == y[1])).all(), what   # minima of the device QIC
+        for u, v in zip(x[2][:3], y[2][:3]):
+            assert np.array_equal(u, v, equal_nan=True), what
+
+    a, b = steps(0), steps(1)
+    same(a, b, "whole table")
+    if kind != "multif" and n <= 41:    # (plain-Python closed form: small tables only)
+        wlq, wqp, weqp = emulate.scores_from_table(ref, T.astype(np.int64), qp_exact64=False)
+        inner = np.isfinite(wlq)
+        got = a[2]
+        assert (got[0][inner] == wlq[inner]).all() and (got[1][inner] == wqp[inner]).all() and (got[2][inner] == weqp[inner]).all()
+    # ragged views of the same table: (first rank, tuples)
+    full = torch.from_numpy(np.ascontiguousarray(T.astype(dt)).reshape(-1).view(np.uint8)).cuda()
+    item = 3 * (bits // 8)
+    views = [(0, nq), (nq // 3 + 1, nq // 2), (nq - 5, 5), (7, 8192 + 9), (nq // 2, 3), (nq // 2 + 1, 1), (0, 1), (nq // 5, nq // 7)]
+    for r_lo, cnt in views:
+        if r_lo + cnt > nq or (r_lo * item) % 4:
+            continue
+        pad = (-cnt * item) % 4
+        shard = torch.zeros(cnt * item + pad, dtype=torch.uint8, device="cuda")
+        shard[: cnt * item] = full[r_lo * item:(r_lo + cnt) * item]
+        ctx.score_set_view(shard.view(torch.int32), bits, r_lo, cnt)
+        same(steps(0), steps(1), (r_lo, cnt))
+    ctx.score_set_view(None, 0, 0, 0)
+    ctx.close()
