@@ -296,6 +296,14 @@ int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 int qs_last_count_launches(const qs_ctx *ctx);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);
+/* How score passes 1 and 2 decompose the tuples [rank_lo, rank_lo + n_tuples) of an n_taxa table (host arithmetic only,
+ * no device, no context; the reference walks node pairs instead, QuartetScoreComputer.hpp:495-508). A table ROW = the
+ * b consecutive tuples (a = 0..b-1) of one (b,c,d). For every second id b the rows that lie completely inside the
+ * range are those of the pairs (c,d), b < c < d, number [first_pair[b], first_pair[b] + n_pairs[b]) in the order
+ * C(d-b-1,2) + (c-b-1); the bundle kernel walks 64 of them per wave. parts[0..3] = (first rank, tuples) of the at most
+ * two partial rows at the ends of the range (0,0 if absent), which the scan kernel walks. first_pair / n_pairs: n_taxa
+ * entries each. */
+int qs_score_plan(uint32_t n_taxa, uint64_t rank_lo, uint64_t n_tuples, uint32_t *first_pair, uint32_t *n_pairs, uint64_t parts[4]);
 
 #ifdef __cplusplus
 }

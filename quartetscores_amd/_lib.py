@@ -28,6 +28,7 @@ EXPORTS = [
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
+    "qs_score_plan",
 ]
 
 
@@ -139,6 +140,8 @@ def load():
     L.qs_set_tuning.argtypes = [vp, u32, u64]
     L.qs_last_count_launches.restype = i32
     L.qs_last_count_launches.argtypes = [vp]
+    L.qs_score_plan.restype = i32
+    L.qs_score_plan.argtypes = [u32, u64, u64, vp, vp, vp]
     L.qs_last_count_variant.restype = C.c_char_p
     L.qs_last_count_variant.argtypes = [vp]
     _lib = L

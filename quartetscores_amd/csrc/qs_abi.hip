@@ -1038,6 +1038,17 @@ static int ensure_bundle_plan(qs_ctx *c, ScoreDevice &sd, int pass) {
     return QS_OK;
 }
 
+extern "C" int qs_score_plan(uint32_t n_taxa, uint64_t rank_lo, uint64_t n_tuples, uint32_t *first_pair, uint32_t *n_pairs, uint64_t parts[4]) {
+    if (!first_pair || !n_pairs || !parts || n_taxa < 4 || n_taxa > 65535) return QS_ERR_ARG;
+    if (rank_lo > binom4(n_taxa) || n_tuples > binom4(n_taxa) - rank_lo) return QS_ERR_ARG;
+    BundlePlan plan;
+    plan_bundles(n_taxa, rank_lo, rank_lo + n_tuples, score_bundle_waves(1), plan);
+    std::copy(plan.plo.begin(), plan.plo.end(), first_pair);
+    std::copy(plan.pcnt.begin(), plan.pcnt.end(), n_pairs);
+    for (int i = 0; i < 2; ++i) { parts[2 * i] = i < plan.n_parts ? plan.part_lo[i] : 0; parts[2 * i + 1] = i < plan.n_parts ? plan.part_n[i] : 0; }
+    return QS_OK;
+}
+
 extern "C" uint64_t qs_score_pair_slots(const qs_ref_tree *ref) {
     if (!ref || !ref->parent || ref->n_nodes == 0) return 0;
     std::vector<uint32_t> nchild(ref->n_nodes, 0);

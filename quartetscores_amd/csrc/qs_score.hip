@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
 // Rows are contiguous (b tuples at rank C(d,4)+C(c,3)+C(b,2)), so a lane streams its own row; a wave reads 64 streams.
 // The host plans the rounds for the rank range at hand (plan_bundles): rows that lie completely inside it; the at most
 // two partial rows at its ends (views of a reduce-scattered table) go through score_scan_kernel.
-__device__ __forceinline__ uint32_t chunk_classify(const ScoreDevice &sd, uint32_t e01, uint32_t e12, uint32_t e23, uint32_t &code) {
+__device__ __forceinline__ uint32_t pair_classify(const ScoreDevice &sd, uint32_t e01, uint32_t e12, uint32_t e23, uint32_t &code) {
     const uint32_t d01 = e01 >> 16, d12 = e12 >> 16, d23 = e23 >> 16;
     const uint32_t mx = max(d01, d23);
     const uint32_t n01 = e01 & 0xFFFFu, n12 = e12 & 0xFFFFu, n23 = e23 & 0xFFFFu;
@@ -364,7 +364,7 @@ __device__ __forceinline__ uint32_t chunk_classify(const ScoreDevice &sd, uint32
     code = abcd ? 0u : (adbc ? (sd.frame == 0 ? 1u : 2u) : 3u);
     return (abcd || adbc) ? min(j1, j2) * sd.n_inner + max(j1, j2) : kKeyEmpty;
 }
-__device__ __forceinline__ void chunk_permute(uint32_t code, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t &q1, uint32_t &q2, uint32_t &q3) {
+__device__ __forceinline__ void permute_counts(uint32_t code, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t &q1, uint32_t &q2, uint32_t &q3) {
     q1 = code == 0 ? n0 : n2;
     q2 = code == 2 ? n0 : n1;
     q3 = code == 0 ? n2 : (code == 1 ? n0 : n1);
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                             const uint32_t e01 = __builtin_amdgcn_readfirstlane(lrow[a]);
                             end = __builtin_amdgcn_readfirstlane((uint32_t)nrow[a]);
                             uint32_t ncode;
-                            uint32_t nkey = chunk_classify(sd, e01, e12, e23, ncode);
+                            uint32_t nkey = pair_classify(sd, e01, e12, e23, ncode);
                             if (!live) { nkey = kKeyEmpty; ncode = 3; }
                             const bool changed = nkey != key;
                             if (PASS == 1) {
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                             if (__any(hit)) {
                                 if (hit) {
                                     uint32_t q1, q2, q3;
-                                    chunk_permute(code, n0, n1, n2, q1, q2, q3);
+                                    permute_counts(code, n0, n1, n2, q1, q2, q3);
                                     scan_candidate(sd, key, q1, q2, q3);
                                 }
                             }

@@ -242,3 +242,61 @@ def test_python_closed_form_scores_match_the_oracle():
         assert (lq[e + 1], qp[e + 1], eqp[e + 1]) == want[key]
         seen += 1
     assert seen == len(want)
+
+
+def test_score_plan_covers_every_rank_range_exactly_once():
+    """qs_score_plan (the host planner of the score bundle kernel: pure arithmetic, no device): for whole tables, table
+    shards (ranges of the largest id) and arbitrary rank ranges -- the views of a reduce-scattered table, which start and
+    end inside rows -- the full rows of the plan plus its partial rows are pairwise disjoint and their union is exactly
+    [rank_lo, rank_lo + n_tuples)."""
+    from quartetscores_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)     # (no device: the planner is host code)
+    L.qs_score_plan.restype = C.c_int
+    L.qs_score_plan.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def plan(n, r0, cnt):
+        plo = np.zeros(n, dtype=np.uint32); pc = np.zeros(n, dtype=np.uint32); parts = np.zeros(4, dtype=np.uint64)
+        assert L.qs_score_plan(n, r0, cnt, plo.ctypes.data, pc.ctypes.data, parts.ctypes.data) == 0
+        return plo, pc, parts
+
+    def covered(n, r0, cnt):
+        plo, pc, parts = plan(n, r0, cnt)
+        hit = np.zeros(ranks.n_quartets(n) + 1, dtype=np.int32)
+        for b in range(n):
+            assert pc[b] == 0 or 1 <= b <= n - 3
+            for p in range(int(plo[b]), int(plo[b]) + int(pc[b])):
+                dd = int((1 + (1 + 8 * p) ** 0.5) / 2)          # pair index -> (c', d'), c' < d': p = C(d',2) + c'
+                while dd * (dd - 1) // 2 > p:
+                    dd -= 1
+                while (dd + 1) * dd // 2 <= p:
+                    dd += 1
+                cc = p - dd * (dd - 1) // 2
+                c, d = b + 1 + cc, b + 1 + dd
+                assert b < c < d < n
+                start = ranks.rank4(0, b, c, d)
+                hit[start:start + b] += 1
+        for lo, k in ((int(parts[0]), int(parts[1])), (int(parts[2]), int(parts[3]))):
+            hit[lo:lo + k] += 1
+        want = np.zeros_like(hit)
+        want[r0:r0 + cnt] = 1
+        assert (hit == want).all(), (n, r0, cnt)
+
+    rng = np.random.default_rng(77)
+    for n in (4, 5, 6, 9, 17, 24):
+        nq = ranks.n_quartets(n)
+        covered(n, 0, nq)
+        covered(n, 0, 0)
+        for d_lo in range(3, n):                                   # table shards: d in [d_lo, d_hi)
+            d_hi = int(rng.integers(d_lo + 1, n + 1))
+            covered(n, ranks.n_quartets(d_lo), ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo))
+        for _ in range(60):                                        # arbitrary ranges, also inside one row
+            r0 = int(rng.integers(0, nq))
+            cnt = int(rng.integers(0, nq - r0 + 1)) if rng.random() < 0.5 else int(rng.integers(0, min(nq - r0, 30) + 1))
+            covered(n, r0, cnt)
+        for r0 in range(min(nq, 40)):                              # every short range near the start (tiny rows)
+            for cnt in range(0, min(nq - r0, 12)):
+                covered(n, r0, cnt)
+    # argument checks
+    buf = np.zeros(8, dtype=np.uint64)
+    assert L.qs_score_plan(3, 0, 0, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data) != 0
+    assert L.qs_score_plan(8, 0, ranks.n_quartets(8) + 1, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data) != 0
