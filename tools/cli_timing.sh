@@ -27,6 +27,8 @@ def timed(label, cmd, out):
 
 for t in ("1", "8", "64", "0"):
     timed(f"QuartetScores -t {t}", ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out.nwk", "-t", t], d + "/out.nwk")
+timed("QuartetScores --gpus 1 (RCCL driver, one device)", ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out3.nwk", "--gpus", "1"], d + "/out3.nwk")
+print("--gpus 1 output identical:", open(d + "/out.nwk").read() == open(d + "/out3.nwk").read())
 timed("dist_cli, 1 process", [sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out2.nwk"], d + "/out2.nwk")
 print("outputs identical:", open(d + "/out.nwk").read() == open(d + "/out2.nwk").read())
 PY
