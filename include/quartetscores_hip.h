@@ -200,7 +200,10 @@ int qs_unpack16x2(qs_ctx *ctx, const void *src_device, uint64_t n_tuples, uint32
 /* Opaque device-resident copy of a batch. */
 typedef struct qs_device_batch qs_device_batch;
 
-/* Validates and copies the batch into HBM (synchronous w.r.t. the host buffers). */
+/* Validates the batch and copies it into HBM: on return the host buffers are free again (the arrays sit in pinned staging
+ * memory of the context; two buffers, so that the next batch can be staged meanwhile), the copy to the device runs on a
+ * copy stream of the library and qs_count_batch orders itself behind it. qs_batch_free never waits for kernels: the
+ * device memory is kept for a later upload, whose copy is ordered behind the kernels that still read it. */
 int qs_batch_upload(qs_ctx *ctx, const qs_tree_batch *batch, qs_device_batch **out);
 void qs_batch_free(qs_ctx *ctx, qs_device_batch *b);
 /* What the validation found: QS_BATCH_ALL_TAXA = every tree holds all n taxa, QS_BATCH_BINARY = every tree is fully

@@ -163,11 +163,13 @@ private:
                 hb.adj_depth = b.adj_depth.data();
                 hb.node_off = want_ranges ? b.node_off.data() : nullptr; hb.rng_off = want_ranges ? b.rng_off.data() : nullptr;
                 hb.ranges = b.ranges.data();
-                // at most two device batches alive: the one being counted and the one being uploaded. The upload's
-                // copy synchronises with the stream anyway, so the batch counted two iterations ago is finished.
+                // at most two device batches alive: the one being counted and the one being uploaded. Freeing is cheap
+                // (the library keeps the device slab for the next upload and orders its reuse behind the kernels).
                 if (in_flight.size() == 2) { qs_batch_free(ctx_, in_flight.front()); in_flight.erase(in_flight.begin()); }
                 qs_device_batch *db = nullptr;
-                if (qs_batch_upload(ctx_, &hb, &db) != QS_OK) fail();  // synchronous copy: `b` may go away
+                // the batch is copied into pinned staging memory here (`b` may go away); the copy to the device runs on
+                // the library's copy stream while the previous batch is still being counted
+                if (qs_batch_upload(ctx_, &hb, &db) != QS_OK) fail();
                 in_flight.push_back(db);
                 if (qs_count_batch(ctx_, db, opt.algo) != QS_OK) fail(); // asynchronous
                 while ((float)i1 > progress * onePercent && progress <= 100) { // QCL:230-233

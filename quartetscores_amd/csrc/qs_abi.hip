@@ -96,6 +96,14 @@ struct qs_ctx {
     uint64_t bundle_r0[2] = {~0ull, ~0ull}, bundle_r1[2] = {~0ull, ~0ull};
     uint32_t *bundle_dev[2] = {nullptr, nullptr};    // plo[n] | pcnt[n] | rounds[2 R]
     int n_cu = 0;
+    // tree batches go to the device through two pinned staging buffers on a copy stream of their own:
+    // qs_batch_upload returns once the batch is in pinned memory, the copy of batch k+1 overlaps the counting of batch k
+    hipStream_t copy_stream = nullptr;
+    void *pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};   // recorded after the last copy out of the buffer
+    unsigned pin_next = 0;
+    std::vector<BatchSlab> slabs;                // device slabs of freed batches, for the next uploads
 };
 
 static std::string g_create_err;
@@ -326,6 +334,9 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->ref_next_dev) (void)hipFree(c->ref_next_dev);
     if (c->root_pairs_dev) (void)hipFree(c->root_pairs_dev);
     for (int w = 0; w < 2; ++w) if (c->bundle_dev[w]) (void)hipFree(c->bundle_dev[w]);
+    for (int w = 0; w < 2; ++w) { if (c->pin_ev[w]) { (void)hipEventSynchronize(c->pin_ev[w]); (void)hipEventDestroy(c->pin_ev[w]); } if (c->pin[w]) (void)hipHostFree(c->pin[w]); }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (BatchSlab &sl : c->slabs) { (void)hipFree(sl.p); if (sl.last_use) (void)hipEventDestroy(sl.last_use); }
     delete c->ref_cache;
     delete c;
 }
@@ -434,18 +445,73 @@ extern "C" int qs_unpack16x2(qs_ctx *c, const void *src_device, uint64_t n_tuple
 extern "C" void qs_batch_free(qs_ctx *c, qs_device_batch *b) {
     if (!b) return;
     if (c) (void)hipSetDevice(c->device);
-    (void)hipFree(b->d.leaf_off); (void)hipFree(b->d.leaf_ids); (void)hipFree(b->d.adj_depth); (void)hipFree(b->d.tree_order);
-    (void)hipFree(b->d.node_off); (void)hipFree(b->d.rng_off); (void)hipFree(b->d.node_tree); (void)hipFree(b->d.ranges);
+    DeviceBatch &d = b->d;
+    if (d.ready) { (void)hipEventSynchronize(d.ready); (void)hipEventDestroy(d.ready); }
+    if (d.slab.p) {
+        // kernels that read the batch may still be queued: remember where the compute stream stands and keep the slab
+        bool kept = false;
+        if (c && c->slabs.size() < 4) {
+            if (!d.slab.last_use && hipEventCreateWithFlags(&d.slab.last_use, hipEventDisableTiming) != hipSuccess) d.slab.last_use = nullptr;
+            if (d.slab.last_use && hipEventRecord(d.slab.last_use, c->stream) == hipSuccess) { c->slabs.push_back(d.slab); kept = true; }
+        }
+        if (!kept) { (void)hipFree(d.slab.p); if (d.slab.last_use) (void)hipEventDestroy(d.slab.last_use); }   // (hipFree waits for the device)
+    }
     delete b;
 }
 
-template <typename T> static hipError_t to_device(T **dst, const T *src, size_t count) {
-    *dst = nullptr;
-    hipError_t e = hipMalloc((void **)dst, std::max<size_t>(count, 1) * sizeof(T));
-    if (e != hipSuccess) return e;
-    if (count) e = hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
-    return e;
-}
+// One batch's arrays are packed (256-byte aligned pieces) into a pinned staging buffer of the context and go to a device
+// slab of the same layout with ONE copy on the copy stream. Slabs come from a small cache of the context: qs_batch_free
+// records where the compute stream stands and hands the slab back, the next upload makes the copy stream wait for that
+// point -- no hipMalloc / hipFree (a device-wide synchronisation) per batch, and no host thread ever waits for a kernel.
+struct Stager {
+    qs_ctx *c = nullptr; int slot = 0; size_t off = 0, need = 0; hipError_t err = hipSuccess;
+    BatchSlab slab;
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    hipError_t begin(qs_ctx *ctx, size_t bytes) {
+        c = ctx; need = std::max<size_t>(bytes, 256); slot = (int)(c->pin_next++ & 1u);
+        hipError_t e = hipSuccess;
+        if (!c->copy_stream) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess && !c->pin_ev[slot]) e = hipEventCreateWithFlags(&c->pin_ev[slot], hipEventDisableTiming);
+        else if (e == hipSuccess) e = hipEventSynchronize(c->pin_ev[slot]);      // its previous contents are on the device
+        if (e == hipSuccess && c->pin_cap[slot] < need) {
+            if (c->pin[slot]) { (void)hipHostFree(c->pin[slot]); c->pin[slot] = nullptr; c->pin_cap[slot] = 0; }
+            const size_t cap = need + need / 4 + 4096;
+            e = hipHostMalloc(&c->pin[slot], cap, hipHostMallocDefault);
+            if (e == hipSuccess) c->pin_cap[slot] = cap;
+        }
+        if (e != hipSuccess) return err = e;
+        // device slab: the smallest cached one that is large enough, else a new one
+        int best = -1;
+        for (size_t i = 0; i < c->slabs.size(); ++i)
+            if (c->slabs[i].cap >= need && (best < 0 || c->slabs[i].cap < c->slabs[(size_t)best].cap)) best = (int)i;
+        if (best >= 0) { slab = c->slabs[(size_t)best]; c->slabs.erase(c->slabs.begin() + best); }
+        else {
+            slab = BatchSlab();
+            slab.cap = need + need / 4;
+            e = hipMalloc(&slab.p, slab.cap);
+            if (e != hipSuccess) { slab = BatchSlab(); return err = e; }
+        }
+        if (slab.last_use) e = hipStreamWaitEvent(c->copy_stream, slab.last_use, 0);   // kernels of its previous batch
+        return err = e;
+    }
+    template <typename T> T *put(const T *src, size_t count) {
+        if (err != hipSuccess) return nullptr;
+        const size_t bytes = count * sizeof(T);
+        if (count) std::memcpy(static_cast<unsigned char *>(c->pin[slot]) + off, src, bytes);
+        T *dev = reinterpret_cast<T *>(static_cast<unsigned char *>(slab.p) + off);
+        off += padded(bytes);
+        return dev;
+    }
+    // `ready` fires when the batch is on the device; the staging buffer is free again at the same moment
+    hipError_t finish(hipEvent_t *ready) {
+        if (err != hipSuccess) return err;
+        err = hipMemcpyAsync(slab.p, c->pin[slot], std::max<size_t>(off, 1), hipMemcpyHostToDevice, c->copy_stream);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(ready, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventRecord(*ready, c->copy_stream);
+        if (err == hipSuccess) err = hipEventRecord(c->pin_ev[slot], c->copy_stream);
+        return err;
+    }
+};
 
 extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_batch **out) {
     if (!c || !hb || !out) return fail(c, QS_ERR_ARG, "qs_batch_upload: NULL argument");
@@ -545,15 +611,13 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
             for (uint32_t t = 0; t < nt; ++t) order_host[start[final_cls(cls[t])]++] = t;
         }
     }
-    hipError_t e = hipSetDevice(c->device);
-    if (e == hipSuccess) e = to_device(&d.leaf_off, hb->leaf_off, (size_t)nt + 1);
-    if (e == hipSuccess) e = to_device(&d.leaf_ids, hb->leaf_ids, d.total_leaves);
-    if (e == hipSuccess) e = to_device(&d.adj_depth, hb->adj_depth, d.total_leaves);
-    if (e == hipSuccess && !order_host.empty()) e = to_device(&d.tree_order, order_host.data(), order_host.size());
-    if (e == hipSuccess && hb->node_off && hb->rng_off && hb->ranges) {
+    // scatter batches: the tree of every inner node, and a bounds check of the leaf ranges (host side, before any copy)
+    const bool with_nodes = hb->node_off && hb->rng_off && hb->ranges;
+    std::vector<uint32_t> node_tree;
+    if (with_nodes) {
         d.n_nodes = hb->node_off[nt];
         d.n_links = hb->rng_off[d.n_nodes];
-        std::vector<uint32_t> node_tree(d.n_nodes);
+        node_tree.resize(d.n_nodes);
         for (uint32_t t = 0; t < nt; ++t) {
             const uint32_t L = hb->leaf_off[t + 1] - hb->leaf_off[t];
             for (uint32_t v = hb->node_off[t]; v < hb->node_off[t + 1]; ++v) {
@@ -565,11 +629,28 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
                     }
             }
         }
-        if (e == hipSuccess) e = to_device(&d.node_off, hb->node_off, (size_t)nt + 1);
-        if (e == hipSuccess) e = to_device(&d.rng_off, hb->rng_off, (size_t)d.n_nodes + 1);
-        if (e == hipSuccess) e = to_device(&d.node_tree, node_tree.data(), d.n_nodes);
-        if (e == hipSuccess) e = to_device(&d.ranges, hb->ranges, (size_t)2 * d.n_links);
     }
+    hipError_t e = hipSetDevice(c->device);
+    Stager st;
+    if (e == hipSuccess) {
+        size_t need = Stager::padded(((size_t)nt + 1) * 4) + 2 * Stager::padded((size_t)d.total_leaves * 2) + Stager::padded(order_host.size() * 4);
+        if (with_nodes) need += Stager::padded(((size_t)nt + 1) * 4) + Stager::padded(((size_t)d.n_nodes + 1) * 4) + Stager::padded((size_t)d.n_nodes * 4) + Stager::padded((size_t)2 * d.n_links * 2);
+        e = st.begin(c, need);
+    }
+    if (e == hipSuccess) {
+        d.leaf_off = st.put(hb->leaf_off, (size_t)nt + 1);
+        d.leaf_ids = st.put(hb->leaf_ids, d.total_leaves);
+        d.adj_depth = st.put(hb->adj_depth, d.total_leaves);
+        if (!order_host.empty()) d.tree_order = st.put(order_host.data(), order_host.size());
+        if (with_nodes) {
+            d.node_off = st.put(hb->node_off, (size_t)nt + 1);
+            d.rng_off = st.put(hb->rng_off, (size_t)d.n_nodes + 1);
+            d.node_tree = st.put(node_tree.data(), d.n_nodes);
+            d.ranges = st.put(hb->ranges, (size_t)2 * d.n_links);
+        }
+        e = st.finish(&d.ready);
+    }
+    d.slab = st.slab;
     if (e != hipSuccess) {
         qs_batch_free(c, b);
         return fail(c, e == hipErrorOutOfMemory ? QS_ERR_OOM : QS_ERR_HIP, std::string("qs_batch_upload: ") + hipGetErrorString(e));
@@ -598,6 +679,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     }
     if (!(d.all_full && d.all_binary))
         return fail(c, QS_ERR_STATE, "QS_COUNT_WIRE16X2: the batch is not made of binary trees that hold all taxa (count into the table and use qs_table_pack16)");
+    if (d.ready) QS_HIP(c, hipStreamWaitEvent(c->stream, d.ready, 0));
     if ((overwrite ? 0 : c->wire_trees) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "QS_COUNT_WIRE16X2: more than 65535 trees do not fit 16-bit cells");
     if (d.class_bits[d.n_classes - 1] > 7) return fail(c, QS_ERR_UNSUPPORTED, "QS_COUNT_WIRE16X2: tree depth needs more than 7 bits; count into the table instead");
@@ -654,6 +736,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     }
     if (c->count_bits == 16 && ((algo & QS_COUNT_OVERWRITE) ? 0 : c->trees_counted) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "qs_count_batch: more than 65535 trees need count_bits = 32");
+    if (d.ready) QS_HIP(c, hipStreamWaitEvent(c->stream, d.ready, 0));   // the batch's copies run on the copy stream
     const bool overwrite = (algo & QS_COUNT_OVERWRITE) != 0;
     const bool timed = (algo & QS_COUNT_TIMED) != 0;
     algo &= ~(QS_COUNT_OVERWRITE | QS_COUNT_TIMED);

@@ -21,6 +21,10 @@ constexpr uint32_t kMaxDepthU8Partial = 31;
 constexpr uint32_t kMaxDepthU16Full = 16383;
 constexpr uint32_t kMaxDepthU16Partial = 8191;
 
+// device memory of one uploaded batch (all its arrays in one allocation); last_use: where the compute stream stood when
+// the batch was freed (the slab is handed to a later upload, whose copy waits for it)
+struct BatchSlab { void *p = nullptr; size_t cap = 0; hipEvent_t last_use = nullptr; };
+
 struct DeviceBatch {
     uint32_t n_trees = 0;
     uint32_t total_leaves = 0;
@@ -42,6 +46,8 @@ struct DeviceBatch {
     uint32_t n_nodes = 0, n_links = 0;
     uint32_t *node_off = nullptr, *rng_off = nullptr, *node_tree = nullptr;
     uint16_t *ranges = nullptr;
+    BatchSlab slab;                 // owns the arrays above
+    hipEvent_t ready = nullptr;     // fires when the batch's arrays have arrived (copy stream); the count waits for it
 };
 
 struct CountGeometry {
