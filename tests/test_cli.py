@@ -342,3 +342,28 @@ def test_cpp_cli_gpus_path_matches_single_gpu(tmp_path, trees, rooted):
     assert "all-reduce" in p.stdout and o3.read_text() == o1.read_text() and q3.read_text() == q1.read_text()
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "o4.nwk"), "--gpus", "9")
     assert p.returncode == 1 and "device(s) visible" in p.stderr
+
+
+@pytest.mark.gpu
+def test_insufficient_memory_is_reported_like_the_reference(tmp_path):
+    """A count table that does not fit the device: the library reports QS_ERR_OOM with the reference's message
+    ("Insufficient memory!", QuartetScoreComputer.hpp:724-745 throws it as a runtime_error) instead of crashing, the
+    context stays usable, and the CLI ends with that message and a non-zero status. 1200 taxa = 3 * C(1200,4) * 2 B = 515 GB."""
+    from quartetscores_amd import engine, synth
+    ctx = engine.Context(1200, 16)
+    with pytest.raises(engine.QSError) as ei:
+        ctx.table_alloc()
+    assert ei.value.code == -3 and "Insufficient memory!" in str(ei.value)
+    ctx.close()
+    small = engine.Context(12, 16)      # the device is fine afterwards
+    small.table_alloc()
+    small.close()
+    n = 1200
+    ref = tmp_path / "big_ref.nwk"
+    ref.write_text(synth.reference_tree(n, 31) + "\n")
+    ev = tmp_path / "big_eval.nwk"
+    ev.write_text(synth.reference_tree(n, 32) + "\n")
+    out = tmp_path / "big_out.nwk"
+    p = run("-r", str(ref), "-e", str(ev), "-o", str(out))
+    assert p.returncode != 0 and "Insufficient memory!" in (p.stderr + p.stdout)
+    assert not out.exists()
