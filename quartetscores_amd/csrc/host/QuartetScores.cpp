@@ -10,6 +10,7 @@
 // --save-table / --load-table write / read the raw count table (resume without recounting).
 #include "QuartetScoreComputer.hpp"
 #include "multi_gpu.hpp"
+#include "table_shards.hpp"
 
 #include <cerrno>
 #include <chrono>
@@ -27,6 +28,8 @@ struct Args {
     std::string ref, eval, out, raw, raw_bin;
     size_t threads = 0;
     bool verbose = false, savemem = false, raw_rank_order = false;
+    int table_shards = -1;   // -1 = off (the whole table on the device); 0 = as many as the device's free memory asks for; K = K shards, one after the other (table_shards.hpp)
+    int spill = 0;           // ShardedTableQuartetScoreComputer::Spill
     int gpus = 0;   // 0 = the single-GPU path; N >= 1 = trees split over N GPUs of this node + one RCCL collective (multi_gpu.hpp)
     DeviceOptions dev;
 };
@@ -48,6 +51,10 @@ void usage(std::ostream &os) {
           "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
           "   --root-as-edge rooted reference tree: score the two root edges as one internode (the reference's\n"
           "                  own handling of a degree-2 root is the default)\n"
+          "   --table-shards K  a count table larger than the device's memory: K shards by largest taxon id pass through the\n"
+          "                  GPU one after the other (0 = as many as the free device memory asks for)\n"
+          "   --spill M      with --table-shards: host (keep finished shards in host memory) | recount (count every shard a\n"
+          "                  second time for the second scoring pass) | auto (host if it fits MemAvailable; default)\n"
           "   --save-table F write the count table to F after counting\n"
           "   --load-table F read the count table from F instead of counting (-e is still needed for m)\n"
           "   --qic-binary F raw per-quartet QIC as a binary file (topology byte + double per quartet, in rank order)\n";
@@ -87,6 +94,15 @@ int parse(int argc, char **argv, Args &a) {
         else if (f == "-v" || f == "--verbose") a.verbose = true;
         else if (f == "-s" || f == "--savemem") a.savemem = true;
         else if (f == "--gpus") { if (!(v = need(i, "--gpus")) || !number(v, "--gpus", num)) return 1; a.gpus = (int)num; }
+        else if (f == "--table-shards") { if (!(v = need(i, "--table-shards")) || !number(v, "--table-shards", num)) return 1; a.table_shards = (int)num; }
+        else if (f == "--spill") {
+            if (!(v = need(i, "--spill"))) return 1;
+            const std::string sv = v;
+            if (sv == "host") a.spill = ShardedTableQuartetScoreComputer::SPILL_HOST;
+            else if (sv == "recount") a.spill = ShardedTableQuartetScoreComputer::SPILL_RECOUNT;
+            else if (sv == "auto") a.spill = ShardedTableQuartetScoreComputer::SPILL_AUTO;
+            else { std::cerr << "ERROR: --spill takes host, recount or auto" << std::endl; return 1; }
+        }
         else if (f == "--device") { if (!(v = need(i, "--device")) || !number(v, "--device", num)) return 1; a.dev.device = (int)num; }
         else if (f == "--algo") {
             if (!(v = need(i, "--algo"))) return 1;
@@ -117,10 +133,27 @@ void run_multi(const Tree &referenceTree, const Args &a, size_t m, uint32_t coun
     if (!a.raw_bin.empty()) print_raw_qic_binary(mg.context0(), mg.reference(), referenceTree, a.raw_bin);
 }
 
+// --table-shards K: the table passes through one GPU shard by shard (table_shards.hpp)
+void run_sharded(const Tree &referenceTree, const Args &a, size_t m, uint32_t count_bits, int shards, std::vector<double> &lqic,
+                 std::vector<double> &qpic, std::vector<double> &eqpic) {
+    if (!a.dev.load_table.empty() || !a.dev.save_table.empty() || !a.raw.empty() || !a.raw_bin.empty())
+        throw std::runtime_error("--table-shards: -q / --qic-binary / --save-table / --load-table need the whole table on the device");
+    ShardedTableQuartetScoreComputer st(referenceTree, a.eval, m, count_bits, shards, (ShardedTableQuartetScoreComputer::Spill)a.spill, a.dev);
+    lqic = st.scores.lq; qpic = st.scores.qp; eqpic = st.scores.eqp;
+}
+
 template <typename CINT>
 void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double> &lqic, std::vector<double> &qpic,
          std::vector<double> &eqpic) {
     if (a.gpus > 0) return run_multi(referenceTree, a, m, sizeof(CINT) <= 2 ? 16u : 32u, lqic, qpic, eqpic);
+    if (a.table_shards >= 0) {
+        const uint32_t bits = sizeof(CINT) <= 2 ? 16u : 32u;
+        size_t n = 0;
+        for (size_t v = 0; v < referenceTree.node_count(); ++v) n += referenceTree.is_leaf(v);
+        const uint64_t bytes = (uint64_t)n * (n - 1) * (n - 2) * (n - 3) / 24 * 3 * (bits / 8);
+        const int shards = a.table_shards > 0 ? a.table_shards : ShardedTableQuartetScoreComputer::shards_needed(bytes, a.dev.device);
+        if (a.table_shards > 0 || shards > 1) return run_sharded(referenceTree, a, m, bits, shards, lqic, qpic, eqpic);
+    }
     QuartetScoreComputer<CINT> qsc(referenceTree, a.eval, m, a.verbose, a.savemem, a.dev);
     lqic = qsc.getLQICScores();
     qpic = qsc.getQPICScores();

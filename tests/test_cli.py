@@ -367,3 +367,40 @@ def test_insufficient_memory_is_reported_like_the_reference(tmp_path):
     p = run("-r", str(ref), "-e", str(ev), "-o", str(out))
     assert p.returncode != 0 and "Insufficient memory!" in (p.stderr + p.stdout)
     assert not out.exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trees,rooted,kind", [(90, False, "mixed"), (70000, False, "binary"), (150, True, "binary")])
+def test_cpp_cli_table_shards_match_the_whole_table_run(tmp_path, trees, rooted, kind):
+    """QuartetScores --table-shards K (table_shards.hpp): the count table passes through ONE GPU in K shards by largest
+    taxon id -- count all trees into the shard, score pass 1, spill the shard to host memory or drop it and count it
+    again, score pass 2 against the global minima -- and the annotated tree is identical to the whole-table run: u16 and
+    u32 tables, partial / multifurcating evaluation trees, a rooted reference (the (root, v) pair sums add up over the
+    shards), more shards than largest ids can fill (empty ones are dropped), --table-shards 0 (as many as needed: one)."""
+    import numpy as np
+    from quartetscores_amd import native_ingest, synth
+    n = 19
+    ref_nw = synth.random_tree(n, np.random.default_rng(911), rooted=rooted)
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    if kind == "binary":
+        e.write_bytes(native_ingest.synth_trees(n, trees, 912))
+    else:
+        e.write_text("\n".join(synth.tree_set(n, trees, 913, collapse=0.2, dropout=0.15)) + "\n")
+    o1 = tmp_path / "o1.nwk"
+    p = run("-r", str(r), "-e", str(e), "-o", str(o1))
+    assert p.returncode == 0, p.stderr
+    want = o1.read_text()
+    for i, extra in enumerate((["--table-shards", "3", "--spill", "host"], ["--table-shards", "3", "--spill", "recount"],
+                               ["--table-shards", "40"], ["--table-shards", "1"], ["--table-shards", "0"])):
+        o = tmp_path / f"s{i}.nwk"
+        p = run("-r", str(r), "-e", str(e), "-o", str(o), *extra)
+        assert p.returncode == 0, (extra, p.stderr)
+        assert o.read_text() == want, extra
+        if extra[1] not in ("0",):
+            assert "table shard(s) by largest taxon id" in p.stdout and "Finished computing scores." in p.stdout
+            assert ("kept in host memory" in p.stdout) == (extra[-1] != "recount")
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "x.nwk"), "--table-shards", "2", "-q", str(tmp_path / "x.txt"))
+    assert p.returncode == 1 and "need the whole table" in p.stderr
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "y.nwk"), "--table-shards", "2", "--spill", "disk")
+    assert p.returncode == 1 and "--spill takes" in p.stderr
