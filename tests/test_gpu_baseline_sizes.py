@@ -103,10 +103,31 @@ def check_full_size(eng, cfg_no, n, m, bits, d_lo=0, d_hi=0, expect_slices=True)
     return ctx, table, (ref_nw, ref, text, batch)
 
 
+def score_steps(ctx, ref, kernel):
+    """Score passes 1 and 2 with the bundle kernel (0) or the scan kernel (1): per-node-pair sums, candidate slots."""
+    import torch
+    ctx.set_tuning(_lib.QS_TUNE_SCORE_KERNEL, kernel)
+    P = ctx.score_pair_slots(ref)
+    sums = torch.empty(3 * P, dtype=torch.int64, device="cuda"); mins = torch.empty(P, dtype=torch.int64, device="cuda")
+    cand = torch.empty(8 * P, dtype=torch.int64, device="cuda")
+    ctx.score_pass1(ref, sums, mins)
+    ctx.score_pass2(ref, mins, cand)
+    extra = ctx.score_overflow(ref, mins, cand)
+    sh, ch = sums.cpu().numpy(), cand.cpu().numpy()
+    return sh, ctx.score_finish(ref, sh, ch[None, :], extra=extra)
+
+
 def test_configs2_512_taxa_10000_trees_u32(eng):
-    """BASELINE configs[2]: 34 GB table, bitslice_b5x2, default 96 MiB panel slices (9 launches with table RMW)."""
-    ctx, table, _ = check_full_size(eng, 2, 512, 10000, 32)
+    """BASELINE configs[2]: 34 GB table, depth classes B=4 / B=5, three panel slices (the later ones read-modify-write
+    the table). Scoring at full size: the bundle kernel (43 000 planned rounds) and the scan kernel give the same
+    per-node-pair sums bit for bit and the same LQ-/QP-/EQP-IC."""
+    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 2, 512, 10000, 32)
     assert ctx.table_bytes == 33958525440
+    a, b = score_steps(ctx, ref, 0), score_steps(ctx, ref, 1)
+    assert (a[0] == b[0]).all()
+    for x, y in zip(a[1][:3], b[1][:3]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert np.isfinite(a[1][0][1:]).sum() == 512 - 3          # every internode of the binary reference got its LQ-IC
     ctx.close()
 
 
@@ -155,6 +176,9 @@ def test_configs4_shard_1024_taxa_5000_trees_u16(eng):
     """One of the 8 table shards of BASELINE configs[4] (34 GB of u16 cells; every GPU counts all 5000 trees)."""
     n, m = 1024, 5000
     d_lo, d_hi = distributed.shard_of_largest_id(n, 8, 3)
-    ctx, table, _ = check_full_size(eng, 4, n, m, 16, d_lo, d_hi)
+    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 4, n, m, 16, d_lo, d_hi)
     assert 33e9 < ctx.table_bytes < 35e9
+    # the shard's part of the scoring (u16 cells, a plan restricted to d in [d_lo, d_hi)): both kernels, same sums
+    a, b = score_steps(ctx, ref, 0), score_steps(ctx, ref, 1)
+    assert (a[0] == b[0]).all() and a[0].any()
     ctx.close()
