@@ -877,7 +877,7 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     // one (d-block, c) neighbourhood instead of all eight: +4 % at 512 taxa, +1.5 % at 256, -2 % at 128 (there the
     // whole panel fits every L2), so the launcher sets it from 200 taxa on.
     uint32_t lb = blockIdx.x;
-    if (xcd_remap) {
+    if (xcd_remap & 1u) {
         const uint32_t nb = gridDim.x, q8 = nb / 8, r8 = nb % 8, xcd = lb % 8, y = lb / 8;
         lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + y; // bijective on [0, nb)
     }
@@ -1000,6 +1000,13 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
                     Planes &abn2, auto a2_tag, auto full_tag, auto two_tag) {
         constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value, TWO = decltype(two_tag)::value;
         const __amdgpu_buffer_rsrc_t r = rsrc_of(g_next);
+        // The four waves of a workgroup are independent tiles, but consecutive ones: same b-block, c and d-block. Keeping
+        // them in step (one s_barrier per 32-tree group; every wave runs the same number of steps, a wave without a tile
+        // has ended and does not count) lets their identical panel loads -- M[b,d], M[c,d], M[b,c] -- meet in the L1
+        // instead of becoming separate requests to the L2, whose number bounds the kernel together with VALU issue
+        // (profiles/r02_experiments.md): -5 % at 512 taxa, -9 % with NNI trees, -5 % on a 1024-taxon shard, -1 % at 256;
+        // at 128 taxa and below (the panel sits in the L2 anyway) it costs 4-6 %, so the launcher sets bit 1 from 200 on.
+        if (xcd_remap & 2u) __builtin_amdgcn_s_barrier();
         Staged st;
         st.x0 = gload(r, x0off);
         st.y = gload(r, yoff);
@@ -1139,7 +1146,7 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const v
 #define QS_BS3(BB, MM, CT)                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 1u : 0u, wire, g.perm)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 3u : 0u /* bit 0: XCD remap, bit 1: waves of a workgroup in step */, wire, g.perm)
 #define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
         if (depth_bits <= 4) QS_BS3(4, MM, CT);                                                                     \
