@@ -6,8 +6,10 @@
 //   the topology test of printRawQICScores              :636-672
 //
 // The reference walks node pairs (u,v) and enumerates S1xS2xS3xS4; every 4-set is visited
-// exactly once overall. Here the walk is quartet-major: lane = table rank, so the table is
-// read once with fully coalesced 12-byte tuples. Lookup ids are the reference tree's own
+// exactly once overall. Here the walk is quartet-major, in the order of the table: the bundle
+// kernel (passes 1 and 2) gives a wave 64 table rows with the same second id and walks them in
+// lockstep, the scan kernel (pass 3, partial rows, A/B) gives a lane 8 consecutive ranks; the
+// table is read once per pass. Lookup ids are the reference tree's own
 // depth-first leaf order (QuartetCounterLookup.hpp:252-258), therefore for sorted ids
 // a<b<c<d only the two non-crossing pairings ab|cd and ad|bc can be the reference topology,
 // decided from the LCA depths of the three adjacent pairs (equivalent to the reference's
