@@ -1074,3 +1074,37 @@ def test_score_bundle_kernel_equals_scan_kernel(eng, n, bits, kind):
         same(steps(0), steps(1), (r_lo, cnt))
     ctx.score_set_view(None, 0, 0, 0)
     ctx.close()
+
+
+@pytest.mark.parametrize("dropout,collapse,variant", [(0.0, 0.25, "general_full"), (0.12, 0.0, "partial"), (0.1, 0.2, "partial"),
+                                                      (0.0, 0.0, "binary_full")])
+def test_lockstep_launches_match_the_swar_kernel(eng, dropout, collapse, variant):
+    """From 200 taxa on the four waves of a count workgroup take their 32-tree steps together (one barrier per step).
+    Every mode of the bit-sliced kernel -- multifurcating trees, missing taxa, binary -- at such a size, several tree
+    groups and a ragged last one, both cell widths: the table equals the byte-SWAR kernel's (no barrier) bit for bit,
+    and a sample of it the split-based brute force."""
+    import bruteforce
+    n, m = 212, 150
+    ref_nw, trees = make_case(n, m, 977, dropout=dropout, collapse=collapse)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    for bits in (32, 16):
+        ctx = eng.Context(n, bits)
+        ctx.table_alloc()
+        hb = ctx.batch_upload(batch, with_nodes=False)
+        ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+        ctx.sync()
+        assert variant in ctx.last_count_variant() and "bitslice" in ctx.last_count_variant(), ctx.last_count_variant()
+        mine = ctx.table_download()
+        ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+        ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+        ctx.sync()
+        assert "depth_u" in ctx.last_count_variant()
+        assert (mine == ctx.table_download()).all()
+        rng = np.random.default_rng(978)
+        q = np.sort(np.stack([rng.choice(n, size=4, replace=False) for _ in range(3000)]), axis=1)
+        got = ctx.lookup(q.astype(np.uint16))
+        want = bruteforce.quartet_counts_for(trees, ref.names, q)
+        assert (got == want).all()
+        ctx.batch_free(hb)
+        ctx.close()
