@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--cpu-budget-s", type=float, default=8.0, help="seconds of CPU counting per thread setting of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the e2e legs (CLI child process; steps with the host-array upload inside)")
     ap.add_argument("--no-impl-check", action="store_true", help="skip the on-device comparison with the byte-SWAR implementation")
     ap.add_argument("--nni", action="store_true", help="evaluation trees = reference tree + Poisson(n/8) random NNIs (concentrated counts)")
     ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees; numpy generator, small sizes)")
@@ -135,7 +136,7 @@ def cpu_child(spec_path):
     savemem = bool(info["mem_available_bytes"] and fast_bytes > 0.5 * info["mem_available_bytes"])
     o = Oracle(spec["ref"])
     out = dict(info)
-    out.update({"kind": "port", "unit": "quartets/s", "table": "compact C(n,4)x3 (--savemem)" if savemem else "fast n^4",
+    out.update({"kind": "port", "unit": "quartets/s", "table": "compact table" if savemem else "n^4 table",
                 "cint_bits": cint_bits, "runs": []})
 
     def run(th, secs):
@@ -156,9 +157,11 @@ def cpu_child(spec_path):
                 best = r
     out["t1"] = {"value": r1["value"], "cores": 1}
     out["value"], out["cores"] = best["value"], best["threads"]
-    out["sample"] = (f"first {best['trees_equiv']:.2f} trees' worth of increments of the {m}-tree batch (n={n}), "
-                     f"{out['table']} table of u{cint_bits} cells, OpenMP -t {best['threads']}, {best['seconds']:.1f} s; "
-                     f"-t 1: {r1['value']:.3g} quartets/s over {r1['seconds']:.1f} s")
+    # counting is linear in the number of trees: the rate measured on a prefix stands for the whole batch
+    out["extrapolated_from_trees"] = round(best["trees_equiv"], 3)
+    out["batch_trees"] = m
+    out["sample"] = (f"{best['trees_equiv']:.2f} trees' worth of increments of the {m}-tree batch, {out['table']} u{cint_bits}, "
+                     f"-t {best['threads']}, {best['seconds']:.1f} s")[:100]
     o.close()
     print(json.dumps(out))
 
@@ -187,6 +190,43 @@ def run_cpu_baseline(ref_nw, eval_text, n, m, nq, budget_s):
         return {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     finally:
         for q in (tp, sp):
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
+
+
+def run_cli_e2e(ref_nw, eval_text, threads=8):
+    """The product's own counting phase (QuartetScores CLI: Newick text on disk -> table in HBM) on the same trees, in a
+    child process, BEFORE this process touches the GPU. Returns the phases the CLI prints (Appendix A protocol)."""
+    import re
+    import tempfile
+    exe = os.path.join(ROOT, "quartetscores_amd", "bin", "QuartetScores")
+    if not os.path.exists(exe):
+        return {"error": "quartetscores_amd/bin/QuartetScores not built"}
+    d = tempfile.mkdtemp(prefix="qsbench_cli_")
+    rp, ep, op = (os.path.join(d, x) for x in ("ref.nwk", "eval.nwk", "out.nwk"))
+    try:
+        with open(rp, "w") as f:
+            f.write(ref_nw + "\n")
+        with open(ep, "wb") as f:
+            f.write(eval_text if isinstance(eval_text, bytes) else eval_text.encode())
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "-r", rp, "-e", ep, "-o", op, "-t", str(threads)], capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        took = [int(x) for x in re.findall(r"It took: (\d+) microseconds", p.stdout)]
+        if p.returncode != 0 or len(took) < 2:
+            return {"error": f"rc {p.returncode}: {p.stderr[-200:]}"}
+        return {"counting_phase_ms": took[0] / 1e3, "scoring_phase_ms": took[1] / 1e3, "process_wall_ms": wall * 1e3,
+                "host_threads": threads, "newick_bytes": os.path.getsize(ep)}
+    except Exception as e:  # reported, never required for the metric
+        return {"error": str(e)[:200]}
+    finally:
+        for q in (rp, ep, op):
             try:
                 os.remove(q)
             except OSError:
@@ -280,6 +320,10 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         cpu_baseline = run_cpu_baseline(ref_nw, sample_text, n, m, ranks.n_quartets(n), args.cpu_budget_s)
 
+    cli_e2e = None
+    if not args.no_e2e and world == 1 and binary_full_trees and shards == 1 and args.algo == "gather":
+        cli_e2e = run_cli_e2e(ref_nw, sample_text)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # QS_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, collective) even with one rank
@@ -363,13 +407,14 @@ def main():
             ctx.table_attach(tables[i])
         if args.algo != "gather":
             ctx.table_clear()
-        if collective and wire_fmt == "u16x2" and not timed:
+        t_flag = engine.QS_COUNT_TIMED if timed else 0
+        if collective and wire_fmt == "u16x2":
             ctx.wire_attach(wire[i])     # counted straight into the wire words: no table write, no pack pass
-            ctx.count_batch(hb, step_algo | engine.QS_COUNT_WIRE16X2)
+            ctx.count_batch(hb, step_algo | engine.QS_COUNT_WIRE16X2 | t_flag)
         else:
-            ctx.count_batch(hb, step_algo | (engine.QS_COUNT_TIMED if timed else 0))
+            ctx.count_batch(hb, step_algo | t_flag)
         if collective:
-            if wire_fmt == "u16x2" and not timed:
+            if wire_fmt == "u16x2":
                 src = wire[i]
             elif wire16:
                 (ctx.table_pack16x2 if wire_fmt == "u16x2" else ctx.table_pack16)(wire[i])
@@ -549,19 +594,49 @@ def main():
             lookup_ok = bool((got == want).all())
         ctx_s.close()
 
-    score_ms = None
-    if not args.no_score and shards == 1:
+    # ---- e2e leg 2: the same step with the host-array upload (qs_batch_upload: validation, pinned staging, H2D copy)
+    # inside the timed region; the boundary hands over host arrays, so this is the PCIe-inclusive rate
+    upload_step_ms = None
+    if not args.no_e2e and args.algo == "gather":
+        def up_step():
+            h2 = ctx.batch_upload(batch, with_nodes=False)
+            ctx.count_batch(h2, step_algo)
+            ctx.batch_free(h2)
+        up_step()
+        ctx.sync()
+        k_up = 3 if one_ms >= 100 else max(3, min(steps, 50))
         torch.cuda.synchronize(dev)
-        s0 = time.perf_counter()
-        if reduce_mode == "scatter" and steps > 0:
-            # every rank scores the shard it received (view), accumulators combined with small collectives
-            own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
-            ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
-            distributed.score_sharded(ctx, ref)
-            ctx.score_set_view(None, 0, 0, 0)
-        else:
-            ctx.score(ref)
-        score_ms = (time.perf_counter() - s0) * 1e3
+        u0 = time.perf_counter()
+        for _ in range(k_up):
+            up_step()
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        upload_step_ms = (time.perf_counter() - u0) * 1e3 / k_up
+        step()                           # the gates / scoring below read the table of a plain step
+        ctx.sync()
+
+    # ---- scoring (secondary metric of SURVEY 8(d)): ONE cold call (first use: reference tree, LCA matrix, plans,
+    # accumulator allocation) and then warm calls; phases from qs_last_score_ms
+    score_cold_ms = score_ms = None
+    score_phases_cold = score_phases = None
+    if not args.no_score and shards == 1:
+        def score_once():
+            torch.cuda.synchronize(dev)
+            s0 = time.perf_counter()
+            if reduce_mode == "scatter" and steps > 0:
+                # every rank scores the shard it received (view), accumulators combined with small collectives
+                own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
+                ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
+                distributed.score_sharded(ctx, ref)
+                ctx.score_set_view(None, 0, 0, 0)
+                ph = None
+            else:
+                ctx.score(ref)
+                ph = {k_: round(v_, 3) for k_, v_ in ctx.last_score_ms().items()}
+            return (time.perf_counter() - s0) * 1e3, ph
+        score_cold_ms, score_phases_cold = score_once()
+        warm = [score_once() for _ in range(3)]
+        score_ms, score_phases = min(warm, key=lambda x: x[0])
 
     if rank != 0:
         dist.barrier()
@@ -610,14 +685,17 @@ def main():
         "dtype": "u32" if count_bits == 32 else "u16",
         "data": "synthetic",
         "config": {
-            "workload": f"{wl_name}: {n} taxa, {m_total} eval trees" + (f" split over {world} rank(s) ({m} on rank 0)" if split else f" per rank" if world > 1 else "")
-                        + f", uint{count_bits} C(n,4)x3 table ({nq_all} quartets" + (f"; table-sharded by the largest id into {shards}, this rank d in [{d_lo},{d_hi}) = {nq} quartets" if shards > 1 else "") + ")"
-                        + (", reference tree + Poisson(n/8) NNIs" if args.nni else ", uniformly random binary trees" if binary_full_trees else f", collapse {args.collapse} dropout {args.dropout}")
-                        + f", seeds {seed_ref}/{seed_set}" + ("+rank" if not (split or shards > 1) and world > 1 else ""),
+            "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " per rank" if world > 1 else "")
+                         + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
+                         + (", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else f", collapse {args.collapse} dropout {args.dropout}")
+                         + f", seeds {seed_ref}/{seed_set}")[:100],
+            "quartets": nq_all,
+            "quartets_this_rank": nq,
             "workload_key": workload_key,
             "table_shard": [d_lo, d_hi] if shards > 1 else None,
             "algo": variant,
-            "step": ("pair-depth panel build + count kernel per panel slice (first slice stores: no separate table clear)" if args.algo == "gather" else "table clear + count kernel") + ((({"u16": " + pack to u16 cells", "u16x2": ", counted straight into one word n0|n1<<16 per tuple (binary full trees: n2 = trees - n0 - n1; no table write, no pack pass)", None: ""}[wire_fmt]) + (" + RCCL reduce-scatter of the table (rank r keeps and scores tuples [r*T,(r+1)*T))" if reduce_mode == "scatter" else " + RCCL all-reduce of the table") + ", asynchronous, overlapped with the next step (two buffers in flight)") if collective_saved else ""),
+            "step": (("panel build + count kernel per slice (1st slice stores)" if args.algo == "gather" else "table clear + count kernel")
+                     + ((" + " + {"u16": "pack u16 + ", "u16x2": "1 word/tuple wire + ", None: ""}[wire_fmt] + ("RCCL reduce-scatter" if reduce_mode == "scatter" else "RCCL all-reduce") + ", async, 2 buffers") if collective_saved else ""))[:100],
             "collective": reduce_mode,
             "collective_input_bytes_per_rank": send_words * 4 if collective_saved else None,
             "collective_alone_ms": coll_alone_ms,
@@ -632,9 +710,24 @@ def main():
             "count_kernels_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
             "score_phase_ms": score_ms,
+            "score_phase_ms_cold": score_cold_ms,
+            "score_phases_ms": score_phases,
+            "score_phases_ms_cold": score_phases_cold,
             "input_generation_s": gen_s,
         },
     }
+    # e2e: what the product delivers when the inputs are NOT yet resident (never `value`)
+    if upload_step_ms or cli_e2e:
+        e2e = {"note": "inputs not resident: never `value`"}
+        if upload_step_ms:
+            e2e["upload_in_step_ms"] = upload_step_ms
+            e2e["upload_in_step_quartets_per_s"] = (m * nq) / (upload_step_ms * 1e-3)
+            e2e["host_batch_bytes"] = int(batch.leaf_ids.nbytes + batch.adj_depth.nbytes + batch.leaf_off.nbytes)
+        if cli_e2e:
+            e2e["cli"] = cli_e2e
+            if cli_e2e.get("counting_phase_ms"):
+                e2e["cli_counting_quartets_per_s"] = m * nq_all / (cli_e2e["counting_phase_ms"] * 1e-3)
+        out["e2e"] = e2e
     kname = ("count_bitslice3_kernel" if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel"
     hbm_ratio = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     table_bytes = ctx.table_bytes
@@ -643,16 +736,15 @@ def main():
         achieved = units_per_launch * ops32 / 32.0 / (launch_ms * 1e-3) / 1e12
         roof = {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLOPS,
                 "algorithmic_ops_per_unit": ops32 / 32.0,
-                "algorithmic_ops_note": f"{ops32:.3f} wave-instructions per (quartet, 32 trees): the minimal chain of the bit-sliced four-point test, 2(B+1)+2 at B depth bits for binary trees, averaged over the batch's depth classes {classes} (bits, trees), mode {mode} (DESIGN.md 3.1); instructions really issued: see `issued`"}
+                "algorithmic_ops_note": f"{ops32:.3f} wave-instr per (quartet, 32 trees): 2(B+1)+2, classes {classes}"[:100]}
     else:                                   # scatter / SWAR paths: priced against HBM with SURVEY 8(d)'s bytes
         achieved = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     roof.update({"traffic": None, "kernel": kname, "units_per_launch": units_per_launch, "avg_launch_ms": launch_ms,
                  "launches_per_step": launches, "hbm_algorithmic_ratio": hbm_ratio,
-                 "hbm_algorithmic_note": "SURVEY 8(d): 2 x sizeof(counter) per (tree, quartet) / kernel time / 8 TB/s = speed-up over a perfect "
-                                         "scatter implementation of the reference's RMW loop; not a fraction (the gather kernel does not perform those RMWs)",
+                 "hbm_algorithmic_note": "SURVEY 8(d) RMW bytes / time / 8 TB/s: speed-up over a perfect scatter, not a fraction",
                  "hbm_model_bytes_per_step": (table_bytes * (2 * launches - 1) + 2 * panel_bytes) if panel_bytes else None,
-                 "hbm_model_note": "gather formulation's own minimum per step: table written once by the first slice and read+written by each later one, panel written and read once",
+                 "hbm_model_note": "gather minimum: table 1 write + (launches-1) RMW, panel written+read once",
                  "issued": None})
     pmc = pmc_for(workload_key, variant)
     if pmc:
@@ -665,7 +757,7 @@ def main():
                               "minimal_share": units_per_launch * ops32 / 32.0 / 64.0 / pmc["valu_insts_per_launch"] if ops32 else None}
         roof["pmc_source"] = {k_: pmc.get(k_) for k_ in ("file", "collected", "kernel_source_sha", "fetch_size_kb", "write_size_kb", "l2_hit")}
     else:
-        roof["pmc_source"] = f"no PMC summary under profiles/ matches workload_key={workload_key}, variant={variant}, kernel source {kernel_source_sha()}"
+        roof["pmc_source"] = f"none under profiles/ for kernel source {kernel_source_sha()}"
     out["roofline"] = roof
 
     if cpu_baseline is not None:                     # reported at N=1 only

@@ -24,8 +24,15 @@
  * (QS_OK == 0) and never throws; qs_last_error() gives the message. The caller owns
  * all host buffers and lends them for the duration of a call; the library owns device
  * memory except a table attached with qs_table_attach(). One context drives one GPU
- * from one host thread; multi-GPU = one process (context) per GPU with the table
- * all-reduced by the caller (RCCL through torch.distributed).
+ * from one host thread. Multi-GPU = one context per GPU; the library never calls a
+ * collective itself. Tree-sharded: every context counts its share of the trees into a
+ * private table and the CALLER combines the tables with one RCCL reduce-scatter or
+ * all-reduce -- csrc/host/multi_gpu.hpp (one process, RCCL's C API: `QuartetScores
+ * --gpus N`) or quartetscores_amd/distributed.py (one process per GPU, torch.distributed)
+ * -- then scores its part in steps (qs_score_set_view, qs_score_pass1/2, qs_score_finish).
+ * Table-sharded: contexts created with [d_lo, d_hi) own disjoint rank ranges, every context
+ * counts all trees, no table collective; only the per-node-pair accumulators of the score
+ * passes are combined (`QuartetScores --gpus N --table-shards K`). See INTEGRATION.md.
  * There is NO CPU fallback: every entry point that computes needs a gfx950 device.
  *
  * Data model. Taxa have lookup ids 0..n-1 = the reference
@@ -160,6 +167,9 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_SCORE_CAND_SLOTS 5u   /* candidate slots score pass 2 fills per node pair, 1..8 (default 8; tests force overflows) */
 #define QS_TUNE_SCORE_KERNEL 7u       /* score passes 1 and 2: 0 = bundle kernel (default; a wave walks 64 table rows with the same second id in lockstep), 1 = scan kernel (a lane walks 8 consecutive ranks; A/B and tests) */
 #define QS_TUNE_SCORE_TOL_EXP 6u      /* pass 2 keeps count triples whose device QIC is within 10^-value of the pair's minimum (default 12) */
+#define QS_TUNE_TABLE_TREES 8u        /* number of trees behind a table this context did not count itself (reduced over GPUs, uploaded,
+                                       * attached or viewed): sizes the log table of the device QIC so that every count takes the
+                                       * table path (speed only; scores never depend on it). 0 = what the context counted (default) */
 #define QS_IMPL_AUTO 0u
 #define QS_IMPL_SWAR 1u
 #define QS_IMPL_BITSLICE 2u
@@ -297,6 +307,11 @@ int qs_raw_qic_lex(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t i0, uint64_t nq
  * qs_last_count_launches: how many count-kernel launches [1] covers (0 if the call was not timed). */
 int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 int qs_last_count_launches(const qs_ctx *ctx);
+/* Phases of the most recent qs_score call in milliseconds: [0] the whole call (host clock), [1] set-up (accumulator
+ * allocation, reference tree + LCA matrix, log table: near zero once cached in the context), [2] pass 1 and [3] pass 2
+ * (HIP events on the context's stream), [4] host wait for the passes incl. the overflow pass and the accumulators' way
+ * back, [5] qs_score_finish (host libm + min-propagation; QuartetScoreComputer.hpp:448-454,484-489). */
+int qs_last_score_ms(qs_ctx *ctx, float out_ms[6]);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);
 /* How score passes 1 and 2 decompose the tuples [rank_lo, rank_lo + n_tuples) of an n_taxa table (host arithmetic only,

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +61,7 @@ struct qs_ctx {
     uint32_t *perm[2] = {nullptr, nullptr};
     bool perm_built[2] = {false, false};
     uint32_t tile_chunk = 4, tile_cblock = 16;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major
+    uint32_t tile_cgroup = 0;                          // > 1: c innermost in groups of this many (the waves of a workgroup share M[ab], M[bd])
     std::vector<uint32_t> h_cp3, h_dp3, h_cp, h_dp1t;  // host copies of the prefix arrays
     uint32_t *dprefix1t = nullptr;                     // the same kernel on general / partial batches: 8x8 tiles (cprefix), d-blocks counted down
     uint32_t total_tiles1t = 0;
@@ -104,9 +106,13 @@ struct qs_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};   // recorded after the last copy out of the buffer
     unsigned pin_next = 0;
     std::vector<BatchSlab> slabs;                // device slabs of freed batches, for the next uploads
+    // qs_last_score_ms: phases of the last qs_score call (host clock, passes 1 / 2 by HIP events on the stream)
+    float score_ms[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t score_ev[3] = {nullptr, nullptr, nullptr};
+    uint64_t table_trees_hint = 0;               // QS_TUNE_TABLE_TREES: trees behind an attached / uploaded / viewed table
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;   // per thread: qs_create of several contexts may run concurrently (multi_gpu.hpp)
 // Tree groups (panel elements along the tree axis) per sub-batch of a batch of n_total groups.
 // A batch is counted slice by slice: panel build + count kernel per slice, the first slice stores into the table, the
 // others read-modify-write it. qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES) fixes the slice size in bytes (tests, sweeps).
@@ -196,9 +202,18 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
             for (uint32_t cb = c_lo; cb <= cmax; cb += cblock)
                 for (uint32_t k = 0; k < n_dblk; ++k) {
                     const uint32_t d1 = d_hi - k * kDB;
-                    for (uint32_t cc = cb; cc < cb + cblock && cc + 1 < d1; ++cc) {
-                        const uint32_t id = dp[k] + cp[cc] + base;
-                        for (uint32_t j = j0; j < j1; ++j) perm.push_back(id + j);
+                    if (c->tile_cgroup <= 1) {
+                        for (uint32_t cc = cb; cc < cb + cblock && cc + 1 < d1; ++cc) {
+                            const uint32_t id = dp[k] + cp[cc] + base;
+                            for (uint32_t j = j0; j < j1; ++j) perm.push_back(id + j);
+                        }
+                    } else {
+                        // c innermost in groups of `cgroup`: the waves of a workgroup (consecutive slots) then hold the SAME
+                        // (a-blocks, b-block, d-block) and consecutive c -- their M[ab] and M[bd] elements are identical
+                        for (uint32_t c4 = cb; c4 < cb + cblock && c4 + 1 < d1; c4 += c->tile_cgroup)
+                            for (uint32_t j = j0; j < j1; ++j)
+                                for (uint32_t cc = c4; cc < c4 + c->tile_cgroup && cc < cb + cblock && cc + 1 < d1; ++cc)
+                                    perm.push_back(dp[k] + cp[cc] + base + j);
                     }
                 }
         }
@@ -212,6 +227,13 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
             }
         }
     if (perm.size() != total) return fail(c, QS_ERR_STATE, "tile order: enumeration does not match the tiling");
+    {   // every tile exactly once: a tile listed twice would be counted by two waves (a race on its tuples), one left out never
+        std::vector<uint8_t> seen(total, 0);
+        for (uint32_t id : perm) {
+            if (id >= total || seen[id]) return fail(c, QS_ERR_STATE, "tile order: launch permutation is not a bijection");
+            seen[id] = 1;
+        }
+    }
     if (hipMalloc(&c->perm[which], perm.size() * 4) != hipSuccess) return fail(c, QS_ERR_OOM, "hipMalloc tile order");
     if (hipMemcpyAsync(c->perm[which], perm.data(), perm.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, QS_ERR_HIP, "memcpy tile order");
@@ -235,9 +257,10 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             QS_HIP(c, hipSetDevice(c->device));
             QS_HIP(c, hipStreamSynchronize(c->stream));
             for (int w = 0; w < 2; ++w) { if (c->perm[w]) (void)hipFree(c->perm[w]); c->perm[w] = nullptr; c->perm_built[w] = false; }
-            c->tile_chunk = (uint32_t)(value & 0xFFFF); c->tile_cblock = (uint32_t)(value >> 16);
+            c->tile_chunk = (uint32_t)(value & 0xFFFF); c->tile_cblock = (uint32_t)((value >> 16) & 0xFFFF); c->tile_cgroup = (uint32_t)((value >> 32) & 0xFF);
             return QS_OK;
         case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
+        case QS_TUNE_TABLE_TREES: c->table_trees_hint = value; return QS_OK;
         case QS_TUNE_GATHER_IMPL:
             if (value > QS_IMPL_BITSLICE) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_GATHER_IMPL takes QS_IMPL_AUTO / _SWAR / _BITSLICE");
             c->tune_gather_impl = (uint32_t)value; return QS_OK;
@@ -337,6 +360,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     for (int w = 0; w < 2; ++w) { if (c->pin_ev[w]) { (void)hipEventSynchronize(c->pin_ev[w]); (void)hipEventDestroy(c->pin_ev[w]); } if (c->pin[w]) (void)hipHostFree(c->pin[w]); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (BatchSlab &sl : c->slabs) { (void)hipFree(sl.p); if (sl.last_use) (void)hipEventDestroy(sl.last_use); }
+    for (hipEvent_t e : c->score_ev) if (e) (void)hipEventDestroy(e);
     delete c->ref_cache;
     delete c;
 }
@@ -1070,7 +1094,9 @@ struct DevPtr { // RAII for a hipMalloc'ed pointer
 // number of trees counted. Unknown (uploaded / attached tables, reduce-scattered shards): 65536 entries, larger
 // values take the kernel's slow path.
 static int ensure_score_tables(qs_ctx *c) {
-    const uint64_t want64 = std::min<uint64_t>(std::max<uint64_t>(c->trees_counted + 1, 65536), 1ull << 20);
+    // every count and every tuple sum is at most the number of trees behind the table: what this context counted, or what
+    // the caller says stands behind a reduced / uploaded / viewed table (QS_TUNE_TABLE_TREES)
+    const uint64_t want64 = std::min<uint64_t>(std::max<uint64_t>(std::max(c->trees_counted, c->table_trees_hint) + 1, 65536), 1ull << 20);
     const uint32_t want = (uint32_t)want64;
     if (c->tbl_n >= want) return QS_OK;
     if (c->dev_logk) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dev_logk); c->dev_logk = nullptr; c->tbl_n = 0; }
@@ -1393,24 +1419,59 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     const size_t np = (size_t)qs_score_pair_slots(ref);
     if (np == 0) return fail(c, QS_ERR_ARG, "qs_score: bad reference tree");
     QS_HIP(c, hipSetDevice(c->device));
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
+    const clk::time_point t_all = clk::now();
+    for (hipEvent_t &e : c->score_ev) if (!e) QS_HIP(c, hipEventCreate(&e));
+    for (float &x : c->score_ms) x = 0;
     DevPtr sums, mn, cand;
     QS_HIP(c, hipMalloc(&sums.p, np * 3 * 8));
     QS_HIP(c, hipMalloc(&mn.p, np * 8));
     QS_HIP(c, hipMalloc(&cand.p, np * kCand * 8));
+    {   // the cached pieces both passes need (reference tree + LCA matrix, log table, bundle plans): built here so that
+        // the first call's set-up cost shows as its own phase and the events below bracket kernels only
+        const RefHost *Rp = nullptr;
+        int rc0 = get_ref(c, ref, true, &Rp);
+        if (rc0 != QS_OK) return rc0;
+        rc0 = ensure_score_tables(c);
+        if (rc0 != QS_OK) return rc0;
+    }
+    c->score_ms[1] = ms_since(t_all);
+    QS_HIP(c, hipEventRecord(c->score_ev[0], c->stream));
     int rc = qs_score_pass1(c, ref, (int64_t *)sums.p, (int64_t *)mn.p);
     if (rc != QS_OK) return rc;
+    QS_HIP(c, hipEventRecord(c->score_ev[1], c->stream));
     rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);
     if (rc != QS_OK) return rc;
+    QS_HIP(c, hipEventRecord(c->score_ev[2], c->stream));
+    const clk::time_point t_ov = clk::now();
     int64_t *extra = nullptr;
     uint64_t n_extra = 0;
-    rc = qs_score_overflow(c, ref, (const int64_t *)mn.p, (const int64_t *)cand.p, &extra, &n_extra);
+    rc = qs_score_overflow(c, ref, (const int64_t *)mn.p, (const int64_t *)cand.p, &extra, &n_extra);   // synchronises the stream
     if (rc != QS_OK) return rc;
     struct FreeHost { int64_t *p; ~FreeHost() { free(p); } } free_extra{extra};
     std::vector<int64_t> hs(np * 3), hc(np * kCand);
     QS_HIP(c, hipMemcpyAsync(hs.data(), sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
     QS_HIP(c, hipMemcpyAsync(hc.data(), cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
     QS_HIP(c, hipStreamSynchronize(c->stream));
-    return qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, extra, n_extra, lqic, qpic, eqpic, is_bifurcating);
+    (void)hipEventElapsedTime(&c->score_ms[2], c->score_ev[0], c->score_ev[1]);
+    (void)hipEventElapsedTime(&c->score_ms[3], c->score_ev[1], c->score_ev[2]);
+    c->score_ms[4] = ms_since(t_ov);            // waiting for the passes + overflow pass (if any) + the accumulators' way back
+    const clk::time_point t_fin = clk::now();
+    rc = qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, extra, n_extra, lqic, qpic, eqpic, is_bifurcating);
+    c->score_ms[5] = ms_since(t_fin);
+    c->score_ms[0] = ms_since(t_all);
+    return rc;
+}
+
+// Phases of the last qs_score call in ms: [0] whole call (host clock), [1] set-up (accumulator allocation, reference tree
+// + LCA matrix, log table; near zero once cached), [2] pass 1 and [3] pass 2 (HIP events on the context's stream: kernels
+// + the bundle plan of a first call), [4] host wait for the passes incl. overflow pass and device-to-host copies,
+// [5] qs_score_finish (host libm + min-propagation).
+extern "C" int qs_last_score_ms(qs_ctx *c, float out_ms[6]) {
+    if (!c || !out_ms) return QS_ERR_ARG;
+    for (int i = 0; i < 6; ++i) out_ms[i] = c->score_ms[i];
+    return QS_OK;
 }
 
 static int raw_qic_impl(qs_ctx *c, const qs_ref_tree *ref, uint64_t r0, uint64_t nq, uint8_t *topo, uint64_t *q, bool lex) {

@@ -728,7 +728,10 @@ template <int HW> __device__ __forceinline__ void lds_store_hw(uint4 *buf, uint3
     else if (HW == 2) reinterpret_cast<uint2 *>(buf + stride)[e] = make_uint2(r.w[4], r.w[5]);
     else buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
 }
-// x - y + 2^B over B planes -> B+1 planes (unsigned, bias 2^B); word 7 = presence(x) & presence(y)
+// x - y + 2^B over B planes -> B+1 planes (unsigned, bias 2^B); word 7 = presence(x) & presence(y). The top plane is kept
+// INVERTED (it holds the final borrow, 1 <=> x < y, instead of its complement): every consumer compares two such numbers,
+// and [~p > ~q] = [p < q], so the comparisons swap their truth tables at the top plane (cmp_planes / gt_planes) and the
+// v_not_b32 per difference is gone (3 of ~270 VALU instructions of a 32-tree step).
 template <int B>
 __device__ __forceinline__ Planes sub_biased(const Planes &x, const Planes &y) {
     Planes r;
@@ -739,33 +742,36 @@ __device__ __forceinline__ Planes sub_biased(const Planes &x, const Planes &y) {
         r.w[k] = lut3<kTT_XOR3>(a, b, br);
         br = lut3<kTT_LT>(a, b, br);
     }
-    r.w[B] = ~br;
+    r.w[B] = br;
 #pragma unroll
     for (int k = B + 1; k < 7; ++k) r.w[k] = 0;
     if (B < 7) r.w[7] = x.w[7] & y.w[7];
     return r;
 }
 
-// [l > r] and [l < r] for NB-bit unsigned numbers in planes, 32 trees at once
+// [l > r] and [l < r] for two results of sub_biased (NB = B+1 planes, the top one inverted), 32 trees at once
 template <int NB>
 __device__ __forceinline__ void cmp_planes(const Planes &l, const Planes &r, uint32_t &gt, uint32_t &lt) {
     gt = 0; lt = 0;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
+    for (int k = 0; k < NB - 1; ++k) {
         const uint32_t a = l.w[k], b = r.w[k];
         gt = lut3<kTT_GT>(a, b, gt);
         lt = lut3<kTT_LT>(a, b, lt);
     }
+    const uint32_t a = l.w[NB - 1], b = r.w[NB - 1];   // inverted planes: the roles of the two tables swap
+    gt = lut3<kTT_LT>(a, b, gt);
+    lt = lut3<kTT_GT>(a, b, lt);
 }
 template <int NB>
 __device__ __forceinline__ uint32_t gt_planes(const Planes &l, const Planes &r) {
     uint32_t gt = 0;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
+    for (int k = 0; k < NB - 1; ++k) {
         const uint32_t a = l.w[k], b = r.w[k];
         gt = lut3<kTT_GT>(a, b, gt);
     }
-    return gt;
+    return lut3<kTT_LT>(l.w[NB - 1], r.w[NB - 1], gt);
 }
 
 // ======================================================================================
@@ -829,6 +835,22 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
+#ifndef QS_EXP
+#define QS_EXP 0
+#endif
+#if QS_EXP & 32
+// diagnostic build only (tools/: make exp EXP=33): s_memtime stamps around the step's barrier and around a full drain of
+// the step's panel loads, summed over all waves: [0] waves, [1] cycles in the group loop, [2] at the barrier, [3] in the drain
+__device__ unsigned long long qs_dbg_stamps[8];
+__device__ __forceinline__ unsigned long long qs_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
 // one table tuple = three cells: moved with ONE 12-byte access for u32 cells (global_load/store_dwordx3; a tuple
 // is 4-byte aligned) instead of three 4-byte ones -- the epilogue of a wave is 16 tuples per lane
 template <typename CT> struct Tuple3 { uint32_t a, b, c; };
@@ -845,8 +867,11 @@ template <typename CT> __device__ __forceinline__ void store_tuple(CT *p, uint32
     else { p[0] = (CT)a; p[1] = (CT)b; p[2] = (CT)c; }
 }
 
+// waves per SIMD the register allocation aims at: 4 (<= 128 VGPRs); the two instances that do not fit without spilling
+// (7 depth bits, binary: 8-plane operands in two a-columns; 4 bits, general) take 3 -- a spill means scratch memory
+template <int B, int MODE> constexpr int bs3_waves() { return ((B == 7 && MODE == MODE_BINARY_FULL) || (B == 4 && MODE == MODE_GENERAL_FULL)) ? 3 : QS_BS3_WAVES; }
 template <int B, int MODE, typename CT>
-__global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
+__global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(bs3_waves<B, MODE>(), bs3_waves<B, MODE>()))) void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees,
                                                                         uint32_t d_start, uint32_t d_hi, uint64_t rank_lo,
                                                                         uint32_t n_dblk, uint32_t total_tiles,
@@ -866,6 +891,10 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     static_assert(!PART || B <= 6, "partial batches carry at most 6 depth bits");
     constexpr int kImg = kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
     __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
+#ifdef QS_LDS_PAD   // occupancy experiments: bytes of LDS nobody uses, so that fewer workgroups fit on a CU
+    __shared__ uint4 lds_pad[QS_LDS_PAD / 16];
+    if (n_groups == 0xFFFFFFFFu) lds_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);
+#endif
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -965,7 +994,8 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
 
     auto rsrc_of = [&](uint32_t g) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (int)group_bytes, 0x00020000);
+        // QS_EXP & 16 (timing-only knock-out): zero records -> every panel load returns zeros without touching memory
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (QS_EXP & 16) ? 0 : (int)group_bytes, 0x00020000);
     };
     // compact panel element -> planes in w[0..B-1], presence (partial) in w[7]
     auto gload = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff) {
@@ -993,6 +1023,9 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         return lload(buf, kS3Row0 + col);
     };
     struct Staged { Planes x0, x1, y, row; };
+#if QS_EXP & 32
+    unsigned long long dbg_bar = 0, dbg_vm = 0;
+#endif
 
     // one 32-tree step: request group g_next into (st, abn1, abn2), count group g from (cur, abc1, abc2), then
     // turn the requested elements into the LDS image `nxt`
@@ -1006,7 +1039,13 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         // instead of becoming separate requests to the L2, whose number bounds the kernel together with VALU issue
         // (profiles/r02_experiments.md): -5 % at 512 taxa, -9 % with NNI trees, -5 % on a 1024-taxon shard, -1 % at 256;
         // at 128 taxa and below (the panel sits in the L2 anyway) it costs 4-6 %, so the launcher sets bit 1 from 200 on.
-        if (xcd_remap & 2u) __builtin_amdgcn_s_barrier();
+#if QS_EXP & 32
+        const unsigned long long tb0 = qs_stamp();
+#endif
+        if ((xcd_remap & 2u) && !(QS_EXP & 2)) __builtin_amdgcn_s_barrier();
+#if QS_EXP & 32
+        dbg_bar += qs_stamp() - tb0;
+#endif
         Staged st;
         st.x0 = gload(r, x0off);
         st.y = gload(r, yoff);
@@ -1047,6 +1086,13 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
                 }
             }
         }
+#if QS_EXP & 32
+        {
+            const unsigned long long tv0 = qs_stamp();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_vm += qs_stamp() - tv0;
+        }
+#endif
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
         if (TWO) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
         if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
@@ -1069,14 +1115,22 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
             if (A2) abA2 = gload(r, ab2off);
         }
         const uint32_t g_last = n_groups - 1;
-        for (uint32_t g = 0; g < n_groups; g += 2) {
-            // the request past the last group re-reads the last one (its image is never used)
-            step(min(g + 1, g_last), buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, two_tag);
-            if (g + 1 < n_groups) step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, two_tag);
+        // Both steps of a trip are unconditional and the odd last group is peeled: with the second step under
+        // `if (g + 1 < n_groups)` LLVM sinks the first step's M[ab] loads (used only by the second) into that branch,
+        // i.e. behind the whole compute of the first step and directly in front of their first use -- one exposed L2
+        // round trip per two steps, taken by all waves of a SIMD at about the same time.
+        uint32_t g = 0;
+        for (; g + 2 <= n_groups; g += 2) {
+            step(g + 1, buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, two_tag);
+            step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, two_tag); // past the end: re-reads the last group (unused)
         }
+        if (g < n_groups) step(g_last, buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, two_tag);
     };
     using T_ = std::true_type; using F_ = std::false_type;
     const bool full = jlo == 0 && jhi == (uint32_t)kDB;
+#if QS_EXP & 32
+    const unsigned long long tl0 = qs_stamp();
+#endif
     if (BIN) {
         if (has_a2) { if (full) run(T_{}, T_{}, F_{}); else run(T_{}, F_{}, F_{}); }
         else if (offdiag) run(F_{}, F_{}, F_{});
@@ -1084,6 +1138,14 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
     } else {
         if (full) run(F_{}, T_{}, T_{}); else run(F_{}, F_{}, T_{});
     }
+#if QS_EXP & 32
+    if (lane == 0) {
+        atomicAdd(&qs_dbg_stamps[0], 1ull);
+        atomicAdd(&qs_dbg_stamps[1], qs_stamp() - tl0);
+        atomicAdd(&qs_dbg_stamps[2], dbg_bar);
+        atomicAdd(&qs_dbg_stamps[3], dbg_vm);
+    }
+#endif
 
     // rank of {a,b,c,d} = C(d,4) + C(c,3) + C(b,2) + a; along the d slots C(d+1,4) = C(d,4) + C(d,3) etc., so the
     // 64-bit products and divisions are done once per wave instead of once per slot
@@ -1136,6 +1198,14 @@ __global__ __launch_bounds__(kCountThreads) QS_BS3_OCC void count_bitslice3_kern
         }
     }
 }
+
+#if QS_EXP & 32
+extern "C" int qs_debug_stamps(unsigned long long out[8]) {   // read and reset (diagnostic builds only)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qs_dbg_stamps), 64) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(qs_dbg_stamps), z, 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,

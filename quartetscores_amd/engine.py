@@ -168,6 +168,13 @@ class Context:
         self._chk(self.L.qs_last_count_ms(self.h, C.byref(out)))
         return tuple(float(x) for x in out)
 
+    def last_score_ms(self) -> dict:
+        """qs_last_score_ms: phases of the most recent score() in ms."""
+        out = (C.c_float * 6)()
+        self._chk(self.L.qs_last_score_ms(self.h, C.byref(out)))
+        keys = ("total", "setup", "pass1", "pass2", "wait_overflow_d2h", "host_finish")
+        return {k: float(v) for k, v in zip(keys, out)}
+
     def last_count_launches(self) -> int:
         return int(self.L.qs_last_count_launches(self.h))
 
