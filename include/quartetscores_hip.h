@@ -170,10 +170,18 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_TABLE_TREES 8u        /* number of trees behind a table this context did not count itself (reduced over GPUs, uploaded,
                                        * attached or viewed): sizes the log table of the device QIC so that every count takes the
                                        * table path (speed only; scores never depend on it). 0 = what the context counted (default) */
+#define QS_TUNE_COOP 9u               /* binary full batches: 1 = run the tiles with two a-blocks through count_bitslice4_kernel, whose
+                                       * workgroups (four consecutive third ids of one (a,b,d) tile) share their panel loads through
+                                       * LDS; 0 / 2 = off (default: the barrier it needs costs more than the loads it saves) */
 #define QS_IMPL_AUTO 0u
 #define QS_IMPL_SWAR 1u
 #define QS_IMPL_BITSLICE 2u
 int qs_set_tuning(qs_ctx *ctx, uint32_t key, uint64_t value);
+/* Optional: do ahead of time what the first qs_count_batch does before its first launch -- the launch order of the
+ * count kernel's tiles for binary batches and the pair-depth panel for a batch of n_trees_hint trees (0 = no panel) --
+ * e.g. on the host's GPU-initialisation thread while the evaluation trees are still being parsed. The reference does
+ * its set-up in the table's constructor (QuartetCounterLookup.hpp:245-273). Never required. */
+int qs_prepare(qs_ctx *ctx, uint64_t n_trees_hint);
 const char *qs_version(void);
 
 /* ---- count table (QuartetLookupTable) ------------------------------------------------- */

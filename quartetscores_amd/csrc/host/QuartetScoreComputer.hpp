@@ -60,12 +60,22 @@ inline size_t countEvalTrees(const std::string &evalTreesPath) { return loadEval
 struct DeviceOptions {
     int device = 0;
     uint32_t algo = QS_ALGO_AUTO;
-    size_t batch_trees = 8192;   // trees per device batch
+    size_t batch_trees = 16384;  // trees per device batch: one batch = one set of panel slices (a smaller batch means more launches,
+                                 // each of which reads and writes the whole table); the next batch is parsed while this one counts
     unsigned ingest_threads = 0; // host threads that parse + flatten (0 = hardware concurrency); the CLI's -t
     bool qp_exact64 = false;
     bool root_as_edge = false;   // QS_SCORE_ROOT_AS_EDGE: a degree-2 root as a subdivision of one edge (not the reference's quirk Q5)
     std::string load_table, save_table; // count-table persistence
+    bool trace = false;          // --trace: time stamps of the counting pipeline on stderr
 };
+
+// --trace: "[trace] +12.3 ms  what" relative to the first call (process start for practical purposes)
+inline void trace_mark(const DeviceOptions &opt, const char *what) {
+    if (!opt.trace) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "[trace] +%8.1f ms  %s\n", ms, what);
+}
 
 template <typename CINT> class QuartetCounterLookup {
 public:
@@ -78,10 +88,16 @@ public:
         // file and flattens the first batch
         int rc_create = QS_OK, rc_alloc = QS_OK;
         std::string create_err;
+        trace_mark(opt, "counter: start (GPU set-up thread + first batch on the host threads)");
         std::thread gpu_init([&] {
             rc_create = qs_create(&ctx_, (uint32_t)ref_.names.size(), bits, QS_FLAG_NONE, opt.device, nullptr, 0, 0);
             if (rc_create != QS_OK) { create_err = qs_last_error(nullptr); return; }
+            trace_mark(opt, "gpu thread: context created (HIP initialised)");
             rc_alloc = qs_table_alloc(ctx_);
+            trace_mark(opt, "gpu thread: table allocated");
+            // launch order of the count kernel + panel: otherwise built by the first qs_count_batch, in front of its first launch
+            if (rc_alloc == QS_OK && opt.load_table.empty() && (opt.algo & 0xFFu) != QS_ALGO_SCATTER) (void)qs_prepare(ctx_, std::min<uint64_t>(m, opt.batch_trees));
+            trace_mark(opt, "gpu thread: launch order + panel ready");
         });
         std::shared_ptr<const EvalFile> ef;
         BatchFlat first;
@@ -91,6 +107,7 @@ public:
             if (counting) {
                 ef = loadEvalFile(evalTreesPath);
                 first = flatten_batch(*ef, 0, opt);
+                trace_mark(opt, "host: first batch flattened");
             }
         } catch (...) { host_err = std::current_exception(); }
         gpu_init.join();
@@ -172,12 +189,14 @@ private:
                 if (qs_batch_upload(ctx_, &hb, &db) != QS_OK) fail();
                 in_flight.push_back(db);
                 if (qs_count_batch(ctx_, db, opt.algo) != QS_OK) fail(); // asynchronous
+                trace_mark(opt, "host: batch uploaded, count enqueued");
                 while ((float)i1 > progress * onePercent && progress <= 100) { // QCL:230-233
                     std::cout << "Counting quartets... " << progress << "%" << std::endl;
                     progress++;
                 }
             }
             if (qs_sync(ctx_) != QS_OK) fail();
+            trace_mark(opt, "host: all counts done (device synchronised)");
         } catch (...) {
             (void)qs_sync(ctx_);
             for (auto *db : in_flight) qs_batch_free(ctx_, db);

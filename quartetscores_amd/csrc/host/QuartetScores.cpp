@@ -49,10 +49,14 @@ void usage(std::ostream &os) {
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
           "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
+          "   --trace        time stamps of the counting pipeline on stderr\n"
           "   --root-as-edge rooted reference tree: score the two root edges as one internode (the reference's\n"
           "                  own handling of a degree-2 root is the default)\n"
-          "   --table-shards K  a count table larger than the device's memory: K shards by largest taxon id pass through the\n"
-          "                  GPU one after the other (0 = as many as the free device memory asks for)\n"
+          "   --table-shards K  the count table in K shards by largest taxon id (0 = as many as the free device memory asks for):\n"
+          "                  alone: a table larger than the device's memory passes through ONE GPU shard by shard;\n"
+          "                  with --gpus N: shard s lives on GPU s mod N, every GPU counts all trees into its shard(s), no\n"
+          "                  table collective (1024 taxa, 273 GB: --gpus 8 --table-shards 8). --gpus N alone switches to this\n"
+          "                  mode by itself when the table does not fit one GPU\n"
           "   --spill M      with --table-shards: host (keep finished shards in host memory) | recount (count every shard a\n"
           "                  second time for the second scoring pass) | auto (host if it fits MemAvailable; default)\n"
           "   --save-table F write the count table to F after counting\n"
@@ -109,6 +113,7 @@ int parse(int argc, char **argv, Args &a) {
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
         else if (f == "--root-as-edge") a.dev.root_as_edge = true;
+        else if (f == "--trace") a.dev.trace = true;
         else if (f == "--qic-rank-order") a.raw_rank_order = true;
         else if (f == "--save-table") { if (!(v = need(i, "--save-table"))) return 1; a.dev.save_table = v; }
         else if (f == "--qic-binary") { if (!(v = need(i, "--qic-binary"))) return 1; a.raw_bin = v; }
@@ -133,27 +138,36 @@ void run_multi(const Tree &referenceTree, const Args &a, size_t m, uint32_t coun
     if (!a.raw_bin.empty()) print_raw_qic_binary(mg.context0(), mg.reference(), referenceTree, a.raw_bin);
 }
 
-// --table-shards K: the table passes through one GPU shard by shard (table_shards.hpp)
-void run_sharded(const Tree &referenceTree, const Args &a, size_t m, uint32_t count_bits, int shards, std::vector<double> &lqic,
+// --table-shards K [--gpus N]: the table cut into K shards by the largest taxon id, shard s on GPU s mod N; every GPU counts
+// all trees into its shard(s), no table collective (table_shards.hpp; BASELINE configs[4] = --gpus 8 --table-shards 8)
+void run_sharded(const Tree &referenceTree, const Args &a, size_t m, uint32_t count_bits, int shards, int gpus, std::vector<double> &lqic,
                  std::vector<double> &qpic, std::vector<double> &eqpic) {
     if (!a.dev.load_table.empty() || !a.dev.save_table.empty() || !a.raw.empty() || !a.raw_bin.empty())
-        throw std::runtime_error("--table-shards: -q / --qic-binary / --save-table / --load-table need the whole table on the device");
-    ShardedTableQuartetScoreComputer st(referenceTree, a.eval, m, count_bits, shards, (ShardedTableQuartetScoreComputer::Spill)a.spill, a.dev);
+        throw std::runtime_error("--table-shards: -q / --qic-binary / --save-table / --load-table need the whole table on one device");
+    ShardedTableQuartetScoreComputer st(referenceTree, a.eval, m, count_bits, shards, (ShardedTableQuartetScoreComputer::Spill)a.spill, a.dev, gpus);
     lqic = st.scores.lq; qpic = st.scores.qp; eqpic = st.scores.eqp;
 }
 
 template <typename CINT>
 void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double> &lqic, std::vector<double> &qpic,
          std::vector<double> &eqpic) {
-    if (a.gpus > 0) return run_multi(referenceTree, a, m, sizeof(CINT) <= 2 ? 16u : 32u, lqic, qpic, eqpic);
-    if (a.table_shards >= 0) {
-        const uint32_t bits = sizeof(CINT) <= 2 ? 16u : 32u;
-        size_t n = 0;
-        for (size_t v = 0; v < referenceTree.node_count(); ++v) n += referenceTree.is_leaf(v);
-        const uint64_t bytes = (uint64_t)n * (n - 1) * (n - 2) * (n - 3) / 24 * 3 * (bits / 8);
-        const int shards = a.table_shards > 0 ? a.table_shards : ShardedTableQuartetScoreComputer::shards_needed(bytes, a.dev.device);
-        if (a.table_shards > 0 || shards > 1) return run_sharded(referenceTree, a, m, bits, shards, lqic, qpic, eqpic);
+    const uint32_t bits = sizeof(CINT) <= 2 ? 16u : 32u;
+    size_t n = 0;
+    for (size_t v = 0; v < referenceTree.node_count(); ++v) n += referenceTree.is_leaf(v);
+    const uint64_t bytes = (uint64_t)n * (n - 1) * (n - 2) * (n - 3) / 24 * 3 * (bits / 8);
+    const int gpus = std::max(1, a.gpus);
+    if (a.table_shards >= 0 || a.gpus > 0) {
+        // shards one device's free memory asks for (0 / unset = automatic); with --gpus N at least one shard per GPU
+        const int needed = ShardedTableQuartetScoreComputer::shards_needed(bytes, a.dev.device);
+        if (a.table_shards > 0) return run_sharded(referenceTree, a, m, bits, a.table_shards, gpus, lqic, qpic, eqpic);
+        if (needed > 1) {
+            if (a.gpus > 0 && a.table_shards < 0)
+                std::cout << "The count table (" << bytes << " bytes) does not fit one GPU: table-sharded mode instead of tree-sharded.\n";
+            return run_sharded(referenceTree, a, m, bits, std::max(needed, gpus), gpus, lqic, qpic, eqpic);
+        }
+        if (a.gpus > 0 && a.table_shards == 0) return run_sharded(referenceTree, a, m, bits, gpus, gpus, lqic, qpic, eqpic);
     }
+    if (a.gpus > 0) return run_multi(referenceTree, a, m, bits, lqic, qpic, eqpic);
     QuartetScoreComputer<CINT> qsc(referenceTree, a.eval, m, a.verbose, a.savemem, a.dev);
     lqic = qsc.getLQICScores();
     qpic = qsc.getQPICScores();
@@ -179,6 +193,11 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     a.dev.ingest_threads = (unsigned)a.threads;
+    trace_mark(a.dev, "main: arguments parsed");
+    // HIP start-up (~0.1-0.2 s: driver, device, code objects) begins NOW on a helper thread, while this thread reads and
+    // splits the Newick files; the counter's own set-up thread then finds the runtime initialised
+    std::thread hip_start([&a] { qs_ctx *probe = nullptr; if (qs_create(&probe, 4, 16, QS_FLAG_NONE, a.dev.device, nullptr, 0, 0) == QS_OK) qs_destroy(probe); trace_mark(a.dev, "hip thread: runtime initialised"); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } hip_start_join{hip_start};
 
     try {
         std::string refText = slurp(a.ref);
@@ -192,8 +211,18 @@ int main(int argc, char *argv[]) {
             std::cout << std::endl;
         }
 
+        {   // a rooted reference tree (degree-2 root): say once which of the reference's two behaviours is reproduced
+            size_t root_children = 0;
+            for (size_t v = 1; v < referenceTree.node_count(); ++v) root_children += referenceTree.parent[v] == 0;
+            if (root_children == 2 && !a.dev.root_as_edge)
+                std::cerr << "Note: the reference tree is rooted. QP-IC of the two root edges and EQP-IC along root paths follow the reference's\n"
+                             "      runtime-efficient (n^4) table; its memory-efficient table (-s, or when n^4 cells exceed 0.9 x RAM) reads other\n"
+                             "      cells for those node pairs and is NOT reproduced. --root-as-edge scores the root as a point on one edge.\n";
+        }
         std::vector<double> lqic, qpic, eqpic;
         size_t m = countEvalTrees(a.eval);
+        trace_mark(a.dev, "main: evaluation file read and split into trees");
+        hip_start.join();
         // counter width by m as in QuartetScores.cpp:115-147 (u8 is widened to the GPU's 16-bit cells)
         if (m < (size_t(1) << 8)) run<uint8_t>(referenceTree, a, m, lqic, qpic, eqpic);
         else if (m < (size_t(1) << 16)) run<uint16_t>(referenceTree, a, m, lqic, qpic, eqpic);

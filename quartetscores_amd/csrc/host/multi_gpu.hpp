@@ -49,7 +49,8 @@ public:
         : ref_(flatten_reference(refTree)), opt_(opt), bits_(count_bits), full_(need_full_table) {
         int ndev = 0;
         QSM_HIP(hipGetDeviceCount(&ndev));
-        if (n_gpus < 1 || n_gpus > ndev) throw std::runtime_error("--gpus " + std::to_string(n_gpus) + ": " + std::to_string(ndev) + " device(s) visible");
+        if (n_gpus < 1 || opt.device < 0 || opt.device + n_gpus > ndev)   // the devices used are opt.device .. opt.device + n_gpus - 1
+            throw std::runtime_error("--gpus " + std::to_string(n_gpus) + " from --device " + std::to_string(opt.device) + ": " + std::to_string(ndev) + " device(s) visible");
         G_ = n_gpus;
         std::cout << "There are " << m << " evaluation trees.\n";
         std::cout << "The reference tree has " << ref_.names.size() << " taxa.\n";

@@ -1,16 +1,23 @@
-// table_shards.hpp -- a count table larger than the device's memory on ONE GPU (`QuartetScores --table-shards K`).
+// table_shards.hpp -- the count table cut into K shards by the largest taxon id, on ONE GPU or spread over N GPUs
+// (`QuartetScores --table-shards K [--gpus N]`).
 //
 // The reference keeps its table in host RAM and once planned an STXXL external-memory vector for tables beyond it
-// (quartet_lookup_table.hpp:3,11-13,218-222). Here the table is cut into K shards by the largest
-// taxon id (contiguous rank ranges, because the leading term of the rank is C(s3,4): quartet_lookup_table.hpp:161-165,
-// the same cut the 8-GPU table-sharded mode uses) and the shards pass through the device one after the other:
-//   round 1, per shard: count ALL evaluation trees into the shard (the flattened batches stay in host memory), score
-//            pass 1, add the per-node-pair sums / take the minima on the host, then either copy the shard to host memory
-//            (spill = host) or drop it (spill = recount);
-//   round 2, per shard: bring the shard back (upload, or count again), score pass 2 against the GLOBAL minima, collect the
-//            candidate slots and overflow lists;
-//   qs_score_finish on the host, exactly as for shards on several GPUs.
-// Same scores as the unsharded run (tests/test_cli.py compares the output files).
+// (quartet_lookup_table.hpp:3,11-13,218-222); its disabled quartet-major scoring loop
+// (QuartetScoreComputer.hpp:212-371, bucket key :266-273) is the blueprint of scoring by OWNED quartet. Here the table is
+// cut into K shards by the largest taxon id (contiguous rank ranges, because the leading term of the rank is C(s3,4):
+// quartet_lookup_table.hpp:161-165). Shard s lives on GPU s mod N; every GPU receives ALL evaluation trees (they are
+// small) and counts only the quartets whose largest id falls into its shard -- no table collective at all:
+//   round 1, per shard: count all trees into the shard (the flattened batches stay in host memory, shared by the
+//            GPUs' host threads), score pass 1, fold the per-node-pair sums / minima into the GPU's host accumulators;
+//            a GPU that owns ONE shard keeps it resident, otherwise the shard is copied to host memory
+//            (spill = host) or dropped (spill = recount);
+//   between the rounds: SUM of the sums, MIN of the minima over the GPUs (host, a few MB);
+//   round 2, per shard: bring the shard back (still resident, upload, or count again), score pass 2 against the GLOBAL
+//            minima, collect the candidate slots and overflow lists;
+//   qs_score_finish once on the host.
+// BASELINE configs[4] (1024 taxa, u16, 273 GB) is `--gpus 8 --table-shards 8`; a table larger than one device's memory on
+// one GPU is `--table-shards K` alone (1200 taxa = 515 GB through one 288 GB MI355X in 3 shards). Same scores as the
+// unsharded run and as the oracle (tests/test_cli.py).
 #pragma once
 
 #include "QuartetScoreComputer.hpp"
@@ -18,6 +25,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <fstream>
+#include <mutex>
 
 namespace qsh {
 
@@ -48,11 +56,16 @@ public:
         return table_bytes <= (uint64_t)(0.85 * (double)freeb) ? 1 : (int)std::ceil((double)table_bytes / room);
     }
 
+    // n_gpus devices opt.device .. opt.device + n_gpus - 1; n_shards >= 1 (fewer shards than GPUs leave GPUs idle)
     ShardedTableQuartetScoreComputer(Tree const &refTree, const std::string &evalTreesPath, size_t m, uint32_t count_bits, int n_shards,
-                                     Spill spill, DeviceOptions opt)
-        : ref_(flatten_reference(refTree)), opt_(opt), bits_(count_bits) {
+                                     Spill spill, DeviceOptions opt, int n_gpus = 1)
+        : ref_(flatten_reference(refTree)), opt_(opt), bits_(count_bits), G_(n_gpus) {
         const uint32_t n = (uint32_t)ref_.names.size();
         if (n_shards < 1) throw std::runtime_error("--table-shards needs a positive number");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device (this program has no CPU fallback)");
+        if (G_ < 1 || opt_.device < 0 || opt_.device + G_ > ndev)
+            throw std::runtime_error("--gpus " + std::to_string(G_) + " from --device " + std::to_string(opt_.device) + ": " + std::to_string(ndev) + " device(s) visible");
         std::cout << "There are " << m << " evaluation trees.\n";
         std::cout << "The reference tree has " << n << " taxa.\n";
         const auto t0 = std::chrono::steady_clock::now();
@@ -69,15 +82,19 @@ public:
         bounds.push_back(n);
         for (size_t k = 0; k + 1 < bounds.size(); ++k)
             if (c4(bounds[k + 1]) > c4(bounds[k])) shards_.push_back({bounds[k], bounds[k + 1]});
+        const size_t K = shards_.size();
         const uint64_t table_bytes = total * 3 * (bits_ / 8);
+        // a GPU with one shard keeps it on the device between the rounds; only GPUs with several need a spill policy
+        const bool any_multi = K > (size_t)G_;
         if (spill == SPILL_AUTO) {
             const uint64_t avail = host_mem_available();
             spill = (avail && table_bytes + (table_bytes >> 3) < avail) ? SPILL_HOST : SPILL_RECOUNT;
         }
         spill_host_ = spill == SPILL_HOST;
-        std::cout << "Counting in " << shards_.size() << " table shard(s) by largest taxon id on one GPU; finished shards are "
-                  << (spill_host_ ? "kept in host memory" : "dropped and counted again for the second scoring pass") << ".\n";
-        // the evaluation trees, flattened once
+        std::cout << "Counting in " << K << " table shard(s) by largest taxon id on " << G_ << " GPU(s): every GPU counts all trees into its shard(s), no table collective; ";
+        if (any_multi) std::cout << "finished shards are " << (spill_host_ ? "kept in host memory" : "dropped and counted again for the second scoring pass") << ".\n";
+        else std::cout << "every shard stays on its GPU.\n";
+        // the evaluation trees, flattened once (read-only afterwards: shared by the GPUs' host threads)
         {
             auto ef = loadEvalFile(evalTreesPath);
             if (ef->spans.size() != m) throw std::runtime_error("evaluation file changed while running");
@@ -92,52 +109,28 @@ public:
         rt.parent = ref_.parent.data(); rt.leaf_node = ref_.leaf_node.data();
         const size_t P = (size_t)qs_score_pair_slots(&rt);
         if (P == 0) throw std::runtime_error("bad reference tree");
-        const size_t K = shards_.size();
-        std::vector<int64_t> sums(P * 3, 0), mins(P, INT64_MAX), part_s(P * 3), part_m(P), cand(K * P * QS_SCORE_CAND_SLOTS), extra;
-        std::vector<std::string> spilled(spill_host_ ? K : 0);
-        int64_t *d_sums = nullptr, *d_min = nullptr, *d_cand = nullptr;
-        if (hipSetDevice(opt_.device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-        auto dev_free = [&]() { (void)hipFree(d_sums); (void)hipFree(d_min); (void)hipFree(d_cand); d_sums = d_min = d_cand = nullptr; };
-        qs_ctx *ctx = nullptr;
+        P_ = P; rt_ = &rt; m_ = m;
+
+        std::vector<int64_t> sums(P * 3, 0), mins(P, INT64_MAX), cand(K * P * QS_SCORE_CAND_SLOTS), extra;
+        gpu_.assign((size_t)G_, PerGpu());
+        for (int g = 0; g < G_; ++g) {
+            gpu_[g].dev = opt_.device + g;
+            for (size_t s = (size_t)g; s < K; s += (size_t)G_) gpu_[g].shards.push_back(s);
+            gpu_[g].sums.assign(P * 3, 0); gpu_[g].mins.assign(P, INT64_MAX);
+            gpu_[g].spilled.resize(gpu_[g].shards.size());
+        }
         try {
-            if (hipMalloc((void **)&d_sums, P * 3 * 8) != hipSuccess || hipMalloc((void **)&d_min, P * 8) != hipSuccess ||
-                hipMalloc((void **)&d_cand, P * QS_SCORE_CAND_SLOTS * 8) != hipSuccess)
-                throw std::runtime_error("Insufficient memory!");
-            for (size_t k = 0; k < K; ++k) {       // round 1
-                ctx = open_shard(k);
-                count_all(ctx);
-                if (qs_score_pass1(ctx, &rt, d_sums, d_min) != QS_OK || qs_sync(ctx) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-                if (hipMemcpy(part_s.data(), d_sums, P * 3 * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                    hipMemcpy(part_m.data(), d_min, P * 8, hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("copy of the score accumulators failed");
-                for (size_t i = 0; i < P * 3; ++i) sums[i] = (int64_t)((uint64_t)sums[i] + (uint64_t)part_s[i]);
-                for (size_t i = 0; i < P; ++i) mins[i] = std::min(mins[i], part_m[i]);
-                if (spill_host_) {
-                    spilled[k].resize((size_t)qs_table_bytes(ctx));
-                    if (qs_table_download(ctx, &spilled[k][0], spilled[k].size()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-                }
-                std::cout << "shard " << k << ": largest id in [" << shards_[k].first << ", " << shards_[k].second << "), " << qs_table_bytes(ctx) << " bytes" << std::endl;
-                qs_destroy(ctx); ctx = nullptr;
+            run_on_all([&](PerGpu &w) { round1(w); });
+            for (const PerGpu &w : gpu_) {                     // SUM / MIN over the GPUs (host, a few MB)
+                for (size_t i = 0; i < P * 3; ++i) sums[i] = (int64_t)((uint64_t)sums[i] + (uint64_t)w.sums[i]);
+                for (size_t i = 0; i < P; ++i) mins[i] = std::min(mins[i], w.mins[i]);
             }
             const auto t1 = std::chrono::steady_clock::now();
             std::cout << "lookup table size in bytes: " << table_bytes << "\n";
             std::cout << "Finished counting quartets.\nIt took: " << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << " microseconds." << std::endl;
-            if (hipMemcpy(d_min, mins.data(), P * 8, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("copy of the minima failed");
-            for (size_t k = 0; k < K; ++k) {       // round 2
-                ctx = open_shard(k);
-                if (spill_host_) {
-                    if (qs_table_upload(ctx, spilled[k].data(), spilled[k].size()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-                    std::string().swap(spilled[k]);
-                } else count_all(ctx);
-                if (qs_score_pass2(ctx, &rt, d_min, d_cand) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-                int64_t *list = nullptr;
-                uint64_t cnt = 0;
-                if (qs_score_overflow(ctx, &rt, d_min, d_cand, &list, &cnt) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
-                if (cnt) { extra.insert(extra.end(), list, list + 4 * cnt); qs_free_host(list); }
-                if (hipMemcpy(cand.data() + k * P * QS_SCORE_CAND_SLOTS, d_cand, P * QS_SCORE_CAND_SLOTS * 8, hipMemcpyDeviceToHost) != hipSuccess)
-                    throw std::runtime_error("copy of the candidates failed");
-                qs_destroy(ctx); ctx = nullptr;
-            }
-            dev_free();
+            run_on_all([&](PerGpu &w) { round2(w, mins, cand); });
+            for (PerGpu &w : gpu_) extra.insert(extra.end(), w.extra.begin(), w.extra.end());
+            release();
             const uint32_t flags = (opt_.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt_.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u);
             std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
             int bif = 0;
@@ -151,27 +144,123 @@ public:
             std::cout << (scores.bifurcating ? "The reference tree is bifurcating.\n" : "The reference tree is multifurcating.\n");
             std::cout << "Finished computing scores.\nIt took: " << std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count() << " microseconds." << std::endl;
         } catch (...) {
-            if (ctx) qs_destroy(ctx);
-            dev_free();
+            release();
+            rt_ = nullptr;
             throw;
         }
+        rt_ = nullptr;
     }
+    ~ShardedTableQuartetScoreComputer() { release(); }
     ShardedTableQuartetScoreComputer(const ShardedTableQuartetScoreComputer &) = delete;
     ShardedTableQuartetScoreComputer &operator=(const ShardedTableQuartetScoreComputer &) = delete;
 
     ShardedTableScores scores;
 
 private:
+    struct PerGpu {
+        int dev = 0;
+        std::vector<size_t> shards;            // shard numbers this GPU owns (s mod N == g), in order
+        std::vector<int64_t> sums, mins, extra; // host accumulators of this GPU's shards
+        std::vector<std::string> spilled;      // spill = host: the finished shards
+        qs_ctx *resident = nullptr;            // the one shard of a GPU that owns exactly one: stays on the device
+        int64_t *d_sums = nullptr, *d_min = nullptr, *d_cand = nullptr;
+    };
     RefFlat ref_;
     DeviceOptions opt_;
     uint32_t bits_;
+    int G_ = 1;
     bool spill_host_ = false;
+    size_t P_ = 0, m_ = 0;
+    const qs_ref_tree *rt_ = nullptr;
     std::vector<std::pair<uint32_t, uint32_t>> shards_;
     std::vector<BatchFlat> batches_;
+    std::vector<PerGpu> gpu_;
+    std::mutex io_;
 
-    qs_ctx *open_shard(size_t k) {
+    // one host thread per GPU (the calling thread takes the last one); the first exception is rethrown after all have ended
+    template <typename F> void run_on_all(F f) {
+        std::vector<std::exception_ptr> errs(gpu_.size());
+        auto body = [&](size_t g) { try { f(gpu_[g]); } catch (...) { errs[g] = std::current_exception(); } };
+        std::vector<std::thread> pool;
+        for (size_t g = 0; g + 1 < gpu_.size(); ++g) pool.emplace_back(body, g);
+        body(gpu_.size() - 1);
+        for (auto &th : pool) th.join();
+        for (auto &e : errs) if (e) std::rethrow_exception(e);
+    }
+    void release() {
+        for (PerGpu &w : gpu_) {
+            (void)hipSetDevice(w.dev);
+            if (w.resident) { qs_destroy(w.resident); w.resident = nullptr; }
+            (void)hipFree(w.d_sums); (void)hipFree(w.d_min); (void)hipFree(w.d_cand);
+            w.d_sums = w.d_min = w.d_cand = nullptr;
+        }
+    }
+    static void hip_ok(hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
+
+    void round1(PerGpu &w) {
+        if (w.shards.empty()) return;
+        hip_ok(hipSetDevice(w.dev), "hipSetDevice");
+        if (hipMalloc((void **)&w.d_sums, P_ * 3 * 8) != hipSuccess || hipMalloc((void **)&w.d_min, P_ * 8) != hipSuccess ||
+            hipMalloc((void **)&w.d_cand, P_ * QS_SCORE_CAND_SLOTS * 8) != hipSuccess)
+            throw std::runtime_error("Insufficient memory!");
+        std::vector<int64_t> part_s(P_ * 3), part_m(P_);
+        for (size_t i = 0; i < w.shards.size(); ++i) {
+            const size_t k = w.shards[i];
+            qs_ctx *ctx = open_shard(k, w.dev);
+            try {
+                count_all(ctx);
+                if (qs_score_pass1(ctx, rt_, w.d_sums, w.d_min) != QS_OK || qs_sync(ctx) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+                hip_ok(hipMemcpy(part_s.data(), w.d_sums, P_ * 3 * 8, hipMemcpyDeviceToHost), "copy of the score sums");
+                hip_ok(hipMemcpy(part_m.data(), w.d_min, P_ * 8, hipMemcpyDeviceToHost), "copy of the score minima");
+                for (size_t j = 0; j < P_ * 3; ++j) w.sums[j] = (int64_t)((uint64_t)w.sums[j] + (uint64_t)part_s[j]);
+                for (size_t j = 0; j < P_; ++j) w.mins[j] = std::min(w.mins[j], part_m[j]);
+                const uint64_t bytes = qs_table_bytes(ctx);
+                if (w.shards.size() == 1) { w.resident = ctx; ctx = nullptr; }
+                else if (spill_host_) {
+                    w.spilled[i].resize((size_t)bytes);
+                    if (qs_table_download(ctx, &w.spilled[i][0], w.spilled[i].size()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+                }
+                std::lock_guard<std::mutex> lk(io_);
+                std::cout << "shard " << k << " on GPU " << w.dev << ": largest id in [" << shards_[k].first << ", " << shards_[k].second << "), " << bytes << " bytes" << std::endl;
+            } catch (...) { if (ctx) qs_destroy(ctx); throw; }
+            if (ctx) qs_destroy(ctx);
+        }
+    }
+
+    void round2(PerGpu &w, const std::vector<int64_t> &mins, std::vector<int64_t> &cand) {
+        if (w.shards.empty()) return;
+        hip_ok(hipSetDevice(w.dev), "hipSetDevice");
+        hip_ok(hipMemcpy(w.d_min, mins.data(), P_ * 8, hipMemcpyHostToDevice), "copy of the minima");
+        for (size_t i = 0; i < w.shards.size(); ++i) {
+            const size_t k = w.shards[i];
+            qs_ctx *ctx = w.resident;
+            w.resident = nullptr;
+            if (!ctx) {
+                ctx = open_shard(k, w.dev);
+                try {
+                    if (spill_host_) {
+                        if (qs_table_upload(ctx, w.spilled[i].data(), w.spilled[i].size()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+                        std::string().swap(w.spilled[i]);
+                        // the uploaded table holds the counts of all m trees: size the device QIC's log table for them
+                        (void)qs_set_tuning(ctx, QS_TUNE_TABLE_TREES, (uint64_t)m_);
+                    } else count_all(ctx);
+                } catch (...) { qs_destroy(ctx); throw; }
+            }
+            try {
+                if (qs_score_pass2(ctx, rt_, w.d_min, w.d_cand) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+                int64_t *list = nullptr;
+                uint64_t cnt = 0;
+                if (qs_score_overflow(ctx, rt_, w.d_min, w.d_cand, &list, &cnt) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
+                if (cnt) { w.extra.insert(w.extra.end(), list, list + 4 * cnt); qs_free_host(list); }
+                hip_ok(hipMemcpy(cand.data() + k * P_ * QS_SCORE_CAND_SLOTS, w.d_cand, P_ * QS_SCORE_CAND_SLOTS * 8, hipMemcpyDeviceToHost), "copy of the candidates");
+            } catch (...) { qs_destroy(ctx); throw; }
+            qs_destroy(ctx);
+        }
+    }
+
+    qs_ctx *open_shard(size_t k, int dev) {
         qs_ctx *ctx = nullptr;
-        if (qs_create(&ctx, (uint32_t)ref_.names.size(), bits_, QS_FLAG_NONE, opt_.device, nullptr, shards_[k].first, shards_[k].second) != QS_OK)
+        if (qs_create(&ctx, (uint32_t)ref_.names.size(), bits_, QS_FLAG_NONE, dev, nullptr, shards_[k].first, shards_[k].second) != QS_OK)
             throw std::runtime_error(qs_last_error(nullptr));
         if (qs_table_alloc(ctx) != QS_OK) { std::string e = qs_last_error(ctx); qs_destroy(ctx); throw std::runtime_error(e); }
         return ctx;

@@ -62,6 +62,12 @@ struct qs_ctx {
     bool perm_built[2] = {false, false};
     uint32_t tile_chunk = 4, tile_cblock = 16;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major
     uint32_t tile_cgroup = 0;                          // > 1: c innermost in groups of this many (the waves of a workgroup share M[ab], M[bd])
+    // binary tiling, cooperative workgroups (count_bitslice4_kernel): launch slots in groups of 4 tiles of one (a-blocks,
+    // b-block, d-block) with consecutive c (bit 31 = shadow tile: takes part, does not store), and the list of the tiles
+    // that stay with count_bitslice3_kernel (diagonal tiles, tiles without a second a-block)
+    uint32_t *perm_coop = nullptr, *perm_rest = nullptr;
+    uint32_t n_coop = 0, n_rest = 0;
+    uint32_t tune_coop = 0;                            // QS_TUNE_COOP: 1 = cooperative workgroups on; 0 / 2 = off (the default: measured slower)
     std::vector<uint32_t> h_cp3, h_dp3, h_cp, h_dp1t;  // host copies of the prefix arrays
     uint32_t *dprefix1t = nullptr;                     // the same kernel on general / partial batches: 8x8 tiles (cprefix), d-blocks counted down
     uint32_t total_tiles1t = 0;
@@ -234,6 +240,63 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
             seen[id] = 1;
         }
     }
+    // Off unless asked for (QS_TUNE_COOP = 1): measured on MI355X the real barrier per 32-tree step costs more than the
+    // shared loads save (512 taxa x 10000 trees: 368 ms against 354 ms; profiles/r03_experiments.md)
+    if (bin && c->tune_coop == 1) {
+        // Cooperative launch order: same nesting ((a,b)-major: b-block, chunk of a-block pairs, c-block, d-block), but
+        // innermost FOUR consecutive c of one a-block pair -- one workgroup of count_bitslice4_kernel. A group short of
+        // four valid c is filled with shadow copies of its first tile.
+        std::vector<uint32_t> coop, rest;
+        coop.reserve(total + total / 8);
+        for (uint32_t Bk = 1; Bk < Tmax; ++Bk) {
+            const uint32_t base = (Bk * Bk) / 4;
+            const uint32_t nj = ((Bk + 1) * (Bk + 1)) / 4 - base;     // tiles under this b-block; the last one lacks a2 when Bk is odd
+            const uint32_t nj2 = Bk / 2;                              // pairs (2j, 2j+1) with 2j+1 < Bk
+            const uint32_t c_lo = std::max(2u, 8 * Bk + 1);
+            for (uint32_t j0 = 0; j0 < nj2; j0 += chunk) {
+                const uint32_t j1 = std::min(nj2, j0 + chunk);
+                for (uint32_t cb = c_lo; cb <= cmax; cb += cblock)
+                    for (uint32_t k = 0; k < n_dblk; ++k) {
+                        const uint32_t d1 = d_hi - k * kDB;
+                        for (uint32_t j = j0; j < j1; ++j)
+                            for (uint32_t c4 = cb; c4 < cb + cblock && c4 + 1 < d1; c4 += 4) {
+                                const uint32_t first = dp[k] + cp[c4] + base + j;
+                                for (uint32_t cc = c4; cc < c4 + 4; ++cc)
+                                    coop.push_back((cc < cb + cblock && cc + 1 < d1) ? dp[k] + cp[cc] + base + j : (first | 0x80000000u));
+                            }
+                    }
+            }
+            if (nj > nj2)                                            // the tile with a single a-block
+                for (uint32_t k = 0; k < n_dblk; ++k) {
+                    const uint32_t d1 = d_hi - k * kDB;
+                    for (uint32_t cc = c_lo; cc + 1 < d1; ++cc) rest.push_back(dp[k] + cp[cc] + base + nj2);
+                }
+        }
+        for (uint32_t kd = 0; kd < (Tmax + 1) / 2; ++kd)
+            for (uint32_t k = 0; k < n_dblk; ++k) {
+                const uint32_t d1 = d_hi - k * kDB;
+                for (uint32_t cc = 2; cc + 1 < d1; ++cc) {
+                    const uint32_t T = T_of(cc);
+                    if (kd < (T + 1) / 2) rest.push_back(dp[k] + cp[cc] + (T * T) / 4 + kd);
+                }
+            }
+        {   // coop (without shadows) and rest together: every tile exactly once
+            std::vector<uint8_t> seen(total, 0);
+            size_t real = 0;
+            auto take = [&](uint32_t id) { if (id >= total || seen[id]) return false; seen[id] = 1; ++real; return true; };
+            for (uint32_t id : coop) if (!(id & 0x80000000u) && !take(id)) return fail(c, QS_ERR_STATE, "tile order: cooperative list is not a partition");
+            for (uint32_t id : rest) if (!take(id)) return fail(c, QS_ERR_STATE, "tile order: rest list is not a partition");
+            if (real != total || coop.size() % 4) return fail(c, QS_ERR_STATE, "tile order: cooperative + rest lists do not cover the tiling");
+        }
+        if (!coop.empty()) {
+            if (hipMalloc(&c->perm_coop, coop.size() * 4) != hipSuccess || hipMalloc(&c->perm_rest, std::max<size_t>(rest.size(), 1) * 4) != hipSuccess)
+                return fail(c, QS_ERR_OOM, "hipMalloc tile order (cooperative lists)");
+            if (hipMemcpyAsync(c->perm_coop, coop.data(), coop.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                (!rest.empty() && hipMemcpyAsync(c->perm_rest, rest.data(), rest.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) ||
+                hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, QS_ERR_HIP, "memcpy tile order (cooperative lists)");
+            c->n_coop = (uint32_t)coop.size(); c->n_rest = (uint32_t)rest.size();
+        }
+    }
     if (hipMalloc(&c->perm[which], perm.size() * 4) != hipSuccess) return fail(c, QS_ERR_OOM, "hipMalloc tile order");
     if (hipMemcpyAsync(c->perm[which], perm.data(), perm.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, QS_ERR_HIP, "memcpy tile order");
@@ -257,10 +320,25 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             QS_HIP(c, hipSetDevice(c->device));
             QS_HIP(c, hipStreamSynchronize(c->stream));
             for (int w = 0; w < 2; ++w) { if (c->perm[w]) (void)hipFree(c->perm[w]); c->perm[w] = nullptr; c->perm_built[w] = false; }
+            if (c->perm_coop) (void)hipFree(c->perm_coop);
+            if (c->perm_rest) (void)hipFree(c->perm_rest);
+            c->perm_coop = c->perm_rest = nullptr; c->n_coop = c->n_rest = 0;
             c->tile_chunk = (uint32_t)(value & 0xFFFF); c->tile_cblock = (uint32_t)((value >> 16) & 0xFFFF); c->tile_cgroup = (uint32_t)((value >> 32) & 0xFF);
             return QS_OK;
         case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
         case QS_TUNE_TABLE_TREES: c->table_trees_hint = value; return QS_OK;
+        case QS_TUNE_COOP:
+            if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_COOP takes 0 (default: off), 1 (on) or 2 (off)");
+            if (c->tune_coop != (uint32_t)value) {   // the launch lists depend on it: rebuild on next use
+                QS_HIP(c, hipSetDevice(c->device));
+                QS_HIP(c, hipStreamSynchronize(c->stream));
+                if (c->perm[0]) (void)hipFree(c->perm[0]);
+                c->perm[0] = nullptr; c->perm_built[0] = false;
+                if (c->perm_coop) (void)hipFree(c->perm_coop);
+                if (c->perm_rest) (void)hipFree(c->perm_rest);
+                c->perm_coop = c->perm_rest = nullptr; c->n_coop = c->n_rest = 0;
+            }
+            c->tune_coop = (uint32_t)value; return QS_OK;
         case QS_TUNE_GATHER_IMPL:
             if (value > QS_IMPL_BITSLICE) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_GATHER_IMPL takes QS_IMPL_AUTO / _SWAR / _BITSLICE");
             c->tune_gather_impl = (uint32_t)value; return QS_OK;
@@ -348,6 +426,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->cprefix) (void)hipFree(c->cprefix);
     if (c->dprefix3) (void)hipFree(c->dprefix3);
     for (int w = 0; w < 2; ++w) if (c->perm[w]) (void)hipFree(c->perm[w]);
+    if (c->perm_coop) (void)hipFree(c->perm_coop);
+    if (c->perm_rest) (void)hipFree(c->perm_rest);
     if (c->dev_logk) (void)hipFree(c->dev_logk);
     if (c->dprefix1t) (void)hipFree(c->dprefix1t);
     if (c->cprefix3) (void)hipFree(c->cprefix3);
@@ -363,6 +443,26 @@ extern "C" void qs_destroy(qs_ctx *c) {
     for (hipEvent_t e : c->score_ev) if (e) (void)hipEventDestroy(e);
     delete c->ref_cache;
     delete c;
+}
+
+// Work the first qs_count_batch would otherwise do before its first launch, done ahead of time (the host calls this on its
+// GPU-initialisation thread while the evaluation trees are still being parsed): the launch order of the bit-sliced count
+// kernel for binary batches (12 M slots at 512 taxa: ~60 ms of host work + a 47 MB copy) and the pair-depth panel for a
+// batch of n_trees_hint trees. Purely an optimisation: qs_count_batch builds whatever is missing. The reference does the
+// equivalent set-up in the table's constructor (QuartetCounterLookup.hpp:245-273).
+extern "C" int qs_prepare(qs_ctx *c, uint64_t n_trees_hint) {
+    if (!c) return QS_ERR_ARG;
+    QS_HIP(c, hipSetDevice(c->device));
+    const uint32_t *order = nullptr;
+    int rc = tile_order(c, 0, &order);
+    if (rc != QS_OK) return rc;
+    if (n_trees_hint && !c->panel) {
+        const size_t group_bytes = (size_t)binom2(c->n) * 5 * 4;   // 5 planes: the common depth class
+        const uint32_t groups = slice_groups(c, group_bytes, (uint32_t)std::min<uint64_t>((n_trees_hint + 31) / 32, 1u << 20), order != nullptr);
+        if (hipMalloc(&c->panel, (size_t)groups * group_bytes) == hipSuccess) c->panel_bytes = (size_t)groups * group_bytes;
+        else { c->panel = nullptr; (void)hipGetLastError(); }       // not fatal here: the count reports it if it persists
+    }
+    return QS_OK;
 }
 
 // ---- table -------------------------------------------------------------------------------
@@ -711,6 +811,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo; g.n_dblk = c->n_dblk;
     g.total_tiles = c->total_tiles3; g.dprefix = c->dprefix3; g.cprefix = c->cprefix3;
     { int rc_o = tile_order(c, 0, &g.perm); if (rc_o != QS_OK) return rc_o; }
+    g.perm_coop = c->perm_coop; g.n_coop = c->n_coop; g.perm_rest = c->perm_rest; g.n_rest = c->n_rest;
     bool first = true;
     c->variant = "gather/binary_full/bitslice_";
     for (uint32_t k = 0; k < d.n_classes; ++k) {
@@ -739,6 +840,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
         c->variant += (k ? "+b" : "b") + std::to_string(depth_bits) + "x2" + (d.n_classes > 1 ? ":" + std::to_string(s_hi - s_lo) : "");
     }
     c->variant += "/wire_u16x2";
+    if (c->n_coop) c->variant += "/coop4";
     c->wire_trees = (overwrite ? 0 : c->wire_trees) + d.n_trees;
     c->last_timed = false;
     return QS_OK;
@@ -826,7 +928,10 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 if (timed) QS_HIP(c, mark(c, 0));
                 if (use_bitslice) {
                     CountGeometry g3 = g;
-                    if (mode == MODE_BINARY_FULL) { g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; }
+                    if (mode == MODE_BINARY_FULL) {
+                        g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3;
+                        g3.perm_coop = c->perm_coop; g3.n_coop = c->n_coop; g3.perm_rest = c->perm_rest; g3.n_rest = c->n_rest;
+                    }
                     else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
                     g3.perm = order;
                     QS_HIP(c, launch_count_bitslice3(c->stream, g3, c->panel, (int)depth_bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && first, nullptr));
@@ -842,6 +947,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             names += (k ? "+" : "") + nm;
         }
         c->variant = std::string("gather/") + mode_names[mode] + "/" + names + "/count_u" + std::to_string(c->count_bits);
+        if (mode == MODE_BINARY_FULL && !all_swar && c->n_coop) c->variant += "/coop4";   // tiles with two a-blocks: count_bitslice4_kernel
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");

@@ -39,6 +39,10 @@
 #include <type_traits>
 #include <vector>
 
+#ifndef QS_EXP
+#define QS_EXP 0   // kernel experiments (tools/Makefile: make exp EXP=<bits>); 0 = the product
+#endif
+
 namespace qs {
 
 // ======================================================================================
@@ -808,7 +812,11 @@ uint32_t bitslice3_tiles_for_c(uint32_t c) {
 
 constexpr int kS3RSlots = kDB * 16;            // R elements: slot = d-row * 16 + b-column (0..15)
 constexpr int kS3Row0 = kS3RSlots;             // 16 elements M[x,c] of the a-columns
+#if QS_EXP & 64
+constexpr int kS3Slots = kS3RSlots + 32;       // experiment: 16 dummy slots behind the row for the lanes that load nothing
+#else
 constexpr int kS3Slots = kS3RSlots + 16;       // 144
+#endif
 constexpr uint32_t kS3Inv = 0x80000000u;       // offset beyond any tree group (also after >> 2): the buffer load returns zeros
 
 typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
@@ -835,9 +843,6 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
-#ifndef QS_EXP
-#define QS_EXP 0
-#endif
 #if QS_EXP & 32
 // diagnostic build only (tools/: make exp EXP=33): s_memtime stamps around the step's barrier and around a full drain of
 // the step's panel loads, summed over all waves: [0] waves, [1] cycles in the group loop, [2] at the barrier, [3] in the drain
@@ -972,7 +977,11 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     const bool ok0 = dok && bE0 < c, ok1 = dok && two_r && bE1 < c;
     const uint32_t rowd = (uint32_t)binom2(dE);
     const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv;
+#if QS_EXP & 128   // timing-only knock-out (wrong counts): M[c,d] requested by one lane of eight
+    const uint32_t yoff = (dok && r_col == 0) ? (rowd + c) * 16u : kS3Inv;
+#else
     const uint32_t yoff = dok ? (rowd + c) * 16u : kS3Inv;      // M[c,d]: shared by both R elements of the lane
+#endif
     const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
     // the 16 M[x,c] elements are staged by ALL lanes, four copies of each (lane & 15 picks the element; the copies
     // load the same address and store the same value to the same slot). With the store under `if (lane < 16)` the
@@ -982,8 +991,14 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     uint32_t xa = 0xFFFFFFFFu;
     if (l16 < 8) xa = blk0 * kTA + l16;
     else if (blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (l16 - 8);
+#if QS_EXP & 64
+    // experiment: only lanes 0..15 request the 16 M[x,c] elements (the others: out-of-range offset, dummy LDS slots)
+    const uint32_t rowoff = (xa < c && lane < 16) ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
+    const uint32_t rowslot = kS3Row0 + l16 + (lane < 16 ? 0u : 16u);
+#else
     const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
     const uint32_t rowslot = kS3Row0 + l16;
+#endif
     const uint32_t ab1off = v1 ? pi1 * 16u : kS3Inv, ab2off = v2 ? pi2 * 16u : kS3Inv;
     const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
@@ -1199,6 +1214,214 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     }
 }
 
+
+// ======================================================================================
+// count_bitslice4_kernel: binary_full batches, the waves of a workgroup SHARE their panel loads
+// ======================================================================================
+// What bounds count_bitslice3_kernel besides VALU issue is the vector-memory path, not the caches behind it: a 32-tree
+// step of one wave issues 10 loads over 64 lanes (5 KB of 16-byte gathers plus their upper planes), every CU's L1 address
+// path processes ~16 such waves per round, and a timing-only build whose buffer descriptor has zero records (every load
+// answered without touching the L1) runs 12 % faster while changing the tile order for better L2 hits changes nothing
+// (profiles/r03_experiments.md). This kernel cuts the requests themselves. The four waves of a workgroup take four
+// tiles with the SAME a-blocks, b-block and d-block and consecutive third ids c (the host builds that launch order:
+// tile_order in qs_abi.hip, groups padded with "shadow" tiles that compute but do not store). Of a wave's 216 panel
+// elements per step only M[c,d] (8) and M[x,c] (16) depend on c; M[ab] (2 x 64) and M[bd] (64) are identical for the
+// whole workgroup. So per step
+//   wave w < 3 loads ONE of the three shared sets (one element per lane), every wave its own 24 private elements,
+//   everything is written raw to LDS (double-buffered),
+//   one s_barrier,
+//   every lane reads back its own M[ab] (x2), M[bd], M[cd] and M[ac] (x2) elements and forms L1, L2 and R as before.
+// 7 load pairs per workgroup-step instead of 20, 288 lane-elements instead of 1280; the raw elements of the next group
+// wait in 10 VGPRs (not 25) during the compare chains. Same arithmetic, same table. Only off-diagonal tiles with both
+// a-columns take this kernel (92 % of the tiles at 512 taxa); the rest goes through count_bitslice3_kernel.
+// MEASURED (MI355X, 512 taxa x 10000 trees): 368 ms against 354 ms for count_bitslice3_kernel alone (349.8 ms when forced to
+// 5 waves per SIMD, with spills) -- the barrier is now a true dependency between four waves on four SIMDs, and that costs
+// more than the requests cost. The 12 % that the zero-record knock-out promised was mostly the clock rising on all-zero
+// operands, not the memory path. Kept as an option (QS_TUNE_COOP = 1) and under test; off by default.
+constexpr int kC4Shared = 3 * kWave;                    // raw slots of the three shared sets
+constexpr int kC4Private = 24;                          // per wave: 16 M[x,c] + 8 M[c,d]
+constexpr int kC4Raw = kC4Shared + kWavesPerBlock * kC4Private; // 288 raw slots per buffer
+constexpr uint32_t kShadowTile = 0x80000000u;           // launch-slot flag: compute (loads, barriers) but do not store
+
+template <int NWORDS> __device__ __forceinline__ void c4_put(uint4 *lo, uint32_t *hi, uint32_t slot, const Planes &x) {
+    constexpr int H = NWORDS - 4;                       // upper words: 0..4, kept in records of 1, 2 or 4 words
+    lo[slot] = make_uint4(x.w[0], x.w[1], x.w[2], x.w[3]);
+    if (H == 1) hi[slot] = x.w[4];
+    else if (H == 2) reinterpret_cast<uint2 *>(hi)[slot] = make_uint2(x.w[4], x.w[5]);
+    else if (H >= 3) reinterpret_cast<uint4 *>(hi)[slot] = make_uint4(x.w[4], x.w[5], x.w[6], x.w[7]);
+}
+template <int NWORDS> __device__ __forceinline__ Planes c4_get(const uint4 *lo, const uint32_t *hi, uint32_t slot) {
+    constexpr int H = NWORDS - 4;
+    Planes r;
+    const uint4 v = lo[slot];
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+    if (H == 1) r.w[4] = hi[slot];
+    else if (H == 2) { const uint2 h = reinterpret_cast<const uint2 *>(hi)[slot]; r.w[4] = h.x; r.w[5] = h.y; }
+    else if (H >= 3) { const uint4 h = reinterpret_cast<const uint4 *>(hi)[slot]; r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
+    return r;
+}
+constexpr int c4_hi_words(int nwords) { return nwords <= 4 ? 0 : nwords == 5 ? 1 : nwords == 6 ? 2 : 4; }
+
+
+// 10 staging registers instead of 25: the 4-bit instance fits 5 waves per SIMD (90 VGPRs); the others would spill there
+template <int B> constexpr int bs4_waves() { return B <= 4 ? 5 : 4; }
+template <int B, typename CT>
+__global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(bs4_waves<B>(), bs4_waves<B>()))) void count_bitslice4_kernel(
+    const uint4 *__restrict__ P, uint32_t npairs, uint32_t n_groups, uint32_t m_trees, uint32_t d_start, uint32_t d_hi,
+    uint64_t rank_lo, uint32_t n_dblk, uint32_t n_slots, const uint32_t *__restrict__ dprefix, const uint32_t *__restrict__ cprefix,
+    CT *__restrict__ table, uint32_t *__restrict__ overflow_flag, uint32_t overwrite, uint32_t xcd_remap, uint32_t *__restrict__ wire,
+    const uint32_t *__restrict__ perm) {
+    constexpr int NB = B + 1;                           // planes of L and R
+    constexpr int NWRAW = B < 4 ? 4 : B;                // words of a raw panel element (compact panel: max(B, 4) planes)
+    constexpr int HR = c4_hi_words(NWRAW), HI = c4_hi_words(NB);
+    __shared__ uint4 raw_lo[2][kC4Raw];
+    __shared__ __align__(16) uint32_t raw_hi[2][HR ? kC4Raw * HR : 4];
+    __shared__ uint4 img_lo[kWavesPerBlock][kWave];
+    __shared__ __align__(16) uint32_t img_hi[kWavesPerBlock][HI ? kWave * HI : 4];
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    uint32_t lb = blockIdx.x;
+    if (xcd_remap & 1u) {
+        const uint32_t nb = gridDim.x, q8 = nb / 8, r8 = nb % 8, xcd = lb % 8, y = lb / 8;
+        lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + y;
+    }
+    // launch slot -> tile: the host pads every workgroup to four tiles of one (a-blocks, b-block, d-block)
+    uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)perm[lb * kWavesPerBlock + wave]);
+    const bool shadow = (tile & kShadowTile) != 0;
+    tile &= ~kShadowTile;
+    uint32_t dp_k, cp_c;
+    const uint32_t k = wave_search_le(dprefix, 0, n_dblk, tile, lane, dp_k);
+    const uint32_t local = tile - dp_k;
+    const uint32_t d1 = d_hi - k * kDB;
+    const uint32_t d0 = d1 > d_start + kDB ? d1 - kDB : d_start;
+    const uint32_t c = wave_search_le(cprefix, 2, d1 - 1, local, lane, cp_c);
+    const uint32_t tl = local - cp_c;                   // off-diagonal tile with both a-blocks (host guarantee)
+    uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f));
+    while ((Bk * Bk) / 4 > tl) --Bk;
+    while (((Bk + 1) * (Bk + 1)) / 4 <= tl) ++Bk;
+    const uint32_t jt = tl - (Bk * Bk) / 4;
+    const uint32_t blk0 = 2 * jt, blk1 = 2 * jt + 1;
+    const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
+    const uint32_t a1 = blk0 * kTA + ia, a2 = blk1 * kTA + ia, b = Bk * kTB + ib;
+    const bool v1 = !shadow && b < c, v2 = v1;          // a1 < a2 < b by construction
+    const uint32_t pi1 = (uint32_t)binom2(b) + a1, pi2 = (uint32_t)binom2(b) + a2;
+    const uint32_t jlo = c >= d0 ? c + 1 - d0 : 0u, jhi = d1 - d0;
+
+    // ---- what this lane requests per group: one shared element (waves 0..2) and one private element (lanes 0..23) ----
+    const uint32_t r_j = lane >> 3, r_col = lane & 7, dE = d0 + r_j;
+    uint32_t shoff = kS3Inv;
+    if (wave == 0) shoff = pi1 * 16u;
+    else if (wave == 1) shoff = pi2 * 16u;
+    else if (wave == 2) { const uint32_t bE = Bk * kTB + r_col; if (dE < d1 && bE < dE) shoff = ((uint32_t)binom2(dE) + bE) * 16u; }
+    uint32_t pvoff = kS3Inv;
+    if (lane < 16) { const uint32_t xa = (lane < 8 ? blk0 : blk1) * kTA + (lane & 7); if (xa < c) pvoff = ((uint32_t)binom2(c) + xa) * 16u; }
+    else if (lane < 24) { const uint32_t dy = d0 + (lane - 16); if (dy < d1 && dy > c) pvoff = ((uint32_t)binom2(dy) + c) * 16u; }
+    const uint32_t group_bytes = npairs * (uint32_t)(NWRAW * 4), hi_base = npairs * 16u;
+    const uint32_t pv_slot = kC4Shared + wave * kC4Private;
+
+    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB];
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
+
+    auto rsrc_of = [&](uint32_t g) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (QS_EXP & 16) ? 0 : (int)group_bytes, 0x00020000);
+    };
+    auto put_raw = [&](int bufi, const Planes &sh, const Planes &pv) {
+        if (wave < 3) c4_put<NWRAW>(raw_lo[bufi], raw_hi[bufi], wave * kWave + lane, sh);
+        if (lane < kC4Private) c4_put<NWRAW>(raw_lo[bufi], raw_hi[bufi], pv_slot + lane, pv);
+    };
+    // one 32-tree step: group g sits raw in buffer CUR; request group g_next, count g, park g_next raw in the other buffer
+    auto step = [&](uint32_t g_next, auto cur_tag, auto full_tag) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
+        // all waves have parked their part of this group (LDS writes complete before the barrier releases)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const Planes ab1 = c4_get<NWRAW>(raw_lo[CUR], raw_hi[CUR], lane);
+        const Planes rowA1 = c4_get<NWRAW>(raw_lo[CUR], raw_hi[CUR], pv_slot + ia);
+        const Planes ab2 = c4_get<NWRAW>(raw_lo[CUR], raw_hi[CUR], kWave + lane);
+        const Planes rowA2 = c4_get<NWRAW>(raw_lo[CUR], raw_hi[CUR], pv_slot + 8 + ia);
+        const Planes mbd = c4_get<NWRAW>(raw_lo[CUR], raw_hi[CUR], 2 * kWave + lane);
+        const Planes mcd = c4_get<NWRAW>(raw_lo[CUR], raw_hi[CUR], pv_slot + 16 + r_j);
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(g_next);
+        const Planes sh = buf_load_planes<NWRAW>(r, shoff, hi_base);
+        const Planes pv = buf_load_planes<NWRAW>(r, pvoff, hi_base);
+        c4_put<NB>(img_lo[wave], img_hi[wave], lane, sub_biased<B>(mbd, mcd));   // R element (d-row r_j, b-column r_col)
+        const Planes L1 = sub_biased<B>(ab1, rowA1);
+        const Planes L2 = sub_biased<B>(ab2, rowA2);
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            if (FULL || ((uint32_t)j >= jlo && (uint32_t)j < jhi)) {
+                const Planes Rb = c4_get<NB>(img_lo[wave], img_hi[wave], j * 8 + ib);
+                uint32_t gt, lt, gt2, lt2;
+                cmp_planes<NB>(L1, Rb, gt, lt);
+                popc_acc(gt, x0[j]);
+                popc_acc(lt, x1[j]);
+                cmp_planes<NB>(L2, Rb, gt2, lt2);
+                popc_acc(gt2, y0[j]);
+                popc_acc(lt2, y1[j]);
+            }
+        }
+        put_raw(CUR ^ 1, sh, pv);
+    };
+    auto run = [&](auto full_tag) {
+        using Z_ = std::integral_constant<int, 0>; using O_ = std::integral_constant<int, 1>;
+        {   // group 0 -> buffer 0
+            const __amdgpu_buffer_rsrc_t r = rsrc_of(0);
+            put_raw(0, buf_load_planes<NWRAW>(r, shoff, hi_base), buf_load_planes<NWRAW>(r, pvoff, hi_base));
+        }
+        const uint32_t g_last = n_groups - 1;
+        uint32_t g = 0;
+        for (; g + 2 <= n_groups; g += 2) {
+            step(g + 1, Z_{}, full_tag);
+            step(min(g + 2, g_last), O_{}, full_tag);   // past the end: re-reads the last group (never used)
+        }
+        if (g < n_groups) step(g_last, Z_{}, full_tag);
+    };
+    // every wave of the workgroup must take part in every barrier: the two instances run the same number of steps
+    if (jlo == 0 && jhi == (uint32_t)kDB) run(std::true_type{}); else run(std::false_type{});
+
+    uint64_t bd4 = binom4(d0), bd3 = binom3(d0), bd2 = binom2(d0);
+    const uint64_t rcb = binom3(c) - rank_lo;
+    if (wire) {   // one word n0 | n1 << 16 per tuple (QS_COUNT_WIRE16X2)
+#pragma unroll
+        for (int j = 0; j < kDB; ++j) {
+            const uint32_t d = d0 + j;
+            const uint64_t base = bd4 + rcb;
+            bd4 += bd3; bd3 += bd2; bd2 += d;
+            if (d < d1 && d > c && v1) {
+                uint32_t w = x0[j] | (x1[j] << 16), w2 = y0[j] | (y1[j] << 16);
+                if (!overwrite) { w += wire[base + pi1]; w2 += wire[base + pi2]; }
+                wire[base + pi1] = w;
+                wire[base + pi2] = w2;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < kDB; ++j) {
+        const uint32_t d = d0 + j;
+        const uint64_t base = bd4 + rcb;
+        bd4 += bd3; bd3 += bd2; bd2 += d;
+        if (d < d1 && d > c && v1) {
+            {
+                const uint64_t idx = (base + pi1) * 3;
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = m_trees - x0[j] - x1[j];
+                if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
+                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+                store_tuple(table + idx, w0, w1, w2);
+            }
+            if (v2) {
+                const uint64_t idx = (base + pi2) * 3;
+                uint32_t w0 = y0[j], w1 = y1[j], w2 = m_trees - y0[j] - y1[j];
+                if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
+                if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
+                store_tuple(table + idx, w0, w1, w2);
+            }
+        }
+    }
+}
+
 #if QS_EXP & 32
 extern "C" int qs_debug_stamps(unsigned long long out[8]) {   // read and reset (diagnostic builds only)
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qs_dbg_stamps), 64) != hipSuccess) return -1;
@@ -1207,11 +1430,35 @@ extern "C" int qs_debug_stamps(unsigned long long out[8]) {   // read and reset 
 }
 #endif
 
-hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
+hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g_in, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite, uint32_t *wire) {
-    if (g.total_tiles == 0 || n_groups == 0) return hipSuccess;
-    const uint32_t npairs = (uint32_t)binom2(g.n);
+    if (g_in.total_tiles == 0 || n_groups == 0) return hipSuccess;
+    const uint32_t npairs = (uint32_t)binom2(g_in.n);
+    CountGeometry g = g_in;
+    if (mode == MODE_BINARY_FULL && g.perm_coop && g.n_coop) {
+        // the tiles whose workgroups share their panel loads (count_bitslice4_kernel); the others follow below through
+        // count_bitslice3_kernel with the rest list as its launch order (disjoint tiles: both write the same table)
+        dim3 grid4(g.n_coop / kWavesPerBlock), block4(kCountThreads);
+#define QS_BS4(BB, CT)                                                                                              \
+    hipLaunchKernelGGL((count_bitslice4_kernel<BB, CT>), grid4, block4, 0, s, (const uint4 *)panel, npairs, n_groups, m_trees, \
+                       g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.n_coop, g.dprefix, g.cprefix, (CT *)table, overflow_flag,    \
+                       overwrite ? 1u : 0u, 1u, wire, g.perm_coop)
+#define QS_BS4_B(CT)                                                                                                \
+    do {                                                                                                            \
+        if (depth_bits <= 4) QS_BS4(4, CT);                                                                         \
+        else if (depth_bits == 5) QS_BS4(5, CT);                                                                    \
+        else if (depth_bits == 6) QS_BS4(6, CT);                                                                    \
+        else QS_BS4(7, CT);                                                                                         \
+    } while (0)
+        if (count_bits == 32) QS_BS4_B(uint32_t); else QS_BS4_B(uint16_t);
+#undef QS_BS4_B
+#undef QS_BS4
+        hipError_t e4 = hipGetLastError();
+        if (e4 != hipSuccess) return e4;
+        g.perm = g.perm_rest; g.total_tiles = g.n_rest;
+        if (g.total_tiles == 0) return hipSuccess;
+    }
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
 #define QS_BS3(BB, MM, CT)                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \

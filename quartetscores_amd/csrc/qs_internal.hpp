@@ -59,6 +59,11 @@ struct CountGeometry {
     const uint32_t *dprefix; // device, n_dblk+1
     const uint32_t *cprefix; // device, n+1
     const uint32_t *perm = nullptr; // device, total_tiles: launch slot -> tile id (nullptr = identity); see qs_abi.hip tile_order
+    // binary_full tiling only: the launch order split for count_bitslice4_kernel. perm_coop: n_coop slots (a multiple of 4;
+    // every aligned group of 4 = tiles of one (a-blocks, b-block, d-block), bit 31 = shadow tile that must not store);
+    // perm_rest: the n_rest tiles count_bitslice3_kernel still runs. NULL / 0 = everything through count_bitslice3_kernel.
+    const uint32_t *perm_coop = nullptr, *perm_rest = nullptr;
+    uint32_t n_coop = 0, n_rest = 0;
 };
 
 // qs_count.hip

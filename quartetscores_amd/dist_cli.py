@@ -40,6 +40,60 @@ def _annotate(ref, lq, qp, eqp, bif):
     return newick.write(ref.nodes[0], comment)
 
 
+def _table_sharded(args, ref, world, rank, dev, say, t_begin):
+    """--table-shards K: every rank ingests ALL trees, counts them into the shard(s) it owns (contexts created with
+    [d_lo, d_hi) of the largest taxon id), and the scores come from distributed.score_table_shards."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib, distributed, engine, flatten, native_ingest, newick
+    n_shards = args.table_shards or world
+    if n_shards < world:
+        raise ValueError(f"--table-shards {n_shards}: fewer shards than ranks ({world})")
+    if native_ingest.available():
+        batch, m = native_ingest.ingest(args.ref, args.eval, 0, native_ingest.ALL, args.threads, want_ranges=False)
+    else:
+        trees = list(newick.parse_trees(open(args.eval).read()))
+        m = len(trees)
+        batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    bits = 16 if m < (1 << 16) else 32           # counter width by m (QuartetScores.cpp:115-147; u8 widened to u16)
+    say(f"There are {m} evaluation trees.")
+    say(f"The reference tree has {ref.n_taxa} taxa.")
+    say(f"Counting in {n_shards} table shard(s) by largest taxon id on {world} GPU(s): every GPU counts all trees into its "
+        f"shard(s), no table collective.")
+    t0 = time.perf_counter()
+    stream = torch.cuda.current_stream(dev)
+    mine = distributed.shards_of_rank(n_shards, world, rank)
+    counted = []
+
+    def open_shard(k):
+        if k is None:      # a rank without a shard: a context only for the host-side parts
+            return engine.Context(ref.n_taxa, bits, device=dev.index or 0, stream=stream.cuda_stream)
+        d_lo, d_hi = distributed.shard_of_largest_id(ref.n_taxa, n_shards, k)
+        ctx = engine.Context(ref.n_taxa, bits, device=dev.index or 0, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
+        ctx.table_alloc()
+        ctx.count_trees(batch, engine.QS_ALGO_GATHER)
+        ctx.sync()
+        counted.append(k)
+        if args.verbose:
+            print(f"[rank {rank}] shard {k}: largest id in [{d_lo},{d_hi}), {ctx.table_bytes} bytes ({ctx.last_count_variant()})")
+        return ctx
+    flags = _lib.QS_SCORE_QP_EXACT64 if args.exact_qp else _lib.QS_SCORE_QP_WRAP32
+    lq, qp, eqp, bif = distributed.score_table_shards(open_shard, mine, ref, flags, device=dev, close=lambda c: c.close())
+    if world > 1:
+        dist.barrier()
+    say("Finished counting quartets and computing scores.")
+    say(f"It took: {int((time.perf_counter() - t0) * 1e6)} microseconds.")
+    say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
+    if rank == 0:
+        with open(args.output, "w") as f:
+            f.write(_annotate(ref, lq, qp, eqp, bif) + "\n")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    say(f"Elapsed time: {int((time.perf_counter() - t_begin) * 1e6)} microseconds.")
+    return 0
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="quartetscores_amd.dist_cli", description=__doc__.split("\n\n")[0])
     ap.add_argument("-r", "--ref", required=True)
@@ -49,6 +103,9 @@ def main(argv=None):
     ap.add_argument("-t", "--threads", type=int, default=0, help="host threads per rank for parsing the evaluation trees (0 = all)")
     ap.add_argument("--exact-qp", action="store_true", help="64-bit QP sums instead of the reference's 32-bit wrap")
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto")
+    ap.add_argument("--table-shards", type=int, default=-1,
+                    help="table-sharded mode (1024 taxa x u16 = 273 GB: 8 ranks, 8 shards): the count table in K shards by largest taxon "
+                         "id, shard s on rank s mod N, every rank counts ALL trees into its shard(s), no table collective; 0 = one per rank")
     args = ap.parse_args(argv)
     t_begin = time.perf_counter()
 
@@ -73,6 +130,8 @@ def main(argv=None):
     say = print if rank == 0 else (lambda *a, **k: None)
     try:
         ref = flatten.flatten_reference(open(args.ref).read())
+        if args.table_shards >= 0:
+            return _table_sharded(args, ref, world, rank, dev, say, t_begin)
         if native_ingest.available():
             # the C++ host's multi-threaded ingest: one scan for the tree spans (= m), then only this rank's share is
             # parsed and flattened (the reference parses the whole file twice on one thread, QuartetScores.cpp:23-32)

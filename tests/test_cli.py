@@ -16,6 +16,32 @@ def run(*args):
     return subprocess.run([BIN, *args], capture_output=True, text=True, timeout=300)
 
 
+def cli_comments(path):
+    """sorted per-edge annotations of an annotated Newick file"""
+    return sorted(re.findall(r"\[([^\]]*)\]", open(path).read()))
+
+
+def oracle_comments(ref_nw, eval_text):
+    """what the annotations must be: the oracle's scores, formatted like quartet_newick_writer.hpp:164-187"""
+    o = Oracle(ref_nw)
+    o.count(eval_text)
+    o.score()
+    out = []
+    inf = float("inf")
+    for lq, qp, eqp in o.scores_by_bipartition().values():
+        parts = []
+        if qp is not None and lq != inf:          # the writer's qp-ic guard tests the LQ value (quirk Q6)
+            parts.append("qp-ic:%f" % qp)
+        if lq != inf:
+            parts.append("lq-ic:%f" % lq)
+        if eqp is not None and eqp != inf:
+            parts.append("eqp-ic:%f" % eqp)
+        if parts:
+            out.append(";".join(parts))
+    o.close()
+    return sorted(out)
+
+
 @pytest.fixture()
 def d1_files(tmp_path, golden):
     r, e = tmp_path / "ref.nwk", tmp_path / "eval.nwk"
@@ -391,16 +417,57 @@ def test_cpp_cli_table_shards_match_the_whole_table_run(tmp_path, trees, rooted,
     p = run("-r", str(r), "-e", str(e), "-o", str(o1))
     assert p.returncode == 0, p.stderr
     want = o1.read_text()
+    # the whole-table run itself against the oracle (not only CLI against CLI); the rooted case goes through the
+    # reference's degree-2-root handling, which the oracle restates too
+    if trees <= 1000:
+        assert cli_comments(o1) == oracle_comments(ref_nw, e.read_text())
     for i, extra in enumerate((["--table-shards", "3", "--spill", "host"], ["--table-shards", "3", "--spill", "recount"],
-                               ["--table-shards", "40"], ["--table-shards", "1"], ["--table-shards", "0"])):
+                               ["--table-shards", "40"], ["--table-shards", "1"], ["--table-shards", "0"],
+                               ["--table-shards", "5", "--gpus", "1"])):
         o = tmp_path / f"s{i}.nwk"
         p = run("-r", str(r), "-e", str(e), "-o", str(o), *extra)
         assert p.returncode == 0, (extra, p.stderr)
         assert o.read_text() == want, extra
         if extra[1] not in ("0",):
             assert "table shard(s) by largest taxon id" in p.stdout and "Finished computing scores." in p.stdout
-            assert ("kept in host memory" in p.stdout) == (extra[-1] != "recount")
+            if extra[1] == "1":
+                assert "every shard stays on its GPU" in p.stdout
+            else:
+                assert ("kept in host memory" in p.stdout) == ("recount" not in extra)
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "x.nwk"), "--table-shards", "2", "-q", str(tmp_path / "x.txt"))
     assert p.returncode == 1 and "need the whole table" in p.stderr
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "y.nwk"), "--table-shards", "2", "--spill", "disk")
     assert p.returncode == 1 and "--spill takes" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ref_kind", ["binary", "multifurcating", "rooted"])
+def test_cpp_cli_table_shards_on_gpus_match_the_oracle(tmp_path, ref_kind):
+    """QuartetScores --gpus N --table-shards K (BASELINE configs[4]'s mode; here N = 1 device, K = 8 shards, shard s on
+    GPU s mod N): every shard counts ALL trees, no table collective, pass-1 sums / minima and the pass-2 candidates are
+    combined over the shards, qs_score_finish once -- and the annotated tree carries the ORACLE's scores, for evaluation
+    trees with collapsed edges and missing taxa, on a binary, a multifurcating and a rooted reference tree; spill to
+    host memory, recount, and --gpus 1 alone with a forced shard count agree."""
+    import numpy as np
+    from quartetscores_amd import synth
+    n = 41
+    rng = np.random.default_rng(4100)
+    ref_nw = synth.random_tree(n, rng, rooted=(ref_kind == "rooted"))
+    if ref_kind == "multifurcating":
+        ref_nw = synth.tree_set(n, 1, 4101, collapse=0.3)[0]
+    trees = synth.tree_set(n, 120, 4102) + synth.tree_set(n, 150, 4103, collapse=0.25, dropout=0.1)
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_text("\n".join(trees) + "\n")
+    want = oracle_comments(ref_nw, e.read_text())
+    assert len(want) >= 10
+    for i, extra in enumerate((["--gpus", "1", "--table-shards", "8"], ["--gpus", "1", "--table-shards", "8", "--spill", "recount"],
+                               ["--table-shards", "8", "--spill", "host"], ["--gpus", "1", "--table-shards", "1"])):
+        o = tmp_path / f"g{i}.nwk"
+        p = run("-r", str(r), "-e", str(e), "-o", str(o), *extra)
+        assert p.returncode == 0, (extra, p.stderr)
+        assert "no table collective" in p.stdout and "Finished computing scores." in p.stdout
+        assert cli_comments(o) == want, extra
+    # more GPUs than the box has: a clean error before any counting
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "z.nwk"), "--gpus", "64", "--table-shards", "64")
+    assert p.returncode == 1 and "device(s) visible" in p.stderr

@@ -200,3 +200,72 @@ def test_score_sharded_sum_min_allgather_plumbing(tmp_path, bif):
         assert set(got) == set(want)
         for k in got:
             assert got[k] == want[k], (r, sorted(k), got[k], want[k])
+
+
+def _table_shard_worker(rank, world, port, n_shards, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulate
+    from quartetscores_amd import distributed, flatten, ranks, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m = 12, 50
+    ref_nw = synth.reference_tree(n, 41)
+    ref = flatten.flatten_reference(ref_nw)
+    trees = synth.tree_set(n, m, 42, collapse=0.2, dropout=0.1)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    full = emulate.counts_from_batch(batch, n)
+    opened = []
+
+    def open_shard(k):
+        # shard k of K by the largest id: the tuples [C(d_lo,4), C(d_hi,4)) of the whole table (every "rank" counted all trees)
+        if k is None:
+            return emulate.ScoreEmu(ref, full[:0], 0)
+        d_lo, d_hi = distributed.shard_of_largest_id(n, n_shards, k)
+        r_lo, r_hi = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
+        opened.append(k)
+        return emulate.ScoreEmu(ref, full[r_lo:r_hi], r_lo)
+    mine = distributed.shards_of_rank(n_shards, world, rank)
+    lq, qp, eqp, is_bif = distributed.score_table_shards(open_shard, mine, ref, device=torch.device("cpu"))
+    # a rank with one shard keeps it between the rounds; with several every shard is opened once per round
+    assert opened == (mine if len(mine) == 1 else mine + mine), (rank, opened)
+    np.save(os.path.join(out_dir, f"lq{rank}.npy"), lq)
+    np.save(os.path.join(out_dir, f"qp{rank}.npy"), qp)
+    np.save(os.path.join(out_dir, f"eqp{rank}.npy"), eqp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 5])
+def test_score_table_shards_over_two_ranks(tmp_path, n_shards):
+    """distributed.score_table_shards (BASELINE configs[4]'s mode: K table shards by largest taxon id, shard s on rank
+    s mod world, no table collective) over 2 gloo ranks with 2, 3 and 5 shards -- ranks own different numbers of shards,
+    the candidate gather is padded -- gives the oracle's scores on every rank (numpy emulation of the score passes,
+    the library's own host finish). Reference scheme: QuartetScoreComputer.hpp:212-371."""
+    from oracle_api import Oracle
+    from quartetscores_amd import flatten, newick, synth
+    world = 2
+    mp.spawn(_table_shard_worker, args=(world, _free_port(), n_shards, str(tmp_path)), nprocs=world, join=True)
+    n = 12
+    ref_nw = synth.reference_tree(n, 41)
+    trees = synth.tree_set(n, 50, 42, collapse=0.2, dropout=0.1)
+    o = Oracle(ref_nw)
+    o.count("\n".join(trees))
+    o.score()
+    want = o.scores_by_bipartition()
+    ref = flatten.flatten_reference(ref_nw)
+    names = ref.names
+    for r in range(world):
+        lq, qp, eqp = (np.load(tmp_path / f"{x}{r}.npy") for x in ("lq", "qp", "eqp"))
+        got = {}
+        for e in range(ref.n_nodes - 1):
+            below = frozenset(x.name for x in newick.preorder(ref.nodes[e + 1]) if x.is_leaf)
+            if len(below) <= 1 or len(below) >= n - 1:
+                continue
+            other = frozenset(names) - below
+            key = below if (len(below) < len(other) or (len(below) == len(other) and min(names) not in below)) else other
+            got[key] = (lq[e + 1], qp[e + 1], eqp[e + 1])
+        assert set(got) == set(want)
+        for k in got:
+            assert got[k] == want[k], (r, sorted(k), got[k], want[k])

@@ -285,6 +285,49 @@ def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, ki
         assert (T.astype(np.uint64) == want).all(), (builder, v)
 
 
+@pytest.mark.parametrize("n,m,bits", [(40, 60, 4), (33, 70, 5), (58, 100, 6), (90, 40, 7)])
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_cooperative_count_kernel_matches_oracle(eng, monkeypatch, n, m, bits, count_bits):
+    """count_bitslice4_kernel (binary full batches; the four waves of a workgroup = four consecutive third ids of one
+    (a,b,d) tile share their M[ab] / M[bd] loads through LDS, shadow tiles pad incomplete groups) forced on at small
+    sizes: whole tables equal to the oracle's for every depth width, both cell widths, a table shard, accumulation over
+    two batches, the two-cell wire output -- and equal to what count_bitslice3_kernel alone produces."""
+    ref_nw = synth.reference_tree(n, 700 + n)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"        # a caterpillar that is not re-rooted has depth n - 2: forces the instance with `bits` depth bits
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    trees = ([cat + ";"] * 2 if bits > 4 else []) + synth.tree_set(n, m - (2 if bits > 4 else 0), 800 + n)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=(bits == 4))   # re-centred random trees: 4 bits
+    assert ((1 << (bits - 1)) <= int(batch.adj_depth.max()) or bits == 4) and int(batch.adj_depth.max()) < (1 << bits)
+    want = oracle_counts(ref_nw, trees).counts()
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_COOP, 2)
+    _, T_plain = gpu_table(eng, ref, batch, count_bits)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_COOP, 1)
+    ctx, T = gpu_table(eng, ref, batch, count_bits)
+    v = ctx.last_count_variant()
+    assert "binary_full" in v and "coop" in v and f"bitslice_b{bits}" in v, v
+    assert (T.astype(np.uint64) == want).all(), v
+    assert (T == T_plain).all()
+    # two batches accumulate (the second launch reads-modifies-writes)
+    ctx2 = eng.Context(ref.n_taxa, count_bits)
+    ctx2.table_alloc()
+    half = m // 2
+    ctx2.count_trees(batch.slice(0, half), eng.QS_ALGO_GATHER)
+    ctx2.count_trees(batch.slice(half, m), eng.QS_ALGO_GATHER)
+    ctx2.sync()
+    assert (ctx2.table_download().astype(np.uint64) == want).all()
+    # a table shard: d in [d_lo, n)
+    if n >= 30:
+        d_lo = n - 9
+        ctx3 = eng.Context(ref.n_taxa, count_bits, d_lo=d_lo, d_hi=n)
+        ctx3.table_alloc()
+        ctx3.count_trees(batch, eng.QS_ALGO_GATHER)
+        ctx3.sync()
+        lo = ranks.n_quartets(d_lo)
+        assert (ctx3.table_download().astype(np.uint64) == want[lo:]).all()
+
+
 def test_very_deep_trees_fall_back_to_swar_u16(eng):
     n = 150
     ref_nw = synth.reference_tree(n, 19)

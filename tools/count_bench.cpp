@@ -59,6 +59,7 @@ int main(int argc, char **argv) {
         const uint32_t dlo = getenv("CB_DLO") ? (uint32_t)atoi(getenv("CB_DLO")) : 0, dhi = getenv("CB_DHI") ? (uint32_t)atoi(getenv("CB_DHI")) : 0;
         if (qs_create(&c, n, bits, 0, 0, nullptr, dlo, dhi) != QS_OK) { fprintf(stderr, "qs_create: %s\n", qs_last_error(nullptr)); return 1; }
         if (const char *sb = getenv("CB_SLICE_BYTES")) qs_set_tuning(c, QS_TUNE_PANEL_SLICE_BYTES, (uint64_t)atoll(sb));
+        if (const char *co = getenv("CB_COOP")) qs_set_tuning(c, QS_TUNE_COOP, (uint64_t)atoll(co));
         if (const char *to = getenv("CB_TILE_ORDER")) if (qs_set_tuning(c, QS_TUNE_TILE_ORDER, (uint64_t)atoll(to)) != QS_OK) { fprintf(stderr, "tile order: %s\n", qs_last_error(c)); return 1; }
         if (qs_table_alloc(c) != QS_OK) { fprintf(stderr, "alloc: %s\n", qs_last_error(c)); return 1; }
         qs_device_batch *db = nullptr;
