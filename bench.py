@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true", help="skip the e2e legs (CLI child process; steps with the host-array upload inside)")
     ap.add_argument("--no-impl-check", action="store_true", help="skip the on-device comparison with the byte-SWAR implementation")
     ap.add_argument("--nni", action="store_true", help="evaluation trees = reference tree + Poisson(n/8) random NNIs (concentrated counts)")
+    ap.add_argument("--shape", choices=["random", "ladder"], default="random",
+                    help="ladder: the reference tree is a caterpillar and the evaluation trees are that ladder + Poisson(n/8) NNIs (deep trees: 9 depth bits at 512 taxa)")
     ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees; numpy generator, small sizes)")
     ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees; numpy generator, small sizes)")
     ap.add_argument("--reduce", choices=["scatter", "all"], default="scatter",
@@ -286,7 +288,7 @@ def main():
     # ---- workload -----------------------------------------------------------------------------------------
     cfg_no = args.config or (2 if world == 1 else 3)
     cfg = dict(CONFIGS[cfg_no])
-    custom = bool(args.taxa or args.trees or args.count_bits or args.table_shards or args.split_trees >= 0)
+    custom = bool(args.taxa or args.trees or args.count_bits or args.table_shards or args.split_trees >= 0 or args.shape != "random")
     n = args.taxa or cfg["taxa"]
     m_total = args.trees or cfg["trees"]
     count_bits = args.count_bits or cfg["bits"]
@@ -301,7 +303,14 @@ def main():
     seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or shards > 1) else rank)
     binary_full_trees = not (args.collapse or args.dropout)
     t_gen = time.perf_counter()
-    ref_nw = native_ingest.synth_trees(n, 1, seed_ref).decode().strip()
+    if args.shape == "ladder":
+        lad = "(t0,t1)"
+        for i in range(2, n - 2):
+            lad = "(" + lad + f",t{i})"
+        ref_nw = f"({lad},t{n - 2},t{n - 1});"
+        args.nni = True
+    else:
+        ref_nw = native_ingest.synth_trees(n, 1, seed_ref).decode().strip()
     ref = flatten.flatten_reference(ref_nw)
     if binary_full_trees:
         all_text = native_ingest.synth_trees(n, m_total if split else m, seed_set, kind="nni" if args.nni else "random",
@@ -664,13 +673,13 @@ def main():
     # The batch is counted in depth classes (B = bits of a tree's deepest LCA): "bitslice_b4x2:2358+bitslice_b5x2:7642"
     def ops_of(bits_):
         return {"binary_full": 2 * (bits_ + 1) + 2, "general_full": 3 * (bits_ + 1) + 4, "partial": 3 * (bits_ + 1) + 8}[mode]
-    classes = [(int(b_), int(cnt_) if cnt_ else m) for b_, cnt_ in re.findall(r"bitslice_b(\d)(?:x2)?(?::(\d+))?", variant)]
+    classes = [(int(b_), int(cnt_) if cnt_ else m) for b_, cnt_ in re.findall(r"bitslice_b(\d+)(?:x2)?(?::(\d+))?", variant)]
     depth_bits = max((b_ for b_, _ in classes), default=None)
     ops32 = None
     if classes and "depth_u" not in variant and mode:
         ops32 = sum(ops_of(b_) * cnt_ for b_, cnt_ in classes) / float(sum(cnt_ for _, cnt_ in classes))
     wl_name = (f"configs[{cfg_no}]" if not custom else "custom")
-    workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}")
+    workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'ladder' if args.shape == 'ladder' else 'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}")
     out = {
         "metric": "quartets counted/sec",
         "value": value,
@@ -687,7 +696,7 @@ def main():
         "config": {
             "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " per rank" if world > 1 else "")
                          + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
-                         + (", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else f", collapse {args.collapse} dropout {args.dropout}")
+                         + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else f", collapse {args.collapse} dropout {args.dropout}")
                          + f", seeds {seed_ref}/{seed_set}")[:100],
             "quartets": nq_all,
             "quartets_this_rank": nq,

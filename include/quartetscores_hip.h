@@ -170,6 +170,8 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_TABLE_TREES 8u        /* number of trees behind a table this context did not count itself (reduced over GPUs, uploaded,
                                        * attached or viewed): sizes the log table of the device QIC so that every count takes the
                                        * table path (speed only; scores never depend on it). 0 = what the context counted (default) */
+#define QS_TUNE_SCORE_PASSES 10u      /* qs_score: 0 = single read of the table (default: pass 1 logs the candidates, a filter over the log
+                                       * replaces pass 2), 1 = two passes (A/B and tests; also taken by itself when the log overflows) */
 #define QS_TUNE_COOP 9u               /* binary full batches: 1 = run the tiles with two a-blocks through count_bitslice4_kernel, whose
                                        * workgroups (four consecutive third ids of one (a,b,d) tile) share their panel loads through
                                        * LDS; 0 / 2 = off (default: the barrier it needs costs more than the loads it saves) */
@@ -212,6 +214,12 @@ int qs_table_pack16x2(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
 /* destination of QS_COUNT_WIRE16X2 (table_tuples 32-bit words in caller-owned device memory); NULL detaches */
 int qs_wire_attach(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
 int qs_unpack16x2(qs_ctx *ctx, const void *src_device, uint64_t n_tuples, uint32_t total_trees, void *dst_device);
+/* The same two-cell format with 32-bit cells, for totals of 65536 trees and more (BASELINE configs[3]: 100 000 trees over
+ * 8 GPUs): qs_table_pack32x2 writes (n0, n1) per tuple = 8 bytes instead of 12 on the wire, qs_unpack32x2 restores
+ * [rank][3] u32 tuples with n2 = total_trees - n0 - n1. A tuple that does not sum to the number of trees (the batch was
+ * not binary with all taxa) raises the flag qs_sync reports as QS_ERR_STATE. */
+int qs_table_pack32x2(qs_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+int qs_unpack32x2(qs_ctx *ctx, const void *src_device, uint64_t n_tuples, uint64_t total_trees, void *dst_device);
 
 /* ---- counting (QuartetCounterLookup::countQuartets) ------------------------------------ */
 
@@ -317,7 +325,7 @@ int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 int qs_last_count_launches(const qs_ctx *ctx);
 /* Phases of the most recent qs_score call in milliseconds: [0] the whole call (host clock), [1] set-up (accumulator
  * allocation, reference tree + LCA matrix, log table: near zero once cached in the context), [2] pass 1 and [3] pass 2
- * (HIP events on the context's stream), [4] host wait for the passes incl. the overflow pass and the accumulators' way
+ * (HIP events on the context's stream; [3] = the filter over pass 1's candidate log in the default single-read mode), [4] host wait for the passes incl. the overflow pass and the accumulators' way
  * back, [5] qs_score_finish (host libm + min-propagation; QuartetScoreComputer.hpp:448-454,484-489). */
 int qs_last_score_ms(qs_ctx *ctx, float out_ms[6]);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */

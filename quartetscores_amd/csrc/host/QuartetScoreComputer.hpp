@@ -60,8 +60,9 @@ inline size_t countEvalTrees(const std::string &evalTreesPath) { return loadEval
 struct DeviceOptions {
     int device = 0;
     uint32_t algo = QS_ALGO_AUTO;
-    size_t batch_trees = 16384;  // trees per device batch: one batch = one set of panel slices (a smaller batch means more launches,
-                                 // each of which reads and writes the whole table); the next batch is parsed while this one counts
+    size_t batch_trees = 4096;   // trees per device batch = 128 groups of 32 = one panel slice = one launch of the count kernel (each
+                                 // launch reads and writes the whole table once); batch k+1 is parsed and flattened on the host
+                                 // threads while batch k counts, so only the first batch's parse is exposed
     unsigned ingest_threads = 0; // host threads that parse + flatten (0 = hardware concurrency); the CLI's -t
     bool qp_exact64 = false;
     bool root_as_edge = false;   // QS_SCORE_ROOT_AS_EDGE: a degree-2 root as a subdivision of one edge (not the reference's quirk Q5)

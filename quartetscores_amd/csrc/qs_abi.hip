@@ -116,6 +116,12 @@ struct qs_ctx {
     float score_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t score_ev[3] = {nullptr, nullptr, nullptr};
     uint64_t table_trees_hint = 0;               // QS_TUNE_TABLE_TREES: trees behind an attached / uploaded / viewed table
+    // single-read scoring (qs_score): pass 1 logs candidate (node pair, triple) records, score_log_kernel filters them
+    unsigned long long *score_log = nullptr;     // log_cap records of 4 words + 1 word counter behind them
+    uint64_t score_log_cap = 0;
+    bool score_log_active = false;               // set by qs_score around its pass 1
+    uint32_t tune_score_passes = 0;              // QS_TUNE_SCORE_PASSES: 0 = single read (default), 1 = two passes over the table
+    uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
 };
 
 static thread_local std::string g_create_err;   // per thread: qs_create of several contexts may run concurrently (multi_gpu.hpp)
@@ -327,6 +333,9 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             return QS_OK;
         case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
         case QS_TUNE_TABLE_TREES: c->table_trees_hint = value; return QS_OK;
+        case QS_TUNE_SCORE_PASSES:
+            if (value > 1) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_PASSES takes 0 (single read) or 1 (two passes)");
+            c->tune_score_passes = (uint32_t)value; return QS_OK;
         case QS_TUNE_COOP:
             if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_COOP takes 0 (default: off), 1 (on) or 2 (off)");
             if (c->tune_coop != (uint32_t)value) {   // the launch lists depend on it: rebuild on next use
@@ -441,6 +450,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (BatchSlab &sl : c->slabs) { (void)hipFree(sl.p); if (sl.last_use) (void)hipEventDestroy(sl.last_use); }
     for (hipEvent_t e : c->score_ev) if (e) (void)hipEventDestroy(e);
+    if (c->score_log) (void)hipFree(c->score_log);
     delete c->ref_cache;
     delete c;
 }
@@ -450,6 +460,7 @@ extern "C" void qs_destroy(qs_ctx *c) {
 // kernel for binary batches (12 M slots at 512 taxa: ~60 ms of host work + a 47 MB copy) and the pair-depth panel for a
 // batch of n_trees_hint trees. Purely an optimisation: qs_count_batch builds whatever is missing. The reference does the
 // equivalent set-up in the table's constructor (QuartetCounterLookup.hpp:245-273).
+static size_t Stager_padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }   // = Stager::padded (batches, below)
 extern "C" int qs_prepare(qs_ctx *c, uint64_t n_trees_hint) {
     if (!c) return QS_ERR_ARG;
     QS_HIP(c, hipSetDevice(c->device));
@@ -461,6 +472,27 @@ extern "C" int qs_prepare(qs_ctx *c, uint64_t n_trees_hint) {
         const uint32_t groups = slice_groups(c, group_bytes, (uint32_t)std::min<uint64_t>((n_trees_hint + 31) / 32, 1u << 20), order != nullptr);
         if (hipMalloc(&c->panel, (size_t)groups * group_bytes) == hipSuccess) c->panel_bytes = (size_t)groups * group_bytes;
         else { c->panel = nullptr; (void)hipGetLastError(); }       // not fatal here: the count reports it if it persists
+    }
+    if (n_trees_hint) {
+        // both pinned staging buffers and one device slab for batches of that many full trees (qs_batch_upload's Stager
+        // would allocate them on first use: hipHostMalloc + hipMalloc, tens of ms in front of the first count)
+        const uint64_t nt = std::min<uint64_t>(n_trees_hint, 1u << 22);
+        const size_t need = Stager_padded(((size_t)nt + 1) * 4) + 2 * Stager_padded((size_t)nt * c->n * 2) + Stager_padded((size_t)nt * 4);
+        if (!c->copy_stream) QS_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int slot = 0; slot < 2; ++slot)
+            if (c->pin_cap[slot] < need) {
+                if (c->pin[slot]) { (void)hipHostFree(c->pin[slot]); c->pin[slot] = nullptr; c->pin_cap[slot] = 0; }
+                const size_t cap = need + need / 4 + 4096;
+                if (hipHostMalloc(&c->pin[slot], cap, hipHostMallocDefault) == hipSuccess) c->pin_cap[slot] = cap;
+                else { c->pin[slot] = nullptr; (void)hipGetLastError(); }
+            }
+        bool have = false;
+        for (const BatchSlab &sl : c->slabs) have = have || sl.cap >= need;
+        if (!have && c->slabs.size() < 4) {
+            BatchSlab sl;
+            sl.cap = need + need / 4;
+            if (hipMalloc(&sl.p, sl.cap) == hipSuccess) c->slabs.push_back(sl); else (void)hipGetLastError();
+        }
     }
     return QS_OK;
 }
@@ -561,6 +593,26 @@ extern "C" int qs_unpack16x2(qs_ctx *c, const void *src_device, uint64_t n_tuple
     if (total_trees > 0xFFFFu) return fail(c, QS_ERR_OVERFLOW, "qs_unpack16x2: more than 65535 trees");
     QS_HIP(c, hipSetDevice(c->device));
     QS_HIP(c, launch_unpack16x2(c->stream, src_device, dst_device, n_tuples, total_trees, c->dev_flags + 3));
+    return QS_OK;
+}
+
+// Two-cell wire format with 32-bit cells: (n0, n1) per tuple, for batches of binary trees holding all taxa whose total
+// over the ranks reaches 65536 trees (8 bytes per quartet on the wire instead of 12).
+extern "C" int qs_table_pack32x2(qs_ctx *c, void *dst_device, uint64_t dst_bytes) {
+    if (!c || !c->table || !dst_device) return fail(c, QS_ERR_STATE, "qs_table_pack32x2: no table / NULL destination");
+    if (c->count_bits != 32) return fail(c, QS_ERR_ARG, "qs_table_pack32x2: needs a 32-bit table");
+    if (c->trees_counted > 0xFFFFFFFFull) return fail(c, QS_ERR_OVERFLOW, "qs_table_pack32x2: more than 2^32 - 1 trees counted");
+    if (dst_bytes < c->n_tuples * 8) return fail(c, QS_ERR_ARG, "qs_table_pack32x2: destination smaller than " + std::to_string(c->n_tuples * 8) + " bytes");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, launch_pack32x2(c->stream, c->table, dst_device, c->n_tuples, (uint32_t)c->trees_counted, c->dev_flags + 3));
+    return QS_OK;
+}
+
+extern "C" int qs_unpack32x2(qs_ctx *c, const void *src_device, uint64_t n_tuples, uint64_t total_trees, void *dst_device) {
+    if (!c || !src_device || !dst_device) return fail(c, QS_ERR_ARG, "qs_unpack32x2: NULL argument");
+    if (total_trees > 0xFFFFFFFFull) return fail(c, QS_ERR_OVERFLOW, "qs_unpack32x2: more than 2^32 - 1 trees");
+    QS_HIP(c, hipSetDevice(c->device));
+    QS_HIP(c, launch_unpack32x2(c->stream, src_device, dst_device, n_tuples, (uint32_t)total_trees, c->dev_flags + 3));
     return QS_OK;
 }
 
@@ -700,19 +752,19 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     d.total_leaves = nt ? hb->leaf_off[nt] : 0;
     d.max_depth = max_depth; d.all_full = all_full && nt > 0; d.all_binary = all_binary && nt > 0;
     // Depth classes. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B of the deepest LCA of the
-    // trees it is given (2(B+1)+2 instructions, B >= 4), and one deep tree would put the whole batch on B = 7 or on the
-    // byte-SWAR kernel (4x slower). Trees are therefore counted class by class: B = 4, 5, 6, 7 (6 is the limit with
-    // missing taxa) and "deeper" (SWAR). A class below the batch's top class that holds fewer than max(1024, 10 %) of
-    // the trees is merged upwards: every class costs at least one more panel slice = one more pass over the table.
-    // (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
+    // trees it is given (2(B+1)+2 instructions, B >= 4), and one deep tree would put the whole batch on its B. Trees are
+    // therefore counted class by class: B = 4 .. 10 (LCA depths below 1024: ladder-like trees of up to ~2000 taxa) and
+    // "deeper" (byte-SWAR kernel, 16-bit depths). A class below the batch's top class that holds fewer than
+    // max(1024, 10 %) of the trees is merged upwards: every class costs at least one more panel slice = one more pass
+    // over the table. (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
     std::vector<uint32_t> order_host;
     {
-        const uint32_t top_bits = d.all_full ? 7u : 6u;
-        auto cls_of = [&](uint32_t depth) { uint32_t bb = 1; while ((1u << bb) <= depth) ++bb; return bb <= 4 ? 4u : (bb <= top_bits ? bb : 8u); };
-        uint32_t cnt[9] = {0}, mx[9] = {0};
+        constexpr uint32_t top_bits = 10, deep = 11;   // class id = depth bits; `deep` = beyond the bit-sliced instances
+        auto cls_of = [&](uint32_t depth) { uint32_t bb = 1; while ((1u << bb) <= depth) ++bb; return bb <= 4 ? 4u : (bb <= top_bits ? bb : deep); };
+        uint32_t cnt[12] = {0}, mx[12] = {0};
         std::vector<uint8_t> cls(nt);
         for (uint32_t t = 0; t < nt; ++t) { cls[t] = (uint8_t)cls_of(tree_depth[t]); cnt[cls[t]]++; mx[cls[t]] = std::max<uint32_t>(mx[cls[t]], tree_depth[t]); }
-        uint32_t remap[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+        uint32_t remap[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
         const uint32_t small = std::max<uint32_t>(1024, nt / 10);
         for (uint32_t bb = 4; bb < top_bits; ++bb) {
             if (cnt[bb] == 0 || cnt[bb] >= small) continue;
@@ -723,8 +775,8 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
         }
         auto final_cls = [&](uint32_t k) { while (remap[k] != k) k = remap[k]; return k; };
         d.n_classes = 0;
-        uint32_t run = 0, start[9] = {0};
-        for (uint32_t k = 4; k <= 8; ++k) {
+        uint32_t run = 0, start[12] = {0};
+        for (uint32_t k = 4; k <= deep; ++k) {
             if (cnt[k] == 0) continue;
             start[k] = run; run += cnt[k];
             d.class_bits[d.n_classes] = k; d.class_end[d.n_classes] = run; d.class_max_depth[d.n_classes] = mx[k];
@@ -795,7 +847,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     const bool overwrite = (algo & QS_COUNT_OVERWRITE) != 0;
     const uint32_t base_algo = algo & 0xFFu;
     if (base_algo != QS_ALGO_AUTO && base_algo != QS_ALGO_GATHER) return fail(c, QS_ERR_ARG, "QS_COUNT_WIRE16X2 needs the gather algorithm");
-    if (algo & QS_COUNT_TIMED) return fail(c, QS_ERR_ARG, "QS_COUNT_WIRE16X2 cannot be combined with QS_COUNT_TIMED");
+    const bool timed = (algo & QS_COUNT_TIMED) != 0;
     QS_HIP(c, hipSetDevice(c->device));
     if (d.n_trees == 0) {
         if (overwrite) { QS_HIP(c, hipMemsetAsync(c->wire_out, 0, c->n_tuples * 4, c->stream)); c->wire_trees = 0; }
@@ -806,12 +858,14 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     if (d.ready) QS_HIP(c, hipStreamWaitEvent(c->stream, d.ready, 0));
     if ((overwrite ? 0 : c->wire_trees) + d.n_trees > 0xFFFFull)
         return fail(c, QS_ERR_OVERFLOW, "QS_COUNT_WIRE16X2: more than 65535 trees do not fit 16-bit cells");
-    if (d.class_bits[d.n_classes - 1] > 7) return fail(c, QS_ERR_UNSUPPORTED, "QS_COUNT_WIRE16X2: tree depth needs more than 7 bits; count into the table instead");
+    if (d.class_bits[d.n_classes - 1] > 10) return fail(c, QS_ERR_UNSUPPORTED, "QS_COUNT_WIRE16X2: tree depth needs more than 10 bits; count into the table instead");
     CountGeometry g;
     g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo; g.n_dblk = c->n_dblk;
     g.total_tiles = c->total_tiles3; g.dprefix = c->dprefix3; g.cprefix = c->cprefix3;
     { int rc_o = tile_order(c, 0, &g.perm); if (rc_o != QS_OK) return rc_o; }
     g.perm_coop = c->perm_coop; g.n_coop = c->n_coop; g.perm_rest = c->perm_rest; g.n_rest = c->n_rest;
+    c->ev_used = 0;
+    if (timed) QS_HIP(c, mark(c, 0));
     bool first = true;
     c->variant = "gather/binary_full/bitslice_";
     for (uint32_t k = 0; k < d.n_classes; ++k) {
@@ -833,8 +887,10 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
             sub.slot0 = s_lo + t0;
             sub.n_trees = nt;
             QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, false, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
+            if (timed) QS_HIP(c, mark(c, 0));
             QS_HIP(c, launch_count_bitslice3(c->stream, g, c->panel, (int)depth_bits, MODE_BINARY_FULL, nch, nt, nullptr, 32, c->dev_flags,
                                              overwrite && first, c->wire_out));
+            if (timed) QS_HIP(c, mark(c, 1));
             first = false;
         }
         c->variant += (k ? "+b" : "b") + std::to_string(depth_bits) + "x2" + (d.n_classes > 1 ? ":" + std::to_string(s_hi - s_lo) : "");
@@ -842,7 +898,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
     c->variant += "/wire_u16x2";
     if (c->n_coop) c->variant += "/coop4";
     c->wire_trees = (overwrite ? 0 : c->wire_trees) + d.n_trees;
-    c->last_timed = false;
+    c->last_timed = timed;
     return QS_OK;
 }
 
@@ -879,16 +935,16 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
         // One (panel build + count kernel) per slice of every depth class of the batch (classes: qs_batch_upload; slices:
         // slice_groups). With QS_IMPL_SWAR the whole batch is one class of the byte-SWAR kernel.
-        const uint32_t top_bits = mode == MODE_PARTIAL ? 6u : 7u;
+        const uint32_t top_bits = 10u;
         if (c->tune_gather_impl == QS_IMPL_BITSLICE && d.class_bits[d.n_classes - 1] > top_bits)
-            return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 7 (6 with missing taxa) bits");
+            return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 10 bits");
         const bool all_swar = c->tune_gather_impl == QS_IMPL_SWAR;
         const uint32_t n_cls = all_swar ? 1u : d.n_classes;
         bool first = true;
         std::string names;
         for (uint32_t k = 0; k < n_cls; ++k) {
             const uint32_t s_lo = (all_swar || k == 0) ? 0u : d.class_end[k - 1], s_hi = all_swar ? d.n_trees : d.class_end[k];
-            const uint32_t depth_bits = all_swar ? 8u : d.class_bits[k];
+            const uint32_t depth_bits = all_swar ? 11u : d.class_bits[k];   // 11 = beyond the bit-sliced instances
             const uint32_t cls_max_depth = all_swar ? d.max_depth : d.class_max_depth[k];
             const bool use_bitslice = depth_bits <= top_bits;
             // bit-sliced classes run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane)
@@ -1299,7 +1355,11 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
     { int rc_b = ensure_bundle_plan(c, sd, 1); if (rc_b != QS_OK) return rc_b; }
-    QS_HIP(c, launch_score_pass1(c->stream, sd, c->tune_score_kernel, c->n_cu, c->bundle[0].part_lo, c->bundle[0].part_n, c->bundle[0].n_parts));
+    if (c->score_log_active && c->tune_score_kernel == 0 && c->bundle[0].n_parts == 0 && c->score_log) {
+        sd.list = c->score_log; sd.list_count = c->score_log + 4 * c->score_log_cap; sd.list_cap = c->score_log_cap;
+        QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+    } else c->score_log_active = false;   // (partial rows / scan kernel: the caller falls back to two passes)
+    QS_HIP(c, launch_score_pass1(c->stream, sd, c->tune_score_kernel, c->n_cu, c->bundle[0].part_lo, c->bundle[0].part_n, c->bundle[0].n_parts, c->tune_score_tol));
     // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
     if (c->root_pairs_dev) QS_HIP(c, launch_root_pair_sums(c->stream, sd, c->root_pairs_dev, (uint32_t)R.root_pairs.size(), R.root_items));
     return QS_OK;   // asynchronous on the context's stream
@@ -1543,12 +1603,46 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
         if (rc0 != QS_OK) return rc0;
     }
     c->score_ms[1] = ms_since(t_all);
+    // Single-read scoring (default): pass 1 also logs every quartet that is near-minimal for its node pair AT THAT MOMENT (a
+    // superset of the finally near-minimal ones), and a filter over the log replaces the second pass over the table
+    // (QuartetScoreComputer.hpp:417-469 evaluates log_score of every quartet once, too). Two passes if the log overflows.
+    c->last_score_log = 0;
+    if (c->tune_score_passes == 0 && c->tune_score_kernel == 0) {
+        const uint64_t want_cap = 1ull << 22;                       // 4 M records = 128 MB
+        if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1) * 8) == hipSuccess) c->score_log_cap = want_cap;
+        else if (!c->score_log) (void)hipGetLastError();
+        c->score_log_active = c->score_log != nullptr;
+    }
     QS_HIP(c, hipEventRecord(c->score_ev[0], c->stream));
     int rc = qs_score_pass1(c, ref, (int64_t *)sums.p, (int64_t *)mn.p);
+    const bool logged = c->score_log_active;
+    c->score_log_active = false;
     if (rc != QS_OK) return rc;
     QS_HIP(c, hipEventRecord(c->score_ev[1], c->stream));
-    rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);
-    if (rc != QS_OK) return rc;
+    bool need_pass2 = true;
+    if (logged) {
+        unsigned long long n_rec = 0;
+        QS_HIP(c, hipMemcpyAsync(&n_rec, c->score_log + 4 * c->score_log_cap, 8, hipMemcpyDeviceToHost, c->stream));
+        QS_HIP(c, hipStreamSynchronize(c->stream));
+        if (n_rec <= c->score_log_cap) {
+            const RefHost *Rp = nullptr;
+            rc = get_ref(c, ref, true, &Rp);
+            if (rc != QS_OK) return rc;
+            QS_HIP(c, hipMemsetAsync(cand.p, 0xFF, np * kCand * 8, c->stream));
+            QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
+            ScoreDevice sd;
+            fill_score_device(c, *Rp, c->ref_lca_dev, sd);
+            sd.pair_min = (long long *)mn.p; sd.pair_cand = (unsigned long long *)cand.p;
+            sd.list = c->score_log; sd.list_cap = c->score_log_cap;
+            QS_HIP(c, launch_score_log(c->stream, sd, c->tune_score_tol, n_rec));
+            c->last_score_log = n_rec;
+            need_pass2 = false;
+        }
+    }
+    if (need_pass2) {
+        rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);
+        if (rc != QS_OK) return rc;
+    }
     QS_HIP(c, hipEventRecord(c->score_ev[2], c->stream));
     const clk::time_point t_ov = clk::now();
     int64_t *extra = nullptr;

@@ -462,7 +462,9 @@ hipError_t launch_count_gather(hipStream_t s, const CountGeometry &g, const void
 // so one (quartet, 32 trees) step costs 2(B+1) boolean ops + 2 popcounts instead of 8 x 7 ops.
 // The third topology of the general modes is the same comparison on  M[ad]-M[cd]  vs  M[ab]-M[bc].
 
-constexpr int kBitWords = 8;   // words per bit-plane element (32 bytes)
+constexpr int kBitWords = 12;  // words of a Planes value in registers: up to 11 planes (R / L of 10-bit depths) + the presence word
+constexpr int kPres = kBitWords - 1; // where the presence word ("pair present in tree t", partial batches) travels in registers
+constexpr int kMaxDepthBits = 10;    // deepest bit-sliced class: LCA depths below 1024 (deeper trees: byte-SWAR kernel)
 constexpr int kBitTrees = 32;  // trees per element
 
 // Bit-plane panel, general builder (any n). Workgroup = (group of 32 trees, 4096 pairs), 16 waves. The 32 trees are
@@ -476,7 +478,7 @@ constexpr int kBitTrees = 32;  // trees per element
 constexpr int kBPThreads = 1024;
 constexpr int kBPPPT = 4;      // pairs per thread
 constexpr int kBPPB = kBPThreads * kBPPPT;
-template <bool PARTIAL, int NWC>
+template <bool PARTIAL, int NWC, typename DT>
 __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32_t *__restrict__ leaf_off,
                                                                     const uint32_t *__restrict__ order, uint32_t slot0,
                                                                     const uint16_t *__restrict__ leaf_ids,
@@ -508,12 +510,12 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
             if (slot >= n_trees) continue;
             const uint32_t t = order ? order[slot0 + slot] : slot0 + slot;
             uint16_t *pos = reinterpret_cast<uint16_t *>(smem + (size_t)j * tree_bytes); // [n]
-            uint8_t *st = reinterpret_cast<uint8_t *>(pos + n);                          // [levels][n]
+            DT *st = reinterpret_cast<DT *>(pos + n);                                    // [levels][n]
             const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
             for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
             for (uint32_t i = lane; i < L; i += kWave) {
                 pos[leaf_ids[base + i]] = (uint16_t)i;
-                st[i] = (uint8_t)adj_depth[base + i];
+                st[i] = (DT)adj_depth[base + i];
             }
             for (uint32_t k = 1; k < levels; ++k) {
                 const uint32_t half = 1u << (k - 1), span = 1u << k;
@@ -528,12 +530,12 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
             if (slot >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
                 if (!PARTIAL) {
 #pragma unroll
-                    for (int q = 0; q < kBPPPT; ++q) w[q][7] |= 1u << bit;
+                    for (int q = 0; q < kBPPPT; ++q) w[q][kPres] |= 1u << bit;
                 }
                 continue;
             }
             const uint16_t *pos = reinterpret_cast<const uint16_t *>(smem + (size_t)j * tree_bytes);
-            const uint8_t *st = reinterpret_cast<const uint8_t *>(pos + n);
+            const DT *st = reinterpret_cast<const DT *>(pos + n);
 #pragma unroll
             for (int q = 0; q < kBPPPT; ++q) {
                 const uint32_t a = pos[px[q]], b = pos[py[q]];
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
                 const uint32_t val = min((uint32_t)st[k * n + lo], (uint32_t)st[k * n + hi - (1u << k)]);
 #pragma unroll
                 for (int pl = 0; pl < kPlanes; ++pl) w[q][pl] |= ((val >> pl) & 1u) << bit;
-                w[q][7] |= 1u << bit;
+                w[q][kPres] |= 1u << bit;
             }
         }
     }
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
     for (int q = 0; q < kBPPPT; ++q) {
         const uint32_t p = p0 + q * kBPThreads + tid;
         if (p >= npairs) continue;
-        if (PARTIAL) w[q][NWC - 1] = w[q][7];
+        if (PARTIAL) w[q][NWC - 1] = w[q][kPres];
         reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
         uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
 #pragma unroll
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
     for (int j = 0; j < kBitTrees; ++j) {
         const uint32_t t = g * kBitTrees + j;
         if (t >= n_trees) { // padding trees: depth 0 everywhere (resolve nothing), absent in partial mode
-            if (!PARTIAL) w[7] |= 1u << j;
+            if (!PARTIAL) w[kPres] |= 1u << j;
             continue;
         }
         const uint16_t *pos = reinterpret_cast<const uint16_t *>(smem + (size_t)j * tree_bytes);
@@ -628,9 +630,9 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
         const uint32_t val = min((uint32_t)st[k * n + lo], (uint32_t)st[k * n + hi - (1u << k)]);
 #pragma unroll
         for (int q = 0; q < kPlanes; ++q) w[q] |= ((val >> q) & 1u) << j;
-        w[7] |= 1u << j;
+        w[kPres] |= 1u << j;
     }
-    if (PARTIAL) w[NWC - 1] = w[7];
+    if (PARTIAL) w[NWC - 1] = w[kPres];
     char *grp = reinterpret_cast<char *>(Pb) + (size_t)g * npairs * NWC * 4;
     reinterpret_cast<uint4 *>(grp)[p] = make_uint4(w[0], w[1], w[2], w[3]);
     uint32_t *hi = reinterpret_cast<uint32_t *>(grp + (size_t)npairs * 16) + (size_t)p * (NWC > 4 ? NWC - 4 : 0);
@@ -642,7 +644,9 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
                                  uint32_t n_groups, uint32_t compact_nw, bool force_general) {
     const uint32_t npairs = (uint32_t)binom2(n);
     const uint32_t levels = panel_levels(n);
-    {   // all 32 trees' tables resident at once -> the small-n kernel
+    const uint32_t planes = compact_nw - (partial ? 1u : 0u);   // depth bits the panel carries
+    if (compact_nw > (uint32_t)kMaxDepthBits + (partial ? 1u : 0u)) return hipErrorInvalidValue;
+    if (planes <= 7 && compact_nw <= 7) {   // all 32 trees' tables (u8 depths) resident at once -> the small-n kernel
         const uint32_t tree_bytes = (n * 2 + levels * n + 3) & ~3u;
         const size_t lds_small = (size_t)kBitTrees * tree_bytes;
         if (lds_small <= 96 * 1024 && !force_general) { // force_general: qs_set_tuning(QS_TUNE_PANEL_KERNEL, 1) (tests / A-B runs)
@@ -670,16 +674,18 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
             return hipGetLastError();
         }
     }
-    // general builder: as many trees per round as fit in 128 KB of LDS (a power of two, at most 16 = one per wave)
-    const uint32_t tree_bytes = (n * 2 + levels * n + 3) & ~3u;
+    // general builder: as many trees per round as fit in 128 KB of LDS (a power of two, at most 16 = one per wave); the
+    // range-minimum tables hold u8 depths up to 7 planes and u16 depths beyond (deep trees: 8..10 planes)
+    const uint32_t dbytes = planes <= 7 ? 1u : 2u;
+    const uint32_t tree_bytes = (n * 2 + levels * n * dbytes + 3) & ~3u;
     uint32_t per_round = 16;
     while (per_round > 1 && (size_t)per_round * tree_bytes > 128 * 1024) per_round >>= 1;
     const size_t lds = (size_t)per_round * tree_bytes;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((npairs + kBPPB - 1) / kBPPB, n_groups), block(kBPThreads);
-#define QS_BPG(PART, NWC)                                                                                          \
+#define QS_BPG(PART, NWC, DT)                                                                                      \
     do {                                                                                                           \
-        auto k = build_bitpanel_kernel<PART, NWC>;                                                                 \
+        auto k = build_bitpanel_kernel<PART, NWC, DT>;                                                             \
         if (lds > 48 * 1024) {                                                                                     \
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                         \
@@ -687,15 +693,27 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
         hipLaunchKernelGGL(k, grid, block, lds, s, b.leaf_off, b.tree_order, b.slot0, b.leaf_ids, b.adj_depth, b.n_trees, n, npairs, levels, \
                            tree_bytes, per_round, (uint4 *)panel);                                                 \
     } while (0)
-    if (partial) { // planes + presence word: 5..7
-        if (compact_nw <= 5) QS_BPG(true, 5);
-        else if (compact_nw == 6) QS_BPG(true, 6);
-        else QS_BPG(true, 7);
+    if (partial) { // planes + presence word: 5..11
+        switch (compact_nw <= 5 ? 5u : compact_nw) {
+            case 5: QS_BPG(true, 5, uint8_t); break;
+            case 6: QS_BPG(true, 6, uint8_t); break;
+            case 7: QS_BPG(true, 7, uint8_t); break;
+            case 8: QS_BPG(true, 8, uint8_t); break;
+            case 9: QS_BPG(true, 9, uint16_t); break;
+            case 10: QS_BPG(true, 10, uint16_t); break;
+            default: QS_BPG(true, 11, uint16_t); break;
+        }
+    } else {
+        switch (compact_nw <= 4 ? 4u : compact_nw) {
+            case 4: QS_BPG(false, 4, uint8_t); break;
+            case 5: QS_BPG(false, 5, uint8_t); break;
+            case 6: QS_BPG(false, 6, uint8_t); break;
+            case 7: QS_BPG(false, 7, uint8_t); break;
+            case 8: QS_BPG(false, 8, uint16_t); break;
+            case 9: QS_BPG(false, 9, uint16_t); break;
+            default: QS_BPG(false, 10, uint16_t); break;
+        }
     }
-    else if (compact_nw <= 4) QS_BPG(false, 4);
-    else if (compact_nw == 5) QS_BPG(false, 5);
-    else if (compact_nw == 6) QS_BPG(false, 6);
-    else QS_BPG(false, 7);
 #undef QS_BPG
     return hipGetLastError();
 }
@@ -714,23 +732,40 @@ constexpr int kTT_LT = ((0x0F & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      //
 constexpr int kTT_GT = ((0xF0 & 0x33) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (a & ~b) | (~(a ^ b) & c): greater-than step
 constexpr int kTT_NOR_AND = (0xF0 & ~(0xCC | 0xAA)) & 0xFF;                   // a & ~(b | c)
 
-// LDS image with HW (1, 2 or 4) upper words per slot: words 0..3 at buf[e], the upper words in an array
+// LDS image with HW (1, 2, 4 or 8) upper words per slot: words 0..3 at buf[e], the upper words in an array
 // of HW-word records behind the `stride` 16-byte slots
 template <int HW> __device__ __forceinline__ Planes lds_load_hw(const uint4 *buf, uint32_t e, int stride) {
     const uint4 lo = buf[e];
     Planes r;
     r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
-    r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+#pragma unroll
+    for (int k = 4; k < kBitWords; ++k) r.w[k] = 0;
     if (HW == 1) r.w[4] = reinterpret_cast<const uint32_t *>(buf + stride)[e];
     else if (HW == 2) { const uint2 h = reinterpret_cast<const uint2 *>(buf + stride)[e]; r.w[4] = h.x; r.w[5] = h.y; }
-    else { const uint4 h = buf[stride + e]; r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
+    else if (HW == 4) { const uint4 h = buf[stride + e]; r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
+    else if (HW == 5 || HW == 6) {   // 4 + 1 or 4 + 2 upper words: a second 16-byte array, then a 4- or 8-byte one (9- / 10-word operands)
+        const uint4 h = buf[stride + e];
+        r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w;
+        if (HW == 5) r.w[8] = reinterpret_cast<const uint32_t *>(buf + 2 * stride)[e];
+        else { const uint2 g = reinterpret_cast<const uint2 *>(buf + 2 * stride)[e]; r.w[8] = g.x; r.w[9] = g.y; }
+    }
+    else {   // 8 upper words: two 16-byte records per slot
+        const uint4 h = buf[stride + 2 * e], g = buf[stride + 2 * e + 1];
+        r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; r.w[8] = g.x; r.w[9] = g.y; r.w[10] = g.z; r.w[11] = g.w;
+    }
     return r;
 }
 template <int HW> __device__ __forceinline__ void lds_store_hw(uint4 *buf, uint32_t e, int stride, const Planes &r) {
     buf[e] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
     if (HW == 1) reinterpret_cast<uint32_t *>(buf + stride)[e] = r.w[4];
     else if (HW == 2) reinterpret_cast<uint2 *>(buf + stride)[e] = make_uint2(r.w[4], r.w[5]);
-    else buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+    else if (HW == 4) buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+    else if (HW == 5 || HW == 6) {
+        buf[stride + e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+        if (HW == 5) reinterpret_cast<uint32_t *>(buf + 2 * stride)[e] = r.w[8];
+        else reinterpret_cast<uint2 *>(buf + 2 * stride)[e] = make_uint2(r.w[8], r.w[9]);
+    }
+    else { buf[stride + 2 * e] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]); buf[stride + 2 * e + 1] = make_uint4(r.w[8], r.w[9], r.w[10], r.w[11]); }
 }
 // x - y + 2^B over B planes -> B+1 planes (unsigned, bias 2^B); word 7 = presence(x) & presence(y). The top plane is kept
 // INVERTED (it holds the final borrow, 1 <=> x < y, instead of its complement): every consumer compares two such numbers,
@@ -748,8 +783,8 @@ __device__ __forceinline__ Planes sub_biased(const Planes &x, const Planes &y) {
     }
     r.w[B] = br;
 #pragma unroll
-    for (int k = B + 1; k < 7; ++k) r.w[k] = 0;
-    if (B < 7) r.w[7] = x.w[7] & y.w[7];
+    for (int k = B + 1; k < kPres; ++k) r.w[k] = 0;
+    r.w[kPres] = x.w[kPres] & y.w[kPres];   // (B <= 10: the presence word never collides with a plane)
     return r;
 }
 
@@ -830,10 +865,20 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
     Planes p;
     const qs_u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
     p.w[0] = lo.x; p.w[1] = lo.y; p.w[2] = lo.z; p.w[3] = lo.w;
-    p.w[4] = p.w[5] = p.w[6] = p.w[7] = 0;
-    if (NW == 5) p.w[4] = __builtin_amdgcn_raw_buffer_load_b32(r, voff >> 2, hi_base, 0);
-    else if (NW == 6) { const qs_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r, voff >> 1, hi_base, 0); p.w[4] = h.x; p.w[5] = h.y; }
-    else if (NW >= 7) { const qs_u32x3 h = __builtin_amdgcn_raw_buffer_load_b96(r, (voff >> 2) * 3, hi_base, 0); p.w[4] = h.x; p.w[5] = h.y; p.w[6] = h.z; }
+#pragma unroll
+    for (int k = 4; k < kBitWords; ++k) p.w[k] = 0;
+    constexpr int H = NW - 4;                                   // upper words: a record of H words per pair behind the lo array
+    const uint32_t hoff = (voff >> 2) * (uint32_t)(H > 0 ? H : 1); // = pair * H * 4 bytes (voff = pair * 16)
+    if (H == 1) p.w[4] = __builtin_amdgcn_raw_buffer_load_b32(r, hoff, hi_base, 0);
+    else if (H == 2) { const qs_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r, hoff, hi_base, 0); p.w[4] = h.x; p.w[5] = h.y; }
+    else if (H == 3) { const qs_u32x3 h = __builtin_amdgcn_raw_buffer_load_b96(r, hoff, hi_base, 0); p.w[4] = h.x; p.w[5] = h.y; p.w[6] = h.z; }
+    else if (H >= 4) {
+        const qs_u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(r, hoff, hi_base, 0);
+        p.w[4] = h.x; p.w[5] = h.y; p.w[6] = h.z; p.w[7] = h.w;
+        if (H == 5) p.w[8] = __builtin_amdgcn_raw_buffer_load_b32(r, hoff + 16, hi_base, 0);
+        else if (H == 6) { const qs_u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(r, hoff + 16, hi_base, 0); p.w[8] = g.x; p.w[9] = g.y; }
+        else if (H == 7) { const qs_u32x3 g = __builtin_amdgcn_raw_buffer_load_b96(r, hoff + 16, hi_base, 0); p.w[8] = g.x; p.w[9] = g.y; p.w[10] = g.z; }
+    }
     return p;
 }
 
@@ -874,7 +919,9 @@ template <typename CT> __device__ __forceinline__ void store_tuple(CT *p, uint32
 
 // waves per SIMD the register allocation aims at: 4 (<= 128 VGPRs); the two instances that do not fit without spilling
 // (7 depth bits, binary: 8-plane operands in two a-columns; 4 bits, general) take 3 -- a spill means scratch memory
-template <int B, int MODE> constexpr int bs3_waves() { return ((B == 7 && MODE == MODE_BINARY_FULL) || (B == 4 && MODE == MODE_GENERAL_FULL)) ? 3 : QS_BS3_WAVES; }
+// Deep trees (8..10 depth bits: ladders of up to ~2000 taxa) carry 9..12-word operands: 2 waves per SIMD.
+// (8 and 9 bits in the binary / general modes: 3 waves -- <= 168 VGPRs and 42-46 KB of LDS per workgroup.)
+template <int B, int MODE> constexpr int bs3_waves() { return (B >= 10 || (B >= 7 && MODE == MODE_PARTIAL)) ? 2 : B >= 8 ? 3 : ((B == 7 && MODE == MODE_BINARY_FULL) || (B == 4 && MODE == MODE_GENERAL_FULL)) ? 3 : QS_BS3_WAVES; }
 template <int B, int MODE, typename CT>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(bs3_waves<B, MODE>(), bs3_waves<B, MODE>()))) void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees,
@@ -891,10 +938,10 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
     constexpr int NW = NWP < 4 ? 4 : NWP;
     constexpr int RW = NB + (PART ? 1 : 0);                 // words of an LDS element (R has B+1 planes [+ presence])
-    constexpr int HW = RW <= 5 ? 1 : (RW == 6 ? 2 : 4);     // upper words of an LDS slot
+    constexpr int HW = RW <= 5 ? 1 : (RW == 6 ? 2 : (RW <= 8 ? 4 : (RW == 9 ? 5 : (RW == 10 ? 6 : 8)))); // upper words of an LDS slot
     constexpr int PW = B + 1;                               // where the presence word travels in an LDS element
-    static_assert(!PART || B <= 6, "partial batches carry at most 6 depth bits");
-    constexpr int kImg = kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
+    static_assert(B <= kMaxDepthBits && RW <= kBitWords, "at most 10 depth bits (11 planes + presence in 12 words)");
+    constexpr int kImg = (HW == 5 || HW == 6) ? 2 * kS3Slots + (kS3Slots * (HW - 4) + 3) / 4 : kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
     __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
 #ifdef QS_LDS_PAD   // occupancy experiments: bytes of LDS nobody uses, so that fewer workgroups fit on a CU
     __shared__ uint4 lds_pad[QS_LDS_PAD / 16];
@@ -1012,27 +1059,29 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         // QS_EXP & 16 (timing-only knock-out): zero records -> every panel load returns zeros without touching memory
         return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (QS_EXP & 16) ? 0 : (int)group_bytes, 0x00020000);
     };
-    // compact panel element -> planes in w[0..B-1], presence (partial) in w[7]
+    // compact panel element -> planes in w[0..B-1], presence (partial) in w[kPres]
     auto gload = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff) {
         Planes p = buf_load_planes<NW>(r, voff, hi_base);
-        if (PART) { p.w[7] = p.w[B]; p.w[B] = 0; }
+        if (PART && B != kPres) { p.w[kPres] = p.w[B]; p.w[B] = 0; }
         return p;
     };
     // LDS element: words 0..B [+ presence at word B+1]
     auto lstore = [&](uint4 *buf, uint32_t slot, Planes x) {
-        if (PART && PW != 7) x.w[PW] = x.w[7];
+        if (PART && PW != kPres) x.w[PW] = x.w[kPres];
         lds_store_hw<HW>(buf, slot, kS3Slots, x);
     };
     auto lload = [&](const uint4 *buf, uint32_t slot) {
         Planes r = lds_load_hw<HW>(buf, slot, kS3Slots);
-        if (PART && PW != 7) { r.w[7] = r.w[PW]; r.w[PW] = 0; }
+        if (PART && PW != kPres) { r.w[kPres] = r.w[PW]; r.w[PW] = 0; }
         return r;
     };
     auto row0_load = [&](const uint4 *buf, uint32_t col) {
         if (B <= 4 && !PART) {
             const uint4 lo = buf[kS3Row0 + col];
             Planes r;
-            r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w; r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+            r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+#pragma unroll
+            for (int k = 4; k < kBitWords; ++k) r.w[k] = 0;
             return r;
         }
         return lload(buf, kS3Row0 + col);
@@ -1092,7 +1141,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                     const Planes Ra = lload(cur, j * 16 + colA1);    // M[ad] - M[cd] + 2^B
                     uint32_t g3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, L2), gt, lt); // S1 == S2 and S3 > S1
                     if (PART) {
-                        const uint32_t v = L1.w[7] & Rb.w[7]; // a, b, c, d all present
+                        const uint32_t v = L1.w[kPres] & Rb.w[kPres]; // a, b, c, d all present
                         gt &= v; lt &= v; g3 &= v;
                     }
                     popc_acc(gt, x0[j]);
@@ -1254,7 +1303,9 @@ template <int NWORDS> __device__ __forceinline__ Planes c4_get(const uint4 *lo, 
     constexpr int H = NWORDS - 4;
     Planes r;
     const uint4 v = lo[slot];
-    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; r.w[4] = r.w[5] = r.w[6] = r.w[7] = 0;
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+#pragma unroll
+    for (int k = 4; k < kBitWords; ++k) r.w[k] = 0;
     if (H == 1) r.w[4] = hi[slot];
     else if (H == 2) { const uint2 h = reinterpret_cast<const uint2 *>(hi)[slot]; r.w[4] = h.x; r.w[5] = h.y; }
     else if (H >= 3) { const uint4 h = reinterpret_cast<const uint4 *>(hi)[slot]; r.w[4] = h.x; r.w[5] = h.y; r.w[6] = h.z; r.w[7] = h.w; }
@@ -1466,18 +1517,18 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g_in, cons
                        (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 3u : 0u /* bit 0: XCD remap, bit 1: waves of a workgroup in step */, wire, g.perm)
 #define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
-        if (depth_bits <= 4) QS_BS3(4, MM, CT);                                                                     \
-        else if (depth_bits == 5) QS_BS3(5, MM, CT);                                                                \
-        else if (depth_bits == 6) QS_BS3(6, MM, CT);                                                                \
-        else QS_BS3(7, MM, CT);                                                                                     \
+        switch (depth_bits <= 4 ? 4 : depth_bits) {                                                                 \
+            case 4: QS_BS3(4, MM, CT); break;                                                                       \
+            case 5: QS_BS3(5, MM, CT); break;                                                                       \
+            case 6: QS_BS3(6, MM, CT); break;                                                                       \
+            case 7: QS_BS3(7, MM, CT); break;                                                                       \
+            case 8: QS_BS3(8, MM, CT); break;                                                                       \
+            case 9: QS_BS3(9, MM, CT); break;                                                                       \
+            default: QS_BS3(10, MM, CT); break;                                                                     \
+        }                                                                                                           \
     } while (0)
-#define QS_BS3_BP(CT)                                                                                               \
-    do {                                                                                                            \
-        if (depth_bits <= 4) QS_BS3(4, MODE_PARTIAL, CT);                                                           \
-        else if (depth_bits == 5) QS_BS3(5, MODE_PARTIAL, CT);                                                      \
-        else QS_BS3(6, MODE_PARTIAL, CT);                                                                           \
-    } while (0)
-    if (mode == MODE_PARTIAL && depth_bits > 6) return hipErrorInvalidValue;
+#define QS_BS3_BP(CT) QS_BS3_B(MODE_PARTIAL, CT)
+    if (depth_bits > kMaxDepthBits) return hipErrorInvalidValue;
     if (count_bits == 32) {
         if (mode == MODE_BINARY_FULL) QS_BS3_B(MODE_BINARY_FULL, uint32_t);
         else if (mode == MODE_GENERAL_FULL) QS_BS3_B(MODE_GENERAL_FULL, uint32_t);
@@ -1614,6 +1665,36 @@ __global__ __launch_bounds__(256) void unpack16x2_kernel(const uint32_t *__restr
     const uint32_t w = src[i], n0 = w & 0xFFFFu, n1 = w >> 16;
     if (n0 + n1 > trees) atomicOr(shape_flag, 1u);
     dst[3 * i] = (uint16_t)n0; dst[3 * i + 1] = (uint16_t)n1; dst[3 * i + 2] = (uint16_t)(trees - n0 - n1);
+}
+// The same for totals of 65536 trees and more (BASELINE configs[3]: 100 000 trees): TWO u32 cells (n0, n1) per tuple on the
+// wire instead of three, 8 bytes per quartet instead of 12; n2 = total trees - n0 - n1 after the collective.
+__global__ __launch_bounds__(256) void pack32x2_kernel(const uint32_t *__restrict__ src, uint2 *__restrict__ dst, uint64_t n_tuples,
+                                                       uint32_t trees, uint32_t *__restrict__ shape_flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tuples) return;
+    const uint32_t n0 = src[3 * i], n1 = src[3 * i + 1], n2 = src[3 * i + 2];
+    if (n0 + n1 + n2 != trees) atomicOr(shape_flag, 1u);
+    dst[i] = make_uint2(n0, n1);
+}
+__global__ __launch_bounds__(256) void unpack32x2_kernel(const uint2 *__restrict__ src, uint32_t *__restrict__ dst, uint64_t n_tuples,
+                                                         uint32_t trees, uint32_t *__restrict__ shape_flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tuples) return;
+    const uint2 w = src[i];
+    if ((uint64_t)w.x + w.y > trees) atomicOr(shape_flag, 1u);
+    dst[3 * i] = w.x; dst[3 * i + 1] = w.y; dst[3 * i + 2] = trees - w.x - w.y;
+}
+hipError_t launch_pack32x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag) {
+    if (n_tuples == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_tuples + 255) / 256));
+    hipLaunchKernelGGL(pack32x2_kernel, grid, block, 0, s, (const uint32_t *)table_u32, (uint2 *)dst, n_tuples, trees, shape_flag);
+    return hipGetLastError();
+}
+hipError_t launch_unpack32x2(hipStream_t s, const void *src, void *dst_u32, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag) {
+    if (n_tuples == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_tuples + 255) / 256));
+    hipLaunchKernelGGL(unpack32x2_kernel, grid, block, 0, s, (const uint2 *)src, (uint32_t *)dst_u32, n_tuples, trees, shape_flag);
+    return hipGetLastError();
 }
 hipError_t launch_pack16x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees,
                            uint32_t *overflow_flag, uint32_t *shape_flag) {

@@ -33,7 +33,7 @@ struct DeviceBatch {
     bool all_binary = false;
     // Trees are counted class by class (classes = bits of the deepest LCA of a tree, so that shallow trees run the
     // cheaper kernel instances): slot s of the class-ordered batch is tree tree_order[s]; class k holds the slots
-    // [class_end[k-1], class_end[k]) and needs class_bits[k] depth bits (> 7: byte-SWAR kernel). A sub-batch for the
+    // [class_end[k-1], class_end[k]) and needs class_bits[k] depth bits (> 10: byte-SWAR kernel). A sub-batch for the
     // panel builders = slots [slot0, slot0 + n_trees).
     uint32_t *tree_order = nullptr; // device, n_trees entries, or NULL = identity
     uint32_t slot0 = 0;
@@ -85,6 +85,8 @@ hipError_t launch_pack16(hipStream_t s, const void *table_u32, void *dst, uint64
 hipError_t launch_pack16x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees,
                            uint32_t *overflow_flag, uint32_t *shape_flag);
 hipError_t launch_unpack16x2(hipStream_t s, const void *src, void *dst_u16, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
+hipError_t launch_pack32x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
+hipError_t launch_unpack32x2(hipStream_t s, const void *src, void *dst_u32, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
 hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,
                          int count_bits, uint64_t nq, const uint16_t *abcd_dev, uint64_t *out_dev);
 size_t gather_lds_bytes(uint32_t d_hi);
@@ -102,7 +104,8 @@ struct ScoreDevice {
     long long *pair_min;           // n_inner*n_inner (f64_to_sortable of the device QIC)
     unsigned long long *pair_cand; // n_inner*n_inner*kCand
     uint32_t cand_limit;           // candidate slots pass 2 may fill per node pair (kCand; smaller in tests)
-    unsigned long long *list;      // pass 3 (qs_score_overflow): 4 words (key, q1, q2, q3) per near-minimal quartet of a marked pair
+    unsigned long long *list;      // pass 3 (qs_score_overflow): 4 words (key, q1, q2, q3) per near-minimal quartet of a marked pair;
+                                   // pass 1 with list != NULL: the candidate log of the single-read scoring (same records)
     unsigned long long *list_count, list_cap;
     uint32_t *flags;               // [0] bit 0: a pair's candidate slots overflowed, bit 1: a reduced triple did not fit the packed slot
     const uint16_t *ref_next; // n*n: for a < b the first a' > a with lca(a',b) != lca(a,b), b if there is none
@@ -125,7 +128,8 @@ uint32_t score_scan_max_lds_log();
 struct BundlePlan { std::vector<uint32_t> plo, pcnt, rounds; uint64_t part_lo[2], part_n[2]; int n_parts; };
 void plan_bundles(uint32_t n, uint64_t r0, uint64_t r1, uint32_t waves, BundlePlan &out);
 uint32_t score_bundle_waves(int pass);   // waves per workgroup (= consecutive b per round) of the bundle kernel in pass 1 / 2
-hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts);
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts, double tol = 0.0);
+hipError_t launch_score_log(hipStream_t s, const ScoreDevice &sd, double tol, unsigned long long n_rec); // single-read scoring: filter pass 1's candidate log (sd.list)
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts);
 hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol);
 // sums of the node pairs (degree-2 root, v): pairs_dev = RootPairHost records (qs_abi.hip), total = number of (v,a,b,c,d) items

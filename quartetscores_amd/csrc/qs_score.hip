@@ -469,8 +469,16 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             bool first_is_n0 = true;
             unsigned long long S0 = 0, S1 = 0, S2 = 0;
             double mn = kHuge, thr = -kHuge;
-            uint32_t h0 = 0, h1 = 0, h2 = 0;        // pass 2: the lane's previous near-minimal tuple in this run
+            uint32_t h0 = 0, h1 = 0, h2 = 0;        // pass 2 / logging pass 1: the lane's previous near-minimal tuple in this run
             bool hprev = false;
+            // Pass 1 with a candidate log (sd.list, single-read scoring): a quartet is logged when its QIC is within tol of
+            // min(the node pair's minimum as this lane last saw it in memory, the lane's own running minimum of the run).
+            // Both bounds are >= the pair's FINAL minimum, so every quartet within tol of the final minimum is in the log;
+            // score_log_kernel filters the log against the final minima afterwards -- the table is read once, not twice.
+            const bool logging = PASS == 1 && sd.list != nullptr;
+            // (wave-uniform) stop logging once the log is full: the counter is looked at once per round
+            bool log_on = logging && __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(sd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sd.list_cap)) != 0;
+            double bound = kHuge;
             QicCache qc = {0xFFFFFFFFu, 0.0, 0.0};
             uint32_t end = 0;
             for (uint32_t a0 = 0; a0 < b; a0 += CH) {                   // uniform
@@ -509,7 +517,10 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                     if (f) scan_flush(hash, sd, key, code == 0 ? S0 : S2, code == 2 ? S0 : S1,
                                                       code == 0 ? S2 : (code == 1 ? S0 : S1), f64_to_sortable(mn));
                                 }
-                                if (changed) { S0 = S1 = S2 = 0; mn = kHuge; }
+                                if (changed) {
+                                    S0 = S1 = S2 = 0; mn = kHuge;
+                                    if (logging) { bound = nkey != kKeyEmpty ? sortable_to_f64(sd.pair_min[nkey]) : -kHuge; hprev = false; }
+                                }
                             } else if (changed) {
                                 thr = nkey != kKeyEmpty ? sortable_to_f64(sd.pair_min[nkey]) + tol : -kHuge;
                                 hprev = false;
@@ -520,6 +531,28 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                         const double qic = bundle_qic(t1, sd, qc, n0, n1, n2, first_is_n0);
                         if (PASS == 1) {
                             S0 += n0; S1 += n1; S2 += n2;
+                            if (logging) {
+                                const bool near = qic <= fmin(bound, mn) + tol;
+                                const bool hit = near && !(hprev && n0 == h0 && n1 == h1 && n2 == h2);
+                                const unsigned long long hits = log_on ? __ballot(hit) : 0ull;
+                                if (hits) {                             // one counter update per wave instruction, not per lane
+                                    const uint32_t leader = (uint32_t)__builtin_ctzll(hits);
+                                    unsigned long long base = 0;
+                                    if (lane == leader) base = atomicAdd(sd.list_count, (unsigned long long)__builtin_popcountll(hits));
+                                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)leader) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)leader);
+                                    if (base >= sd.list_cap) log_on = false;   // overflow: the caller falls back to a second pass
+                                    const unsigned long long at = base + (unsigned long long)__builtin_popcountll(hits & ((1ull << lane) - 1ull));
+                                    if (hit && at < sd.list_cap) {
+                                        uint32_t q1, q2, q3;
+                                        permute_counts(code, n0, n1, n2, q1, q2, q3);
+                                        unsigned long long *rec = sd.list + 4 * at;
+                                        rec[0] = key; rec[1] = q1; rec[2] = q2; rec[3] = q3;
+                                    }
+                                }
+                                if (near) { h0 = n0; h1 = n1; h2 = n2; }
+                                hprev = near;
+                            }
                             mn = fmin(mn, qic);
                         } else {
                             // a near-minimal quartet; a repeat of the lane's previous one in this run -- ties such as
@@ -660,16 +693,36 @@ template <typename CT, int PASS> static hipError_t launch_bundle(hipStream_t s, 
 }
 uint32_t score_bundle_waves(int pass) { return pass == 1 ? kBundleWaves1 : kBundleWaves2; }
 
-hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
+// tol: only read when sd.list is set (pass 1 with the candidate log of the single-read scoring; bundle kernel, whole rows only)
+hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts, double tol) {
     if (kernel == 1) return sd.count_bits == 32 ? launch_scan<uint32_t, 1>(s, sd, 0.0) : launch_scan<uint16_t, 1>(s, sd, 0.0);
-    return sd.count_bits == 32 ? launch_bundle<uint32_t, 1>(s, sd, 0.0, n_cu, part_lo, part_n, n_parts)
-                               : launch_bundle<uint16_t, 1>(s, sd, 0.0, n_cu, part_lo, part_n, n_parts);
+    return sd.count_bits == 32 ? launch_bundle<uint32_t, 1>(s, sd, tol, n_cu, part_lo, part_n, n_parts)
+                               : launch_bundle<uint16_t, 1>(s, sd, tol, n_cu, part_lo, part_n, n_parts);
 }
 
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
     if (kernel == 1) return sd.count_bits == 32 ? launch_scan<uint32_t, 2>(s, sd, tol) : launch_scan<uint16_t, 2>(s, sd, tol);
     return sd.count_bits == 32 ? launch_bundle<uint32_t, 2>(s, sd, tol, n_cu, part_lo, part_n, n_parts)
                                : launch_bundle<uint16_t, 2>(s, sd, tol, n_cu, part_lo, part_n, n_parts);
+}
+
+// Single-read scoring, second step: every logged (node pair, count triple) whose device QIC is within tol of the pair's
+// FINAL minimum goes into the pair's candidate slots exactly as pass 2 would have put it there (scan_candidate). The QIC
+// is recomputed from the global log table (it may differ from pass 1's LDS-table value in the last bits: far inside tol).
+__global__ __launch_bounds__(256) void score_log_kernel(ScoreDevice sd, double tol, unsigned long long n_rec) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const unsigned long long *rec = sd.list + 4 * i;
+    const uint32_t key = (uint32_t)rec[0], q1 = (uint32_t)rec[1], q2 = (uint32_t)rec[2], q3 = (uint32_t)rec[3];
+    const double mag = bundle_qic_slow(sd.logk, sd.tbl_n, q1, q2, q3);
+    const double qic = q1 != max(max(q1, q2), q3) ? -mag : mag;
+    if (qic <= sortable_to_f64(sd.pair_min[key]) + tol) scan_candidate(sd, key, q1, q2, q3);
+}
+hipError_t launch_score_log(hipStream_t s, const ScoreDevice &sd, double tol, unsigned long long n_rec) {
+    if (n_rec == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_rec + 255) / 256));
+    hipLaunchKernelGGL(score_log_kernel, grid, block, 0, s, sd, tol, n_rec);
+    return hipGetLastError();
 }
 
 hipError_t launch_score_overflow_list(hipStream_t s, const ScoreDevice &sd, double tol) {

@@ -31,8 +31,8 @@ def table_words(n_tuples: int, count_bits: int) -> int:
 
 
 def _wire_words_per_2_tuples(wire) -> int:
-    """int32 words that two tuples occupy on the wire: u32 cells 6, u16 cells 3, two-cell u16 format 2."""
-    return {32: 6, "u32": 6, 16: 3, "u16": 3, "u16x2": 2}[wire]
+    """int32 words that two tuples occupy on the wire: u32 cells 6, u16 cells 3, two-cell formats 2 (u16) / 4 (u32)."""
+    return {32: 6, "u32": 6, 16: 3, "u16": 3, "u16x2": 2, "u32x2": 4}[wire]
 
 
 def scatter_layout(n_tuples: int, world: int, wire) -> Tuple[int, int]:
@@ -170,8 +170,8 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
     import torch
     import torch.distributed as dist
     from . import _lib, engine
-    if wire not in ("auto", "u16x2", "u16", "u32"):
-        raise ValueError("wire must be auto, u16x2, u16 or u32")
+    if wire not in ("auto", "u16x2", "u16", "u32", "u32x2"):
+        raise ValueError("wire must be auto, u16x2, u16, u32x2 or u32")
     if wire in ("u16", "u16x2") and total_trees >= (1 << 16):
         raise ValueError("a u16 wire format needs fewer than 65536 trees in total")
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -183,17 +183,17 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
     hb = ctx.batch_upload(local_batch, with_nodes=(algo == engine.QS_ALGO_SCATTER)) if local_batch.n_trees else None
     try:
         if wire == "auto":   # the narrowest format the trees allow, the same on every rank
+            both = _lib.QS_BATCH_ALL_TAXA | _lib.QS_BATCH_BINARY
+            ok = 1 if (hb is None or (ctx.batch_flags(hb) & both) == both) and algo != engine.QS_ALGO_SCATTER else 0
+            if multi and world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
             if total_trees >= (1 << 16):
-                wire = "u32"
+                wire = "u32x2" if ok else "u32"     # binary full trees: two cells (n0, n1) instead of three
             else:
-                both = _lib.QS_BATCH_ALL_TAXA | _lib.QS_BATCH_BINARY
-                ok = 1 if (hb is None or (ctx.batch_flags(hb) & both) == both) and algo != engine.QS_ALGO_SCATTER else 0
-                if multi and world > 1:
-                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                    ok = int(flag.item())
                 wire = "u16x2" if ok else "u16"
-        bits = 32 if wire == "u32" else 16
+        bits = 32 if wire in ("u32", "u32x2") else 16
         t_chunk, words = scatter_layout(ctx.table_tuples, world, wire)
         send = torch.zeros(world * words, dtype=torch.int32, device=dev)
         if wire == "u16x2":
@@ -212,6 +212,8 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
                 ctx.count_batch(hb, algo)
             if wire == "u16":
                 ctx.table_pack16(send)
+            elif wire == "u32x2":
+                ctx.table_pack32x2(send)               # (n0, n1) per tuple; refused by qs_sync if a tuple does not sum to the trees
         ctx.sync()
     finally:
         if hb is not None:
@@ -223,6 +225,9 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
     if wire == "u16x2":                            # restore the third cell: n2 = total trees - n0 - n1
         shard = torch.zeros(table_words(max(n_owned, 1), 16), dtype=torch.int32, device=dev)
         ctx.unpack16x2(recv, n_owned, total_trees, shard)
+    elif wire == "u32x2":
+        shard = torch.zeros(table_words(max(n_owned, 1), 32), dtype=torch.int32, device=dev)
+        ctx.unpack32x2(recv, n_owned, total_trees, shard)
     ctx.sync()                                     # raises if a tuple did not fit the wire format
     ctx.score_set_view(shard, bits, rank_lo, n_owned)
     return ctx, shard, bits, rank_lo, n_owned

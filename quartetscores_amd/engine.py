@@ -104,6 +104,16 @@ class Context:
         """u32 table -> one word n0 | n1 << 16 per tuple (batches of binary trees holding all taxa); asynchronous."""
         self._chk(self.L.qs_table_pack16x2(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
 
+    def table_pack32x2(self, tensor):
+        """qs_table_pack32x2: (n0, n1) per tuple as two u32 words into `tensor` (int32, >= 2 * table_tuples elements)."""
+        self._chk(self.L.qs_table_pack32x2(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))
+
+    def unpack32x2(self, src, n_tuples: int, total_trees: int, dst):
+        """qs_unpack32x2: n_tuples (n0, n1) pairs of `src` -> [rank][3] u32 tuples in `dst` (n2 = total_trees - n0 - n1)."""
+        if src.numel() < 2 * n_tuples or dst.numel() * dst.element_size() < n_tuples * 12:
+            raise ValueError("unpack32x2: buffer too small")
+        self._chk(self.L.qs_unpack32x2(self.h, C.c_void_p(src.data_ptr()), n_tuples, total_trees, C.c_void_p(dst.data_ptr())))
+
     def unpack16x2(self, src, n_tuples: int, total_trees: int, dst):
         """n_tuples reduced words -> [tuple][3] u16 cells in `dst` (n2 = total_trees - n0 - n1); asynchronous."""
         if src.numel() * src.element_size() < n_tuples * 4 or dst.numel() * dst.element_size() < n_tuples * 6:

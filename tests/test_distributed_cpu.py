@@ -105,9 +105,9 @@ def test_scatter_layout_properties():
     from quartetscores_amd import distributed
     for nq in (1, 2, 70, 126, 10668000, 2862209280):
         for w in (1, 2, 3, 8):
-            for bits in (16, 32, "u16x2"):
+            for bits in (16, 32, "u16x2", "u32x2"):
                 t, words = distributed.scatter_layout(nq, w, bits)
-                bytes_per_tuple = 4 if bits == "u16x2" else 3 * bits // 8
+                bytes_per_tuple = {"u16x2": 4, "u32x2": 8}.get(bits) or 3 * bits // 8
                 assert t % 2 == 0 and t * w >= nq and words * 4 == t * bytes_per_tuple
                 owned = [distributed.scatter_owned(nq, w, r, bits) for r in range(w)]
                 assert owned[0][0] == 0 and sum(c for _, c in owned) == nq

@@ -192,8 +192,8 @@ def test_deep_trees_take_the_u16_panel(eng, monkeypatch):
     trees2 = [cat + ";"] * 2 + synth.tree_set(n, 6, 11, dropout=0.2)
     batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id, recentre=False)
     ctx2, T2 = gpu_table(eng, ref, batch2)
-    v2 = ctx2.last_count_variant()   # the two caterpillars go to the SWAR kernel, the shallow trees stay bit-sliced
-    assert "partial/" in v2 and "depth_u16:2" in v2 and "bitslice_b" in v2, v2
+    v2 = ctx2.last_count_variant()   # partial batches take the bit-sliced kernel up to 10 depth bits too (round 3)
+    assert "partial/" in v2 and "bitslice_b7" in v2 and "depth_u" not in v2, v2
     assert (T2.astype(np.uint64) == oracle_counts(ref_nw, trees2).counts()).all()
 
 
@@ -236,7 +236,7 @@ def test_depth_classes_are_counted_separately(eng, kind):
         assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all(), (kind, algo_split)
 
 
-def test_only_the_deep_trees_take_the_swar_kernel(eng, monkeypatch):
+def test_only_the_deep_trees_take_the_deep_instance(eng, monkeypatch):
     n = 140
     ref_nw = synth.reference_tree(n, 420)
     ref = flatten.flatten_reference(ref_nw)
@@ -247,8 +247,8 @@ def test_only_the_deep_trees_take_the_swar_kernel(eng, monkeypatch):
     batch = _concat_batches(flatten.flatten_eval_trees(synth.tree_set(n, 70, 421), ref.name_to_id), deep)
     assert int(batch.adj_depth.max()) > 127
     ctx, T = gpu_table(eng, ref, batch)
-    v = ctx.last_count_variant()
-    assert "bitslice_b" in v and "depth_u16:2" in v, v
+    v = ctx.last_count_variant()   # depth 138 < 256: the 8-bit instance; the 70 shallow trees (< 1024: no class of their own) join it
+    assert "bitslice_b8x2" in v and "depth_u" not in v, v
     assert (T.sum(axis=1) == 72).all()
     monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
     ctx2, T2 = gpu_table(eng, ref, batch)
@@ -256,13 +256,13 @@ def test_only_the_deep_trees_take_the_swar_kernel(eng, monkeypatch):
     assert (T == T2).all()
 
 
-@pytest.mark.parametrize("n,bits", [(20, 5), (40, 6), (80, 7)])
+@pytest.mark.parametrize("n,bits", [(20, 5), (40, 6), (80, 7), (150, 8)])
 @pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial"])
 @pytest.mark.parametrize("count_bits", [32, 16])
 def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, kind, count_bits):
-    """All (depth bits B, mode) instances of count_bitslice3_kernel: a caterpillar that is not re-rooted forces
-    depth n-2; 40 trees span two 32-tree groups; both panel builders. Partial batches carry at most 6 depth bits
-    in the bit-sliced kernel (7 fall back to the byte-SWAR one)."""
+    """All (depth bits B, mode) instances of count_bitslice3_kernel up to 8 bits against the oracle: a caterpillar that is
+    not re-rooted forces depth n-2; 40 trees span two 32-tree groups; both panel builders (9 and 10 bits:
+    test_deep_ladders_9_and_10_bits, on table shards)."""
     ref_nw = synth.reference_tree(n, 200 + n)
     ref = flatten.flatten_reference(ref_nw)
     cat = "(t0,t1)"
@@ -277,11 +277,7 @@ def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, ki
         monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_KERNEL, 1 if builder == "big" else 0)
         ctx, T = gpu_table(eng, ref, batch, count_bits)
         v = ctx.last_count_variant()
-        assert kind in v
-        if kind == "partial" and bits == 7:
-            assert "depth_u" in v
-        else:
-            assert f"bitslice_b{bits}" in v
+        assert kind in v and f"bitslice_b{bits}" in v and "depth_u" not in v, v
         assert (T.astype(np.uint64) == want).all(), (builder, v)
 
 
@@ -328,7 +324,7 @@ def test_cooperative_count_kernel_matches_oracle(eng, monkeypatch, n, m, bits, c
         assert (ctx3.table_download().astype(np.uint64) == want[lo:]).all()
 
 
-def test_very_deep_trees_fall_back_to_swar_u16(eng):
+def test_very_deep_trees_stay_bit_sliced(eng):
     n = 150
     ref_nw = synth.reference_tree(n, 19)
     ref = flatten.flatten_reference(ref_nw)
@@ -339,10 +335,55 @@ def test_very_deep_trees_fall_back_to_swar_u16(eng):
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
     assert int(batch.adj_depth.max()) > 127
     ctx, T = gpu_table(eng, ref, batch)
-    assert "depth_u16" in ctx.last_count_variant()
+    assert "bitslice_b8" in ctx.last_count_variant() and "depth_u" not in ctx.last_count_variant()
     assert (T.sum(axis=1) == 5).all()
     _, T2 = gpu_table(eng, ref, flatten.flatten_eval_trees(trees, ref.name_to_id))  # re-centred: shallow again
     assert (T == T2).all()
+
+
+@pytest.mark.parametrize("n,bits", [(300, 9), (600, 10), (1100, 11)])
+@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial"])
+def test_deep_ladders_9_and_10_bits(eng, monkeypatch, n, bits, kind):
+    """Ladder-like trees (LCA depths up to n - 2, not re-rooted) on the 9- and 10-bit instances of the bit-sliced kernel,
+    11 bits = beyond them (byte-SWAR kernel with 16-bit depths). Tables of these sizes are too large for the oracle, so a
+    table SHARD (the two largest ids) is compared with the byte-SWAR kernel's shard bit for bit and with the split-based
+    brute force (tests/bruteforce.py) on random quartets. The reference's loop is shape-independent
+    (QuartetCounterLookup.hpp:65-106): no cliff for deep trees."""
+    import sys
+    import bruteforce
+    old_limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old_limit, 20 * n))                           # the brute force parses ladders recursively
+    ref_nw = synth.reference_tree(n, 900 + n)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    kw = {"binary_full": {}, "general_full": {"collapse": 0.25}, "partial": {"dropout": 0.1, "collapse": 0.1}}[kind]
+    trees = [cat + ";"] * 2 + synth.tree_set(n, 34, 950 + n, **kw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
+    assert (1 << (bits - 1)) <= int(batch.adj_depth.max()) < (1 << bits)
+    d_lo = n - 2
+
+    def shard_table():
+        ctx = eng.Context(n, 16, d_lo=d_lo, d_hi=n)
+        ctx.table_alloc()
+        ctx.count_trees(batch, eng.QS_ALGO_GATHER)
+        ctx.sync()
+        return ctx, ctx.table_download()
+    ctx, T = shard_table()
+    v = ctx.last_count_variant()
+    assert kind in v and ((f"bitslice_b{bits}" in v) if bits <= 10 else ("depth_u16" in v)), v
+    rng = np.random.default_rng(n)
+    qs_ = np.sort(np.stack([np.append(rng.choice(d_lo + 1, size=3, replace=False), rng.integers(d_lo, n)) for _ in range(1500)]), axis=1)
+    qs_ = qs_[(qs_[:, 2] < qs_[:, 3])].astype(np.uint16)
+    want = bruteforce.quartet_counts_for(trees, ref.names, qs_.astype(np.int64))
+    assert (ctx.lookup(qs_) == want).all()
+    if bits <= 10:
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+        ctx2, T2 = shard_table()
+        assert "depth_u16" in ctx2.last_count_variant()
+        assert (T == T2).all()
+    sys.setrecursionlimit(old_limit)
 
 
 def test_batches_accumulate_and_are_deterministic(eng):
@@ -916,6 +957,50 @@ def test_two_cell_wire_format(eng):
     assert ei.value.code == -4 and "two-cell" in str(ei.value)
     with pytest.raises(eng.QSError):
         ctx.table_pack16x2(words[:-1])
+
+
+def test_two_cell_wire_format_u32(eng):
+    """qs_table_pack32x2 / qs_unpack32x2 (totals of 65536 trees and more: BASELINE configs[3] moves 8 instead of 12 bytes per
+    quartet): (n0, n1) per tuple; the pairs of several ranks add; the unpacked table equals the three-cell one with
+    n2 = total - n0 - n1, also for totals beyond 2^16; a batch with an unresolved quartet is refused; and the tree-sharded
+    driver picks the format by itself (wire = "auto") once the total reaches 65536 trees."""
+    import torch
+    from quartetscores_amd import distributed
+    n, m = 21, 77
+    ref_nw, trees = make_case(n, m, 95)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    ctx.count_trees(batch)
+    want = ctx.table_download()
+    nq = want.shape[0]
+    words = torch.full((2 * nq,), -1, dtype=torch.int32, device="cuda")
+    ctx.table_pack32x2(words)
+    ctx.sync()
+    w = words.cpu().numpy().view(np.uint32).reshape(nq, 2)
+    assert np.array_equal(w[:, 0], want[:, 0]) and np.array_equal(w[:, 1], want[:, 1])
+    ranks_ = 1000                                        # "1000 ranks" with the same trees: totals beyond 2^16
+    out = torch.zeros(nq * 3, dtype=torch.int32, device="cuda")
+    ctx.unpack32x2(words * ranks_, nq, ranks_ * m, out)
+    ctx.sync()
+    got = out.cpu().numpy().view(np.uint32).reshape(nq, 3)
+    assert ranks_ * m > 65535 and np.array_equal(got, want * ranks_)
+    ctx2 = eng.Context(n, 32)
+    ctx2.table_alloc()
+    ctx2.count_trees(flatten.flatten_eval_trees(synth.tree_set(n, 30, 96, collapse=0.3), ref.name_to_id))
+    ctx2.table_pack32x2(words)
+    with pytest.raises(eng.QSError) as ei:
+        ctx2.sync()
+    assert ei.value.code == -4 and "two-cell" in str(ei.value)
+    with pytest.raises(eng.QSError):
+        ctx.table_pack32x2(words[:-1])
+    # the driver: explicit "u32x2" on one rank gives the table back; "auto" below 65536 trees stays with 16-bit cells
+    c3, shard, bits, r_lo, n_own = distributed.reduce_scatter_counts(ref, batch, m, wire="u32x2")
+    assert (bits, r_lo, n_own) == (32, 0, nq)
+    assert np.array_equal(shard.cpu().numpy().view(np.uint32)[: nq * 3].reshape(nq, 3), want)
+    _, _, bits16, _, _ = distributed.reduce_scatter_counts(ref, batch, m, wire="auto")
+    assert bits16 == 16
 
 
 def test_large_batch_validation_runs_on_several_host_threads(eng):

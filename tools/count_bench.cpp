@@ -27,7 +27,12 @@ int main(int argc, char **argv) {
     const int reps = atoi(argv[4]);
     const char *nni = getenv("CB_NNI");
     const unsigned threads = std::max(1u, std::thread::hardware_concurrency());
-    const std::string refText = synth_random_trees(n, 1, 9000, 1);
+    std::string refText = synth_random_trees(n, 1, 9000, 1);
+    if (getenv("CB_LADDER")) {   // caterpillar reference; with CB_NNI the evaluation trees are the ladder + Poisson(n/8) NNIs
+        std::string lad = "(t0,t1)";
+        for (uint32_t i = 2; i + 2 < n; ++i) lad = "(" + lad + ",t" + std::to_string(i) + ")";
+        refText = "(" + lad + ",t" + std::to_string(n - 2) + ",t" + std::to_string(n - 1) + ");\n";
+    }
     const std::string text = nni ? synth_nni_trees(refText, m, 9001, -1.0, threads) : synth_random_trees(n, m, 9001, threads);
     NewickReader rr(refText);
     Tree ref;
