@@ -558,6 +558,31 @@ def main():
     # ---- parity gates run with every measurement -------------------------------------------------------------
     step()
     ctx.sync()
+    # ---- scoring (secondary metric of SURVEY 8(d)): ONE cold call (first use: reference tree, LCA matrix, plans,
+    # accumulator allocation) and then warm calls; phases from qs_last_score_ms. It runs BEFORE the gates below: they
+    # allocate and free tens of GB of scratch (a 17 GB table, a 34 GB clone), and the first hipMalloc after such a free
+    # blocks for ~0.5 s in the runtime -- that, not qs_score, was the 492 ms of round 2's driver line
+    score_cold_ms = score_ms = None
+    score_phases_cold = score_phases = None
+    if not args.no_score and shards == 1:
+        def score_once():
+            torch.cuda.synchronize(dev)
+            s0 = time.perf_counter()
+            if reduce_mode == "scatter" and steps > 0:
+                # every rank scores the shard it received (view), accumulators combined with small collectives
+                own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
+                ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
+                distributed.score_sharded(ctx, ref)
+                ctx.score_set_view(None, 0, 0, 0)
+                ph = None
+            else:
+                ctx.score(ref)
+                ph = {k_: round(v_, 3) for k_, v_ in ctx.last_score_ms().items()}
+            return (time.perf_counter() - s0) * 1e3, ph
+        score_cold_ms, score_phases_cold = score_once()
+        warm = [score_once() for _ in range(3)]
+        score_ms, score_phases = min(warm, key=lambda x: x[0])
+
     parity = None
     if binary_full_trees:              # tuples sum to m only when every tree resolves every quartet
         parity = True
@@ -623,29 +648,6 @@ def main():
         upload_step_ms = (time.perf_counter() - u0) * 1e3 / k_up
         step()                           # the gates / scoring below read the table of a plain step
         ctx.sync()
-
-    # ---- scoring (secondary metric of SURVEY 8(d)): ONE cold call (first use: reference tree, LCA matrix, plans,
-    # accumulator allocation) and then warm calls; phases from qs_last_score_ms
-    score_cold_ms = score_ms = None
-    score_phases_cold = score_phases = None
-    if not args.no_score and shards == 1:
-        def score_once():
-            torch.cuda.synchronize(dev)
-            s0 = time.perf_counter()
-            if reduce_mode == "scatter" and steps > 0:
-                # every rank scores the shard it received (view), accumulators combined with small collectives
-                own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
-                ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
-                distributed.score_sharded(ctx, ref)
-                ctx.score_set_view(None, 0, 0, 0)
-                ph = None
-            else:
-                ctx.score(ref)
-                ph = {k_: round(v_, 3) for k_, v_ in ctx.last_score_ms().items()}
-            return (time.perf_counter() - s0) * 1e3, ph
-        score_cold_ms, score_phases_cold = score_once()
-        warm = [score_once() for _ in range(3)]
-        score_ms, score_phases = min(warm, key=lambda x: x[0])
 
     if rank != 0:
         dist.barrier()

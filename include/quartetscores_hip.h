@@ -170,8 +170,10 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_TABLE_TREES 8u        /* number of trees behind a table this context did not count itself (reduced over GPUs, uploaded,
                                        * attached or viewed): sizes the log table of the device QIC so that every count takes the
                                        * table path (speed only; scores never depend on it). 0 = what the context counted (default) */
-#define QS_TUNE_SCORE_PASSES 10u      /* qs_score: 0 = single read of the table (default: pass 1 logs the candidates, a filter over the log
-                                       * replaces pass 2), 1 = two passes (A/B and tests; also taken by itself when the log overflows) */
+#define QS_TUNE_SCORE_PASSES 10u      /* qs_score: 0 / 1 = two passes over the table (default), 2 = single read (pass 1 logs the candidates, a
+                                       * filter over the log replaces pass 2; falls back to pass 2 when the log overflows). Measured
+                                       * slower on MI355X: an option for A/B runs and tests */
+#define QS_TUNE_SCORE_LOG_CAP 11u     /* records the candidate log of the single-read scoring may hold (0 = 8 M = 256 MB); tests force overflows */
 #define QS_TUNE_COOP 9u               /* binary full batches: 1 = run the tiles with two a-blocks through count_bitslice4_kernel, whose
                                        * workgroups (four consecutive third ids of one (a,b,d) tile) share their panel loads through
                                        * LDS; 0 / 2 = off (default: the barrier it needs costs more than the loads it saves) */
@@ -325,9 +327,12 @@ int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 int qs_last_count_launches(const qs_ctx *ctx);
 /* Phases of the most recent qs_score call in milliseconds: [0] the whole call (host clock), [1] set-up (accumulator
  * allocation, reference tree + LCA matrix, log table: near zero once cached in the context), [2] pass 1 and [3] pass 2
- * (HIP events on the context's stream; [3] = the filter over pass 1's candidate log in the default single-read mode), [4] host wait for the passes incl. the overflow pass and the accumulators' way
+ * (HIP events on the context's stream; [3] = the filter over pass 1's candidate log in single-read mode), [4] host wait for the passes incl. the overflow pass and the accumulators' way
  * back, [5] qs_score_finish (host libm + min-propagation; QuartetScoreComputer.hpp:448-454,484-489). */
 int qs_last_score_ms(qs_ctx *ctx, float out_ms[6]);
+/* Records in the candidate log of the most recent qs_score in single-read mode (QS_TUNE_SCORE_PASSES = 2); 0 = it read the
+ * table twice (the default, or the log overflowed). */
+uint64_t qs_last_score_log(const qs_ctx *ctx);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);
 /* How score passes 1 and 2 decompose the tuples [rank_lo, rank_lo + n_tuples) of an n_taxa table (host arithmetic only,

@@ -58,9 +58,18 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         ctx_.assign(G_, nullptr);
         table_.assign(G_, nullptr);
+        send_.assign(G_, nullptr);
+        // RCCL's communicators take ~2 s to create (ncclCommInitAll): on a helper thread, beside the counting
+        std::vector<int> devs(G_);
+        for (int g = 0; g < G_; ++g) devs[g] = opt_.device + g;
+        comms_.assign(G_, nullptr);
+        ncclResult_t comm_rc = ncclSuccess;
+        std::thread comm_init([&] { comm_rc = ncclCommInitAll(comms_.data(), G_, devs.data()); });
         try {
-            count(evalTreesPath, m);
-            reduce();
+            try { count(evalTreesPath, m); } catch (...) { comm_init.join(); throw; }
+            comm_init.join();
+            if (comm_rc != ncclSuccess) { comms_.assign(G_, nullptr); throw std::runtime_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(comm_rc)); }
+            reduce(m);
             const auto t1 = std::chrono::steady_clock::now();
             std::cout << "Finished counting quartets.\nIt took: " << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << " microseconds." << std::endl;
             score(refTree);
@@ -87,15 +96,20 @@ private:
     bool full_;
     int G_ = 1;
     std::vector<qs_ctx *> ctx_;
-    std::vector<void *> table_;
+    std::vector<void *> table_, send_;        // send_: the two-cell wire words (binary full trees, u32 tables)
+    std::vector<ncclComm_t> comms_;
+    std::atomic<uint32_t> flags_and_{~0u};     // AND of qs_batch_flags over every batch of every GPU
     uint64_t tuples_ = 0, chunk_tuples_ = 0, chunk_words_ = 0;
 
     void release() {
+        for (auto &cm : comms_) if (cm) { (void)ncclCommDestroy(cm); cm = nullptr; }
         for (int g = 0; g < (int)ctx_.size(); ++g) {
             if (ctx_[g]) qs_destroy(ctx_[g]);
-            if (table_[g]) { (void)hipSetDevice(opt_.device + g); (void)hipFree(table_[g]); }
+            (void)hipSetDevice(opt_.device + g);
+            if (table_[g]) (void)hipFree(table_[g]);
+            if (g < (int)send_.size() && send_[g]) (void)hipFree(send_[g]);
         }
-        ctx_.clear(); table_.clear();
+        ctx_.clear(); table_.clear(); send_.clear();
     }
 
     void count(const std::string &evalTreesPath, size_t m) {
@@ -134,6 +148,7 @@ private:
                         if (in_flight.size() == 2) { qs_batch_free(ctx_[g], in_flight.front()); in_flight.erase(in_flight.begin()); }
                         qs_device_batch *db = nullptr;
                         if (qs_batch_upload(ctx_[g], &hb, &db) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                        flags_and_.fetch_and(qs_batch_flags(db));
                         in_flight.push_back(db);
                         if (qs_count_batch(ctx_[g], db, opt_.algo) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
                     }
@@ -156,27 +171,50 @@ private:
         std::cout << "lookup table size in bytes: " << tuples_ * 3 * (bits_ / 8) << "\n";
     }
 
-    // one collective over all GPUs of this process
-    void reduce() {
-        std::vector<int> devs(G_);
-        for (int g = 0; g < G_; ++g) devs[g] = opt_.device + g;
-        std::vector<ncclComm_t> comms(G_);
-        QSM_NCCL(ncclCommInitAll(comms.data(), G_, devs.data()));
+    // one collective over all GPUs of this process. Reduce-scatter of u32 tables whose trees are all binary and hold all taxa:
+    // the TWO-cell wire format, (n0, n1) per tuple = 8 instead of 12 bytes per quartet on xGMI (qs_table_pack32x2 /
+    // qs_unpack32x2; n2 = m - n0 - n1) -- BASELINE configs[3] (100 000 trees: u32 cells) moves 1.4 GB per GPU instead of 2.1.
+    void reduce(size_t m) {
+        const uint32_t both = QS_BATCH_ALL_TAXA | QS_BATCH_BINARY;
+        const bool two_cell = !full_ && bits_ == 32 && (flags_and_.load() & both) == both && (opt_.algo & 0xFFu) != QS_ALGO_SCATTER;
+        const uint64_t words2 = chunk_tuples_ * 2;                    // wire words per chunk in the two-cell format
+        if (two_cell)
+            for (int g = 0; g < G_; ++g) {
+                QSM_HIP(hipSetDevice(opt_.device + g));
+                if (hipMalloc(&send_[g], (size_t)words2 * 4 * G_) != hipSuccess) throw std::runtime_error("Insufficient memory!");
+                QSM_HIP(hipMemset(send_[g], 0, (size_t)words2 * 4 * G_));     // padding tuples behind the table stay zero
+                if (qs_table_pack32x2(ctx_[g], send_[g], (uint64_t)words2 * 4 * G_) != QS_OK || qs_sync(ctx_[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+            }
+        bool group_open = false;
         try {
             QSM_NCCL(ncclGroupStart());
+            group_open = true;
             for (int g = 0; g < G_; ++g) {
-                QSM_HIP(hipSetDevice(devs[g]));
+                QSM_HIP(hipSetDevice(opt_.device + g));
                 uint32_t *buf = (uint32_t *)table_[g];
-                if (full_) QSM_NCCL(ncclAllReduce(buf, buf, chunk_words_ * G_, ncclUint32, ncclSum, comms[g], nullptr));
-                else QSM_NCCL(ncclReduceScatter(buf, buf + (size_t)g * chunk_words_, chunk_words_, ncclUint32, ncclSum, comms[g], nullptr));
+                if (full_) QSM_NCCL(ncclAllReduce(buf, buf, chunk_words_ * G_, ncclUint32, ncclSum, comms_[g], nullptr));
+                else if (two_cell) { uint32_t *sb = (uint32_t *)send_[g]; QSM_NCCL(ncclReduceScatter(sb, sb + (size_t)g * words2, words2, ncclUint32, ncclSum, comms_[g], nullptr)); }
+                else QSM_NCCL(ncclReduceScatter(buf, buf + (size_t)g * chunk_words_, chunk_words_, ncclUint32, ncclSum, comms_[g], nullptr));
             }
+            group_open = false;
             QSM_NCCL(ncclGroupEnd());
-            for (int g = 0; g < G_; ++g) { QSM_HIP(hipSetDevice(devs[g])); QSM_HIP(hipDeviceSynchronize()); }
+            for (int g = 0; g < G_; ++g) { QSM_HIP(hipSetDevice(opt_.device + g)); QSM_HIP(hipDeviceSynchronize()); }
         } catch (...) {
-            for (auto &cm : comms) (void)ncclCommDestroy(cm);
+            if (group_open) (void)ncclGroupEnd();     // never destroy communicators inside an open group
             throw;
         }
-        for (auto &cm : comms) (void)ncclCommDestroy(cm);
+        if (two_cell) {
+            std::cout << "Wire format: two u32 cells per tuple (binary trees holding all taxa).\n";
+            for (int g = 0; g < G_; ++g) {   // the reduced pairs of GPU g's chunk -> [rank][3] tuples where score() expects its shard
+                QSM_HIP(hipSetDevice(opt_.device + g));
+                const uint64_t lo = std::min<uint64_t>((uint64_t)g * chunk_tuples_, tuples_), cnt = std::min<uint64_t>(lo + chunk_tuples_, tuples_) - lo;
+                char *shard = (char *)table_[g] + (size_t)g * chunk_words_ * 4;
+                if (cnt && (qs_unpack32x2(ctx_[g], (const uint32_t *)send_[g] + (size_t)g * words2, cnt, (uint64_t)m, shard) != QS_OK || qs_sync(ctx_[g]) != QS_OK))
+                    throw std::runtime_error(qs_last_error(ctx_[g]));
+                (void)hipFree(send_[g]); send_[g] = nullptr;
+            }
+        }
+        for (int g = 0; g < G_; ++g) (void)qs_set_tuning(ctx_[g], QS_TUNE_TABLE_TREES, (uint64_t)m);   // the reduced table holds all m trees
     }
 
     void score(Tree const &refTree) {

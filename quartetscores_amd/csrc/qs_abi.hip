@@ -120,8 +120,9 @@ struct qs_ctx {
     unsigned long long *score_log = nullptr;     // log_cap records of 4 words + 1 word counter behind them
     uint64_t score_log_cap = 0;
     bool score_log_active = false;               // set by qs_score around its pass 1
-    uint32_t tune_score_passes = 0;              // QS_TUNE_SCORE_PASSES: 0 = single read (default), 1 = two passes over the table
+    uint32_t tune_score_passes = 0;              // QS_TUNE_SCORE_PASSES: 0 / 1 = two passes over the table (default), 2 = single read (measured slower)
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
+    uint64_t tune_score_log_cap = 0;             // QS_TUNE_SCORE_LOG_CAP: records the log may hold (0 = 8 M); tests force overflows
 };
 
 static thread_local std::string g_create_err;   // per thread: qs_create of several contexts may run concurrently (multi_gpu.hpp)
@@ -333,8 +334,11 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             return QS_OK;
         case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
         case QS_TUNE_TABLE_TREES: c->table_trees_hint = value; return QS_OK;
+        case QS_TUNE_SCORE_LOG_CAP:
+            if (value > (1ull << 26)) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOG_CAP takes at most 2^26 records");
+            c->tune_score_log_cap = value; return QS_OK;
         case QS_TUNE_SCORE_PASSES:
-            if (value > 1) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_PASSES takes 0 (single read) or 1 (two passes)");
+            if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_PASSES takes 0 / 1 (two passes) or 2 (single read)");
             c->tune_score_passes = (uint32_t)value; return QS_OK;
         case QS_TUNE_COOP:
             if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_COOP takes 0 (default: off), 1 (on) or 2 (off)");
@@ -1358,6 +1362,8 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     if (c->score_log_active && c->tune_score_kernel == 0 && c->bundle[0].n_parts == 0 && c->score_log) {
         sd.list = c->score_log; sd.list_count = c->score_log + 4 * c->score_log_cap; sd.list_cap = c->score_log_cap;
         QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+        // waves reserve whole chunks of records: what they leave unwritten must read as "no record" (key = all ones)
+        QS_HIP(c, hipMemsetAsync(c->score_log, 0xFF, (size_t)c->score_log_cap * 32, c->stream));
     } else c->score_log_active = false;   // (partial rows / scan kernel: the caller falls back to two passes)
     QS_HIP(c, launch_score_pass1(c->stream, sd, c->tune_score_kernel, c->n_cu, c->bundle[0].part_lo, c->bundle[0].part_n, c->bundle[0].n_parts, c->tune_score_tol));
     // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
@@ -1603,12 +1609,16 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
         if (rc0 != QS_OK) return rc0;
     }
     c->score_ms[1] = ms_since(t_all);
-    // Single-read scoring (default): pass 1 also logs every quartet that is near-minimal for its node pair AT THAT MOMENT (a
-    // superset of the finally near-minimal ones), and a filter over the log replaces the second pass over the table
-    // (QuartetScoreComputer.hpp:417-469 evaluates log_score of every quartet once, too). Two passes if the log overflows.
+    // Single-read scoring (QS_TUNE_SCORE_PASSES = 2): pass 1 also logs every quartet that is near-minimal for its node pair AT
+    // THAT MOMENT (a superset of the finally near-minimal ones), and a filter over the log replaces the second pass over the
+    // table (QuartetScoreComputer.hpp:417-469 evaluates log_score of every quartet once, too); two passes if the log
+    // overflows. NOT the default: measured on MI355X the logging pass 1 takes 12.4 ms instead of 10.3 at 512 taxa and its log
+    // overflows 8 M records there (the bound a lane sees is too stale to prune), at 256 taxa 2.3 + 0.3 ms against 2.6 ms for
+    // both plain passes (profiles/r03_experiments.md section 6).
     c->last_score_log = 0;
-    if (c->tune_score_passes == 0 && c->tune_score_kernel == 0) {
-        const uint64_t want_cap = 1ull << 22;                       // 4 M records = 128 MB
+    if (c->tune_score_passes == 2 && c->tune_score_kernel == 0) {
+        const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
+        if (c->score_log && c->score_log_cap != want_cap) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
         if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1) * 8) == hipSuccess) c->score_log_cap = want_cap;
         else if (!c->score_log) (void)hipGetLastError();
         c->score_log_active = c->score_log != nullptr;
@@ -1668,6 +1678,9 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
 // + LCA matrix, log table; near zero once cached), [2] pass 1 and [3] pass 2 (HIP events on the context's stream: kernels
 // + the bundle plan of a first call), [4] host wait for the passes incl. overflow pass and device-to-host copies,
 // [5] qs_score_finish (host libm + min-propagation).
+// Records the candidate log of the most recent qs_score held (single-read mode); 0 = it took two passes over the table.
+extern "C" uint64_t qs_last_score_log(const qs_ctx *c) { return c ? c->last_score_log : 0; }
+
 extern "C" int qs_last_score_ms(qs_ctx *c, float out_ms[6]) {
     if (!c || !out_ms) return QS_ERR_ARG;
     for (int i = 0; i < 6; ++i) out_ms[i] = c->score_ms[i];

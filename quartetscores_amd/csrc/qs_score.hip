@@ -449,6 +449,9 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
     const uint32_t *__restrict__ L = sd.ref_lca;
     const uint32_t n = sd.n;
     const double kHuge = sortable_to_f64(kSortableMax);
+    constexpr uint32_t kLogChunk = 64;                  // records a wave reserves at a time in the candidate log (pass 1, single-read scoring)
+    unsigned long long wbase = 0;                       // the wave's current chunk: next free record, records left (wave-uniform)
+    uint32_t wleft = 0;
     for (uint32_t round = blockIdx.x; round < sd.n_rounds; round += gridDim.x) {
         const uint32_t rk = sd.bundle_rounds[2 * round], rg = sd.bundle_rounds[2 * round + 1];
         const uint32_t b = __builtin_amdgcn_readfirstlane(rk * kBundleWaves + wave);
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             const bool logging = PASS == 1 && sd.list != nullptr;
             // (wave-uniform) stop logging once the log is full: the counter is looked at once per round
             bool log_on = logging && __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(sd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sd.list_cap)) != 0;
-            double bound = kHuge;
+            double bound = -kHuge;                  // nothing is logged before the first node pair (a run may start unresolved: key stays empty)
             QicCache qc = {0xFFFFFFFFu, 0.0, 0.0};
             uint32_t end = 0;
             for (uint32_t a0 = 0; a0 < b; a0 += CH) {                   // uniform
@@ -519,6 +522,9 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                 }
                                 if (changed) {
                                     S0 = S1 = S2 = 0; mn = kHuge;
+                                    // the pair's minimum as this CU sees it (a plain load: the L1 may hold an older value, but 34 GB of
+                                    // table stream through it, and ANY older value is still an upper bound of the final minimum; an
+                                    // agent-scope load past the L1 made pass 1 4x slower: 46.5 ms against 10.3 at 512 taxa)
                                     if (logging) { bound = nkey != kKeyEmpty ? sortable_to_f64(sd.pair_min[nkey]) : -kHuge; hprev = false; }
                                 }
                             } else if (changed) {
@@ -535,19 +541,28 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                 const bool near = qic <= fmin(bound, mn) + tol;
                                 const bool hit = near && !(hprev && n0 == h0 && n1 == h1 && n2 == h2);
                                 const unsigned long long hits = log_on ? __ballot(hit) : 0ull;
-                                if (hits) {                             // one counter update per wave instruction, not per lane
-                                    const uint32_t leader = (uint32_t)__builtin_ctzll(hits);
-                                    unsigned long long base = 0;
-                                    if (lane == leader) base = atomicAdd(sd.list_count, (unsigned long long)__builtin_popcountll(hits));
-                                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)leader) << 32) |
-                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)leader);
-                                    if (base >= sd.list_cap) log_on = false;   // overflow: the caller falls back to a second pass
-                                    const unsigned long long at = base + (unsigned long long)__builtin_popcountll(hits & ((1ull << lane) - 1ull));
-                                    if (hit && at < sd.list_cap) {
-                                        uint32_t q1, q2, q3;
-                                        permute_counts(code, n0, n1, n2, q1, q2, q3);
-                                        unsigned long long *rec = sd.list + 4 * at;
-                                        rec[0] = key; rec[1] = q1; rec[2] = q2; rec[3] = q3;
+                                if (hits) {
+                                    // The wave writes into a chunk of kLogChunk records it has reserved with ONE atomic on the log's
+                                    // counter (a single counter word takes ~88 updates per microsecond: one update per logging wave
+                                    // instruction made pass 1 4.5x slower). Records of a chunk that stay unwritten keep the key the
+                                    // host's memset put there (all ones) and are skipped by score_log_kernel.
+                                    const uint32_t cnt = (uint32_t)__builtin_popcountll(hits);
+                                    if (cnt > wleft) {                  // uniform
+                                        unsigned long long nb = 0;
+                                        if (lane == 0) nb = atomicAdd(sd.list_count, (unsigned long long)kLogChunk);
+                                        nb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nb >> 32)) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+                                        wbase = nb; wleft = kLogChunk;
+                                        if (nb + kLogChunk > sd.list_cap) { log_on = false; wleft = 0; }   // full: the caller falls back to a second pass
+                                    }
+                                    if (log_on) {
+                                        if (hit) {
+                                            uint32_t q1, q2, q3;
+                                            permute_counts(code, n0, n1, n2, q1, q2, q3);
+                                            unsigned long long *rec = sd.list + 4 * (wbase + (unsigned long long)__builtin_popcountll(hits & ((1ull << lane) - 1ull)));
+                                            rec[0] = key; rec[1] = q1; rec[2] = q2; rec[3] = q3;
+                                        }
+                                        wbase += cnt; wleft -= cnt;
                                     }
                                 }
                                 if (near) { h0 = n0; h1 = n1; h2 = n2; }
@@ -714,6 +729,7 @@ __global__ __launch_bounds__(256) void score_log_kernel(ScoreDevice sd, double t
     if (i >= n_rec) return;
     const unsigned long long *rec = sd.list + 4 * i;
     const uint32_t key = (uint32_t)rec[0], q1 = (uint32_t)rec[1], q2 = (uint32_t)rec[2], q3 = (uint32_t)rec[3];
+    if (key >= sd.n_inner * sd.n_inner) return;         // (never logged; a guard in front of the indexed reads)
     const double mag = bundle_qic_slow(sd.logk, sd.tbl_n, q1, q2, q3);
     const double qic = q1 != max(max(q1, q2), q3) ? -mag : mag;
     if (qic <= sortable_to_f64(sd.pair_min[key]) + tol) scan_candidate(sd, key, q1, q2, q3);

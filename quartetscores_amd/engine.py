@@ -185,6 +185,10 @@ class Context:
         keys = ("total", "setup", "pass1", "pass2", "wait_overflow_d2h", "host_finish")
         return {k: float(v) for k, v in zip(keys, out)}
 
+    def last_score_log(self) -> int:
+        """Records the last score() logged in single-read mode; 0 = the table was read twice."""
+        return int(self.L.qs_last_score_log(self.h))
+
     def last_count_launches(self) -> int:
         return int(self.L.qs_last_count_launches(self.h))
 

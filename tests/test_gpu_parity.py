@@ -925,6 +925,62 @@ def test_config1_fixture_on_the_gpu(eng):
     assert got == fx["scores_lq_qp_eqp_hex"]
 
 
+@pytest.mark.parametrize("kind", ["random", "collapsed", "identical", "rooted_ref", "multifurcating_ref"])
+def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
+    """qs_score's single-read mode (QS_TUNE_SCORE_PASSES = 2: pass 1 logs every quartet that is near-minimal for its node
+    pair at that moment, a filter over the log replaces pass 2; QuartetScoreComputer.hpp:417-469 visits every quartet
+    once, too): the scores are identical, bit for bit, to the default two passes and to the oracle -- also when the log
+    overflows and the call falls back to a second pass by itself (forced with a 16-record log; identical trees make
+    every quartet a minimiser)."""
+    n, m = 37, 90
+    if kind == "multifurcating_ref":
+        ref_nw = synth.tree_set(n, 1, 511, collapse=0.3)[0]
+    else:
+        ref_nw = synth.random_tree(n, np.random.default_rng(510), rooted=(kind == "rooted_ref"))
+    ref = flatten.flatten_reference(ref_nw)
+    if kind == "identical":
+        trees = [synth.reference_tree(n, 512)] * m
+    else:
+        trees = synth.tree_set(n, m, 513, collapse=0.2 if kind == "collapsed" else 0.0)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    o = oracle_counts(ref_nw, trees)
+    o.score()
+    want = o.scores_by_bipartition()
+    results = {}
+    for mode, tuning in (("single", {_lib.QS_TUNE_SCORE_PASSES: 2}), ("two", {}),
+                         ("overflow", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 16})):
+        for k_, v_ in tuning.items():
+            monkeypatch.setitem(eng.DEFAULT_TUNING, k_, v_)
+        ctx = eng.Context(ref.n_taxa, 32)
+        ctx.table_alloc()
+        ctx.count_trees(batch)
+        lq, qp, eqp, bif = ctx.score(ref)
+        results[mode] = (lq.copy(), qp.copy(), eqp.copy(), bif, ctx.last_score_log())
+        for k_ in tuning:
+            monkeypatch.delitem(eng.DEFAULT_TUNING, k_)
+    assert results["single"][4] > 0 and results["two"][4] == 0 and results["overflow"][4] == 0
+    for mode in ("two", "overflow"):
+        for i in range(3):
+            assert np.array_equal(results["single"][i], results[mode][i], equal_nan=True), (mode, i)
+    qsc_like = results["single"]
+    got = {}
+    names = ref.names
+    from quartetscores_amd import newick
+    for e in range(ref.n_nodes - 1):
+        below = frozenset(x.name for x in newick.preorder(ref.nodes[e + 1]) if x.is_leaf)
+        if len(below) <= 1 or len(below) >= n - 1:
+            continue
+        other = frozenset(names) - below
+        key = below if (len(below) < len(other) or (len(below) == len(other) and min(names) not in below)) else other
+        while key in got:
+            key = frozenset(list(key) + ["#dup"])
+        got[key] = (qsc_like[0][e + 1], qsc_like[1][e + 1] if qsc_like[3] else None, qsc_like[2][e + 1] if qsc_like[3] else None)
+    if kind != "rooted_ref":   # (the two root edges share one bipartition: their order in the two dictionaries is not defined)
+        assert set(got) == set(want)
+        for k_ in got:
+            assert got[k_] == want[k_], (sorted(k_), got[k_], want[k_])
+
+
 def test_two_cell_wire_format(eng):
     """qs_table_pack16x2 / qs_unpack16x2: one word per tuple for batches of binary trees holding all taxa; the words
     of several ranks add without carries; the unpacked table equals the three-cell one; anything else is refused."""
