@@ -564,11 +564,19 @@ def main():
     # blocks for ~0.5 s in the runtime -- that, not qs_score, was the 492 ms of round 2's driver line
     score_cold_ms = score_ms = None
     score_phases_cold = score_phases = None
-    if not args.no_score and shards == 1:
+    score_mode = None
+    if not args.no_score:
         def score_once():
             torch.cuda.synchronize(dev)
             s0 = time.perf_counter()
-            if reduce_mode == "scatter" and steps > 0:
+            if shards > 1:
+                # table-sharded mode (configs[4]): this rank's shard stays resident; pass 1 -> SUM / MIN over the ranks ->
+                # pass 2 -> gather of the candidates -> host finish (distributed.score_table_shards). With fewer ranks than
+                # shards (N = 1: one shard of 8) the other shards are simply absent: the TIME is that of one rank's share,
+                # the scores are those of the quartets this shard owns.
+                distributed.score_table_shards(lambda k: ctx, [shard_index], ref, device=dev)
+                ph = None
+            elif reduce_mode == "scatter" and steps > 0:
                 # every rank scores the shard it received (view), accumulators combined with small collectives
                 own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
                 ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
@@ -582,6 +590,8 @@ def main():
         score_cold_ms, score_phases_cold = score_once()
         warm = [score_once() for _ in range(3)]
         score_ms, score_phases = min(warm, key=lambda x: x[0])
+        score_mode = ("table shards: pass 1, SUM/MIN, pass 2, gather, finish" + ("" if world >= shards else f" ({world} of {shards} shards present)")) if shards > 1 \
+            else "reduce-scattered shard per rank" if (reduce_mode == "scatter" and steps > 0) else "qs_score"
 
     parity = None
     if binary_full_trees:              # tuples sum to m only when every tree resolves every quartet
@@ -720,6 +730,7 @@ def main():
             "prewarm_ms": args.prewarm_ms,
             "count_kernels_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
+            "score_mode": score_mode,
             "score_phase_ms": score_ms,
             "score_phase_ms_cold": score_cold_ms,
             "score_phases_ms": score_phases,
@@ -745,7 +756,14 @@ def main():
     panel_bytes = ((m + 31) // 32) * (n * (n - 1) // 2) * (max(depth_bits or 4, 4) * 4) if depth_bits else None
     if ops32:
         achieved = units_per_launch * ops32 / 32.0 / (launch_ms * 1e-3) / 1e12
+        # what the instruction mix itself allows (profiles/r03_valu_yardstick.txt): v_bcnt_u32_b32 issues at half rate, so
+        # the minimal chain of a class with B depth bits takes 2 x (ops - pops) + 4 x pops cycles, not 2 x ops
+        pops = {"binary_full": 2, "general_full": 3, "partial": 3}[mode]
+        cyc_min = sum((2 * (ops_of(b_) - pops) + 4 * pops) * cnt_ for b_, cnt_ in classes) / float(sum(cnt_ for _, cnt_ in classes))
+        mix_ceiling = 2.0 * ops32 / cyc_min
         roof = {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLOPS,
+                "issue_model": {"bcnt_half_rate": True, "min_cycles_per_unit32": cyc_min, "mix_ceiling_frac": mix_ceiling,
+                                "frac_of_mix_ceiling": achieved / VALU_PEAK_TLOPS / mix_ceiling, "source": "profiles/r03_valu_yardstick.txt"},
                 "algorithmic_ops_per_unit": ops32 / 32.0,
                 "algorithmic_ops_note": f"{ops32:.3f} wave-instr per (quartet, 32 trees): 2(B+1)+2, classes {classes}"[:100]}
     else:                                   # scatter / SWAR paths: priced against HBM with SURVEY 8(d)'s bytes

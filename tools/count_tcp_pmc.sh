@@ -3,7 +3,7 @@
 set -u
 TAG=${1:?tag}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-score --no-impl-check --prewarm-ms 0 --steps 3 --warmup 1 $*"
+ARGS="--no-cpu-baseline --no-score --no-impl-check --no-e2e --prewarm-ms 0 --steps 3 --warmup 1 $*"
 cd /tmp
 for grp in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum" "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
     name=$(echo $grp | tr ' ' '_')
