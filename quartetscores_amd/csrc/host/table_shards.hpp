@@ -87,8 +87,14 @@ public:
         // a GPU with one shard keeps it on the device between the rounds; only GPUs with several need a spill policy
         const bool any_multi = K > (size_t)G_;
         if (spill == SPILL_AUTO) {
+            // Keeping a finished shard costs a round trip through (pageable) host memory, ~8 GB/s each way; counting it again
+            // costs m x C(n,4) quartet-tree units at ~7e13 per second plus one pass over the shard per 4096 trees. Measured:
+            // 1024 taxa x 500 trees in 8 shards on one GPU: 75 s with the spill, 2.5 s with the recount. Host memory is used
+            // only when it is the cheaper of the two AND the table fits what is available.
             const uint64_t avail = host_mem_available();
-            spill = (avail && table_bytes + (table_bytes >> 3) < avail) ? SPILL_HOST : SPILL_RECOUNT;
+            const double t_spill = 2.0 * (double)table_bytes / 8e9;
+            const double t_recount = (double)m * (double)total / 7e13 + (double)((m + 4095) / 4096) * (double)table_bytes / 2e12;
+            spill = (avail && table_bytes + (table_bytes >> 3) < avail && t_spill < t_recount) ? SPILL_HOST : SPILL_RECOUNT;
         }
         spill_host_ = spill == SPILL_HOST;
         std::cout << "Counting in " << K << " table shard(s) by largest taxon id on " << G_ << " GPU(s): every GPU counts all trees into its shard(s), no table collective; ";
@@ -164,6 +170,8 @@ private:
         std::vector<std::string> spilled;      // spill = host: the finished shards
         qs_ctx *resident = nullptr;            // the one shard of a GPU that owns exactly one: stays on the device
         int64_t *d_sums = nullptr, *d_min = nullptr, *d_cand = nullptr;
+        void *table_buf = nullptr;             // a GPU with several shards: ONE allocation of the largest, attached to each in turn
+        uint64_t table_buf_bytes = 0;          // (allocating and freeing 34 GB per shard cost ~1 s of the ~1.05 s a shard took)
     };
     RefFlat ref_;
     DeviceOptions opt_;
@@ -191,8 +199,8 @@ private:
         for (PerGpu &w : gpu_) {
             (void)hipSetDevice(w.dev);
             if (w.resident) { qs_destroy(w.resident); w.resident = nullptr; }
-            (void)hipFree(w.d_sums); (void)hipFree(w.d_min); (void)hipFree(w.d_cand);
-            w.d_sums = w.d_min = w.d_cand = nullptr;
+            (void)hipFree(w.d_sums); (void)hipFree(w.d_min); (void)hipFree(w.d_cand); (void)hipFree(w.table_buf);
+            w.d_sums = w.d_min = w.d_cand = nullptr; w.table_buf = nullptr; w.table_buf_bytes = 0;
         }
     }
     static void hip_ok(hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
@@ -206,14 +214,17 @@ private:
         std::vector<int64_t> part_s(P_ * 3), part_m(P_);
         for (size_t i = 0; i < w.shards.size(); ++i) {
             const size_t k = w.shards[i];
-            qs_ctx *ctx = open_shard(k, w.dev);
+            qs_ctx *ctx = open_shard(k, w);
+            trace_mark(opt_, "shard: context + table ready");
             try {
                 count_all(ctx);
+                trace_mark(opt_, "shard: counted");
                 if (qs_score_pass1(ctx, rt_, w.d_sums, w.d_min) != QS_OK || qs_sync(ctx) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
                 hip_ok(hipMemcpy(part_s.data(), w.d_sums, P_ * 3 * 8, hipMemcpyDeviceToHost), "copy of the score sums");
                 hip_ok(hipMemcpy(part_m.data(), w.d_min, P_ * 8, hipMemcpyDeviceToHost), "copy of the score minima");
                 for (size_t j = 0; j < P_ * 3; ++j) w.sums[j] = (int64_t)((uint64_t)w.sums[j] + (uint64_t)part_s[j]);
                 for (size_t j = 0; j < P_; ++j) w.mins[j] = std::min(w.mins[j], part_m[j]);
+                trace_mark(opt_, "shard: score pass 1 done");
                 const uint64_t bytes = qs_table_bytes(ctx);
                 if (w.shards.size() == 1) { w.resident = ctx; ctx = nullptr; }
                 else if (spill_host_) {
@@ -236,7 +247,7 @@ private:
             qs_ctx *ctx = w.resident;
             w.resident = nullptr;
             if (!ctx) {
-                ctx = open_shard(k, w.dev);
+                ctx = open_shard(k, w);
                 try {
                     if (spill_host_) {
                         if (qs_table_upload(ctx, w.spilled[i].data(), w.spilled[i].size()) != QS_OK) throw std::runtime_error(qs_last_error(ctx));
@@ -258,11 +269,27 @@ private:
         }
     }
 
-    qs_ctx *open_shard(size_t k, int dev) {
+    // A GPU that owns one shard lets the context allocate it (it stays resident); a GPU with several allocates the largest
+    // of them once and attaches that buffer to one shard context after the other.
+    qs_ctx *open_shard(size_t k, PerGpu &w) {
         qs_ctx *ctx = nullptr;
-        if (qs_create(&ctx, (uint32_t)ref_.names.size(), bits_, QS_FLAG_NONE, dev, nullptr, shards_[k].first, shards_[k].second) != QS_OK)
+        if (qs_create(&ctx, (uint32_t)ref_.names.size(), bits_, QS_FLAG_NONE, w.dev, nullptr, shards_[k].first, shards_[k].second) != QS_OK)
             throw std::runtime_error(qs_last_error(nullptr));
-        if (qs_table_alloc(ctx) != QS_OK) { std::string e = qs_last_error(ctx); qs_destroy(ctx); throw std::runtime_error(e); }
+        int rc;
+        if (w.shards.size() == 1) rc = qs_table_alloc(ctx);
+        else {
+            if (!w.table_buf) {
+                auto c4 = [](uint64_t x) { return x < 4 ? (uint64_t)0 : x * (x - 1) * (x - 2) * (x - 3) / 24; };
+                uint64_t most = 0;
+                for (size_t s : w.shards) most = std::max(most, (c4(shards_[s].second) - c4(shards_[s].first)) * 3 * (bits_ / 8));
+                most = (most + 3) & ~(uint64_t)3;
+                if (hipMalloc(&w.table_buf, (size_t)most) != hipSuccess) { (void)hipGetLastError(); qs_destroy(ctx); throw std::runtime_error("Insufficient memory!"); }
+                w.table_buf_bytes = most;
+            }
+            rc = qs_table_attach(ctx, w.table_buf, w.table_buf_bytes);
+            if (rc == QS_OK) rc = qs_table_clear(ctx);
+        }
+        if (rc != QS_OK) { std::string e = qs_last_error(ctx); qs_destroy(ctx); throw std::runtime_error(e); }
         return ctx;
     }
     void count_all(qs_ctx *ctx) {

@@ -19,7 +19,8 @@
 
 // every kernel: 40 VGPRs initialised from (seed + lane), then `iters` trips of BODY (kPerTrip instructions), stamps
 // around the loop, lane 0 of every wave writes (cycles, realtime ticks)
-#define KERNEL(NAME, BODY)                                                                                           \
+#define KERNEL(NAME, BODY) KERNELX(NAME, BODY BODY BODY BODY)
+#define KERNELX(NAME, BODY)                                                                                           \
     __global__ __launch_bounds__(256) void NAME(unsigned long long *stamps, uint32_t *out, uint32_t seed, int iters) { \
         uint32_t acc;                                                                                                \
         unsigned long long t0, t1, r0, r1;                                                                           \
@@ -36,7 +37,7 @@
             "v_mul_u32_u24 v32, 59, %1\n v_mul_u32_u24 v33, 61, %1\n v_mul_u32_u24 v34, 62, %1\n v_mul_u32_u24 v35, 63, %1\n" \
             "v_mov_b32 v36, 0\n v_mov_b32 v37, 0\n v_mov_b32 v38, 0\n v_mov_b32 v39, 0\n"                            \
             "s_mov_b32 s20, %2\n s_mov_b32 s21, 0x33cc55aa\n s_mov_b32 s22, 0x5a5a1234\n s_mov_b32 s23, 0x0f0f3c3c\n"        \
-            "1:\n" BODY BODY BODY BODY                                                                                          \
+            "1:\n" BODY                                                                                          \
             "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"                                      \
             "v_xor_b32 %0, v0, v1\n v_xor_b32 %0, %0, v2\n v_xor_b32 %0, %0, v3\n v_xor_b32 %0, %0, v36\n v_xor_b32 %0, %0, v37\n" \
             : "=v"(acc) : "v"(seed + threadIdx.x * 2654435761u), "s"(iters)                                          \
@@ -121,6 +122,71 @@ KERNEL(k_slot_pk,
     GT(0,20,28) LT(1,20,28) GT(2,12,28) LT(3,12,28) GT(0,21,29) LT(1,21,29) GT(2,13,29) LT(3,13,29)
     BC(36,0) BC0(14,1) BC(38,2) BC0(15,3) LA(36,14) LA(38,15)
     GT(4,16,30) LT(5,16,30))
+// 10b. the same 96 v_bitop3 + 16 v_bcnt + 16 v_bitop3 per trip, but the popcounts in groups: after every TWO slots (8 in a row)
+//      and after every FOUR slots (16 in a row): does interleaving 4 half-rate popcounts per 24 full-rate ops cost extra?
+#define CH6(g, l, r) GT(g,l,r) LT(g##1,l,r)
+#define SLOTCH(a0,a1,a2,a3, R0,R1,R2,R3,R4,R5) \
+    GT(a0,16,R0) LT(a1,16,R0) GT(a2,8,R0) LT(a3,8,R0) GT(a0,17,R1) LT(a1,17,R1) GT(a2,9,R1) LT(a3,9,R1) \
+    GT(a0,18,R2) LT(a1,18,R2) GT(a2,10,R2) LT(a3,10,R2) GT(a0,19,R3) LT(a1,19,R3) GT(a2,11,R3) LT(a3,11,R3) \
+    GT(a0,20,R4) LT(a1,20,R4) GT(a2,12,R4) LT(a3,12,R4) GT(a0,21,R5) LT(a1,21,R5) GT(a2,13,R5) LT(a3,13,R5)
+#define FILL4 GT(14,16,30) LT(15,16,30) GT(14,8,30) LT(15,8,30)
+KERNELX(k_slot_g1,
+    SLOTCH(0,1,2,3, 24,25,26,27,28,29) BC(36,0) BC(37,1) BC(38,2) BC(39,3) FILL4
+    SLOTCH(4,5,6,7, 24,25,26,27,28,29) BC(36,4) BC(37,5) BC(38,6) BC(39,7) FILL4
+    SLOTCH(0,1,2,3, 25,26,27,28,29,24) BC(36,0) BC(37,1) BC(38,2) BC(39,3) FILL4
+    SLOTCH(4,5,6,7, 25,26,27,28,29,24) BC(36,4) BC(37,5) BC(38,6) BC(39,7) FILL4)
+KERNELX(k_slot_g2,
+    SLOTCH(0,1,2,3, 24,25,26,27,28,29) SLOTCH(4,5,6,7, 24,25,26,27,28,29)
+    BC(36,0) BC(37,1) BC(38,2) BC(39,3) BC(36,4) BC(37,5) BC(38,6) BC(39,7) FILL4 FILL4
+    SLOTCH(0,1,2,3, 25,26,27,28,29,24) SLOTCH(4,5,6,7, 25,26,27,28,29,24)
+    BC(36,0) BC(37,1) BC(38,2) BC(39,3) BC(36,4) BC(37,5) BC(38,6) BC(39,7) FILL4 FILL4)
+KERNELX(k_slot_g4,
+    SLOTCH(0,1,2,3, 24,25,26,27,28,29) SLOTCH(4,5,6,7, 24,25,26,27,28,29) SLOTCH(32,33,34,35, 25,26,27,28,29,24) SLOTCH(22,23,31,30, 25,26,27,28,29,24)
+    BC(36,0) BC(37,1) BC(38,2) BC(39,3) BC(36,4) BC(37,5) BC(38,6) BC(39,7) BC(36,32) BC(37,33) BC(38,34) BC(39,35) BC(36,22) BC(37,23) BC(38,31) BC(39,30)
+    FILL4 FILL4 FILL4 FILL4)
+// 12. VGPR source banks (register number mod 4). v_add3_u32 d = d + a + b with the three sources in three banks / a and b in one / all in one
+#define ADD3(d, a, b) "v_add3_u32 v" #d ", v" #d ", v" #a ", v" #b "\n"
+KERNEL(k_add3_nc,
+    ADD3(0,17,22) ADD3(1,18,23) ADD3(2,19,20) ADD3(3,16,21) ADD3(4,25,30) ADD3(5,26,31) ADD3(6,27,28) ADD3(7,24,29) ADD3(8,17,22) ADD3(9,18,23) ADD3(10,19,20) ADD3(11,16,21) ADD3(12,25,30) ADD3(13,26,31) ADD3(14,27,28) ADD3(15,24,29)
+    ADD3(0,17,22) ADD3(1,18,23) ADD3(2,19,20) ADD3(3,16,21) ADD3(4,25,30) ADD3(5,26,31) ADD3(6,27,28) ADD3(7,24,29) ADD3(8,17,22) ADD3(9,18,23) ADD3(10,19,20) ADD3(11,16,21) ADD3(12,25,30) ADD3(13,26,31) ADD3(14,27,28) ADD3(15,24,29))
+KERNEL(k_add3_c2,
+    ADD3(0,17,21) ADD3(1,18,22) ADD3(2,19,23) ADD3(3,16,20) ADD3(4,25,29) ADD3(5,26,30) ADD3(6,27,31) ADD3(7,24,28) ADD3(8,17,21) ADD3(9,18,22) ADD3(10,19,23) ADD3(11,16,20) ADD3(12,25,29) ADD3(13,26,30) ADD3(14,27,31) ADD3(15,24,28)
+    ADD3(0,17,21) ADD3(1,18,22) ADD3(2,19,23) ADD3(3,16,20) ADD3(4,25,29) ADD3(5,26,30) ADD3(6,27,31) ADD3(7,24,28) ADD3(8,17,21) ADD3(9,18,22) ADD3(10,19,23) ADD3(11,16,20) ADD3(12,25,29) ADD3(13,26,30) ADD3(14,27,31) ADD3(15,24,28))
+KERNEL(k_add3_c3,
+    ADD3(0,16,20) ADD3(1,17,21) ADD3(2,18,22) ADD3(3,19,23) ADD3(4,24,28) ADD3(5,25,29) ADD3(6,26,30) ADD3(7,27,31) ADD3(8,16,20) ADD3(9,17,21) ADD3(10,18,22) ADD3(11,19,23) ADD3(12,24,28) ADD3(13,25,29) ADD3(14,26,30) ADD3(15,27,31)
+    ADD3(0,16,20) ADD3(1,17,21) ADD3(2,18,22) ADD3(3,19,23) ADD3(4,24,28) ADD3(5,25,29) ADD3(6,26,30) ADD3(7,27,31) ADD3(8,16,20) ADD3(9,17,21) ADD3(10,18,22) ADD3(11,19,23) ADD3(12,24,28) ADD3(13,25,29) ADD3(14,26,30) ADD3(15,27,31))
+// v_and_b32 with both sources (and the destination) in one bank
+KERNEL(k_and_c,
+    A2(0,0,16) A2(1,1,17) A2(2,2,18) A2(3,3,19) A2(4,4,20) A2(5,5,21) A2(6,6,22) A2(7,7,23) A2(8,8,24) A2(9,9,25) A2(10,10,26) A2(11,11,27) A2(12,12,28) A2(13,13,29) A2(14,14,30) A2(15,15,31)
+    A2(0,0,16) A2(1,1,17) A2(2,2,18) A2(3,3,19) A2(4,4,20) A2(5,5,21) A2(6,6,22) A2(7,7,23) A2(8,8,24) A2(9,9,25) A2(10,10,26) A2(11,11,27) A2(12,12,28) A2(13,13,29) A2(14,14,30) A2(15,15,31))
+// the slot's mix with NO two sources of an instruction in one bank / L and R planes in one bank / accumulator in R's bank
+KERNEL(k_slot_nc,
+    GT(2,16,25) LT(3,16,25) GT(6,8,25) LT(7,8,25)
+    GT(3,17,26) LT(0,17,26) GT(7,9,26) LT(4,9,26)
+    GT(0,18,27) LT(1,18,27) GT(4,10,27) LT(5,10,27)
+    GT(1,19,28) LT(2,19,28) GT(5,11,28) LT(6,11,28)
+    GT(2,20,29) LT(3,20,29) GT(6,12,29) LT(7,12,29)
+    GT(3,21,30) LT(0,21,30) GT(7,13,30) LT(4,13,30)
+    BC(36,1) BC(37,2) BC(38,3) BC(39,0)
+    GT(2,16,25) LT(3,16,25) GT(6,8,25) LT(7,8,25))
+KERNEL(k_slot_clr,
+    GT(1,16,24) LT(2,16,24) GT(5,8,24) LT(6,8,24)
+    GT(2,17,25) LT(3,17,25) GT(6,9,25) LT(7,9,25)
+    GT(3,18,26) LT(0,18,26) GT(7,10,26) LT(4,10,26)
+    GT(0,19,27) LT(1,19,27) GT(4,11,27) LT(5,11,27)
+    GT(1,20,28) LT(2,20,28) GT(5,12,28) LT(6,12,28)
+    GT(2,21,29) LT(3,21,29) GT(6,13,29) LT(7,13,29)
+    BC(36,1) BC(37,2) BC(38,3) BC(39,0)
+    GT(1,16,24) LT(2,16,24) GT(5,8,24) LT(6,8,24))
+KERNEL(k_slot_cacc,
+    GT(1,16,25) LT(5,16,25) GT(33,8,25) LT(1,8,25)
+    GT(2,17,26) LT(6,17,26) GT(34,9,26) LT(2,9,26)
+    GT(3,18,27) LT(7,18,27) GT(35,10,27) LT(3,10,27)
+    GT(0,19,28) LT(4,19,28) GT(32,11,28) LT(0,11,28)
+    GT(1,20,29) LT(5,20,29) GT(33,12,29) LT(1,12,29)
+    GT(2,21,30) LT(6,21,30) GT(34,13,30) LT(2,13,30)
+    BC(36,1) BC(37,2) BC(38,3) BC(39,0)
+    GT(1,16,25) LT(5,16,25) GT(33,8,25) LT(1,8,25))
 // 11. 24 v_bitop3 + 8 v_add_u32 (is the slot's excess over 2 cycles the popcount or the mix?)
 KERNEL(k_slot_add,
     GT(0,16,24) LT(1,16,24) GT(2,8,24) LT(3,8,24) GT(0,17,25) LT(1,17,25) GT(2,9,25) LT(3,9,25)
@@ -199,7 +265,7 @@ int main(int argc, char **argv) {
     struct V { const char *name; kern_t k; } vs[] = {
         {"v_and_b32 indep", k_and}, {"v_add_u32 indep", k_add}, {"v_bitop3 3 banks", k_b3_diff}, {"v_bitop3 1 bank", k_b3_same},
         {"v_bitop3 1 chain", k_b3_chain1}, {"v_bitop3 sgpr src", k_b3_sgpr}, {"v_bcnt acc", k_bcnt}, {"v_bcnt +0", k_bcnt0},
-        {"slot 28/32 (B=5)", k_slot}, {"slot packed ctrs", k_slot_pk}, {"slot, add for bcnt", k_slot_add},
+        {"slot 28/32 (B=5)", k_slot}, {"slots, bcnt x4", k_slot_g1}, {"slots, bcnt x8", k_slot_g2}, {"slots, bcnt x16", k_slot_g4}, {"slot, no bank conflict", k_slot_nc}, {"slot, L/R one bank", k_slot_clr}, {"slot, acc in R bank", k_slot_cacc}, {"v_add3 3 banks", k_add3_nc}, {"v_add3 2 in a bank", k_add3_c2}, {"v_add3 1 bank", k_add3_c3}, {"v_and_b32 1 bank", k_and_c}, {"slot packed ctrs", k_slot_pk}, {"slot, add for bcnt", k_slot_add},
         {"v_lshl_add_u32", k_lshladd}, {"v_mad_u32_u24", k_mad24}};
     // pre-warm: 1.5 s of VALU work so that the clock has settled before the first measured variant
     for (int i = 0; i < 3; ++i) run(k_slot, d_st, d_out, 4, 500.0);
