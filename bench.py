@@ -586,12 +586,15 @@ def main():
             else:
                 ctx.score(ref)
                 ph = {k_: round(v_, 3) for k_, v_ in ctx.last_score_ms().items()}
+                ph["log_records"] = ctx.last_score_log()          # > 0: the table was read ONCE (pass2 = filter over the log)
+                ph["log_predicted"] = ctx.last_score_estimate()
             return (time.perf_counter() - s0) * 1e3, ph
         score_cold_ms, score_phases_cold = score_once()
         warm = [score_once() for _ in range(3)]
         score_ms, score_phases = min(warm, key=lambda x: x[0])
         score_mode = ("table shards: pass 1, SUM/MIN, pass 2, gather, finish" + ("" if world >= shards else f" ({world} of {shards} shards present)")) if shards > 1 \
-            else "reduce-scattered shard per rank" if (reduce_mode == "scatter" and steps > 0) else "qs_score"
+            else "reduce-scattered shard per rank" if (reduce_mode == "scatter" and steps > 0) \
+            else ("qs_score: one read (sampled bounds, candidate log)" if (score_phases or {}).get("log_records") else "qs_score: two passes")
 
     parity = None
     if binary_full_trees:              # tuples sum to m only when every tree resolves every quartet

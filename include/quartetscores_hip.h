@@ -170,10 +170,15 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_TABLE_TREES 8u        /* number of trees behind a table this context did not count itself (reduced over GPUs, uploaded,
                                        * attached or viewed): sizes the log table of the device QIC so that every count takes the
                                        * table path (speed only; scores never depend on it). 0 = what the context counted (default) */
-#define QS_TUNE_SCORE_PASSES 10u      /* qs_score: 0 / 1 = two passes over the table (default), 2 = single read (pass 1 logs the candidates, a
-                                       * filter over the log replaces pass 2; falls back to pass 2 when the log overflows). Measured
-                                       * slower on MI355X: an option for A/B runs and tests */
+#define QS_TUNE_SCORE_PASSES 10u      /* qs_score: 0 = automatic (default), 1 = two passes over the table, 2 = single read. Single read: a
+                                       * minima-only pre-pass over a sample of the table, then ONE pass that adds the sums, lowers the
+                                       * minima and logs every quartet within the tolerance of the bound it knows (a superset of pass 2's
+                                       * candidates); a filter over the log replaces pass 2; pass 2 still runs when the log overflows.
+                                       * Automatic: single read for tables from 1 GB unless a second sample predicts that the log would
+                                       * not hold (tie-heavy tables) -- 14.1 instead of 21.8 ms at 512 taxa */
 #define QS_TUNE_SCORE_LOG_CAP 11u     /* records the candidate log of the single-read scoring may hold (0 = 8 M = 256 MB); tests force overflows */
+#define QS_TUNE_SCORE_SAMPLE 12u      /* single-read scoring: the pre-pass takes one round in S (value = S | 65536; default S = 64) or one 96-byte
+                                       * chunk of every row in S (value = S); S a power of two; 0 = no pre-pass (and no automatic mode) */
 #define QS_TUNE_COOP 9u               /* binary full batches: 1 = run the tiles with two a-blocks through count_bitslice4_kernel, whose
                                        * workgroups (four consecutive third ids of one (a,b,d) tile) share their panel loads through
                                        * LDS; 0 / 2 = off (default: the barrier it needs costs more than the loads it saves) */
@@ -330,9 +335,11 @@ int qs_last_count_launches(const qs_ctx *ctx);
  * (HIP events on the context's stream; [3] = the filter over pass 1's candidate log in single-read mode), [4] host wait for the passes incl. the overflow pass and the accumulators' way
  * back, [5] qs_score_finish (host libm + min-propagation; QuartetScoreComputer.hpp:448-454,484-489). */
 int qs_last_score_ms(qs_ctx *ctx, float out_ms[6]);
-/* Records in the candidate log of the most recent qs_score in single-read mode (QS_TUNE_SCORE_PASSES = 2); 0 = it read the
- * table twice (the default, or the log overflowed). */
+/* Records in the candidate log of the most recent qs_score when it read the table once; 0 = it read the table twice (two
+ * passes asked for, a table below 1 GB, a predicted or an actual overflow of the log). */
 uint64_t qs_last_score_log(const qs_ctx *ctx);
+/* Automatic mode: the log size the most recent qs_score predicted from its sample (hits of the sample x S); 0 = no estimate ran. */
+uint64_t qs_last_score_estimate(const qs_ctx *ctx);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);
 /* How score passes 1 and 2 decompose the tuples [rank_lo, rank_lo + n_tuples) of an n_taxa table (host arithmetic only,

@@ -18,7 +18,7 @@ QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64, QS_SCORE_ROOT_AS_EDGE = 0, 1, 2
 QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
-QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP = 5, 6, 7, 8, 9, 10, 11
+QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE = 5, 6, 7, 8, 9, 10, 11, 12
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares
@@ -28,7 +28,7 @@ EXPORTS = [
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
-    "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log",
+    "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate",
 ]
 
 
@@ -142,6 +142,8 @@ def load():
     L.qs_last_count_ms.argtypes = [vp, C.POINTER(C.c_float * 3)]
     L.qs_last_score_log.restype = u64
     L.qs_last_score_log.argtypes = [vp]
+    L.qs_last_score_estimate.restype = u64
+    L.qs_last_score_estimate.argtypes = [vp]
     L.qs_prepare.restype = i32
     L.qs_prepare.argtypes = [vp, u64]
     L.qs_last_score_ms.restype = i32

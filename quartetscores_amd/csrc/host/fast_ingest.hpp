@@ -19,7 +19,48 @@
 
 namespace qsh {
 
+// Taxon name -> lookup id without building a std::string and hashing it through std::unordered_map per leaf (which was
+// ~1/3 of the flatten time of a 512-taxon tree): open addressing over FNV-1a hashes of the bytes, the names themselves
+// stay in the caller's map (verified with memcmp, so a hash collision can never return a wrong id).
+struct NameTable {
+    struct Slot { uint64_t h; const std::string *name; uint32_t id; };
+    std::vector<Slot> slots;
+    uint64_t mask = 0;
+    const void *built_for = nullptr;
+    size_t built_n = 0;
+    static uint64_t hash(const char *p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+        return h | 1ull;                                   // 0 marks an empty slot
+    }
+    void build(const std::unordered_map<std::string, uint32_t> &m) {
+        size_t cap = 16;
+        while (cap < 4 * m.size()) cap <<= 1;
+        slots.assign(cap, Slot{0, nullptr, 0});
+        mask = cap - 1;
+        for (const auto &kv : m) {
+            const uint64_t h = hash(kv.first.data(), kv.first.size());
+            size_t i = (size_t)(h & mask);
+            while (slots[i].h) i = (i + 1) & mask;
+            slots[i] = Slot{h, &kv.first, kv.second};
+        }
+        built_for = &m; built_n = m.size();
+    }
+    // id of the name text[p, p + n), or -1
+    int64_t find(const char *p, size_t n) const {
+        const uint64_t h = hash(p, n);
+        for (size_t i = (size_t)(h & mask);; i = (i + 1) & mask) {
+            const Slot &sl = slots[i];
+            if (!sl.h) return -1;
+            if (sl.h == h && sl.name->size() == n && std::memcmp(sl.name->data(), p, n) == 0) return sl.id;
+        }
+    }
+};
+
 struct FlatScratch {
+    NameTable names;
+    std::vector<uint32_t> seen;           // per lookup id: number of the last tree that held it + 1 (duplicate check without a sort)
+    uint32_t tree_no = 0;
     std::vector<int32_t> parent;
     std::vector<uint32_t> lab_b, lab_e;   // label = text[lab_b, lab_e) (empty span = none); quoted labels: see qidx
     std::vector<int32_t> qidx;            // -1, or index into `quoted` (labels that needed unescaping)
@@ -121,6 +162,13 @@ inline void parse_flat(const std::string &text, size_t b, size_t e, FlatScratch 
 inline void parse_flatten_append(const std::string &text, size_t b, size_t e, const std::unordered_map<std::string, uint32_t> &name_to_id,
                                  BatchFlat &batch, FlatScratch &s, bool recentre = true, bool want_ranges = true) {
     detail::parse_flat(text, b, e, s);
+    if (s.names.built_for != &name_to_id || s.names.built_n != name_to_id.size()) {
+        s.names.build(name_to_id);
+        uint32_t top = 0;
+        for (const auto &kv : name_to_id) top = std::max(top, kv.second + 1);
+        s.seen.assign(top, 0); s.tree_no = 0;
+    }
+    if (++s.tree_no == 0) { std::fill(s.seen.begin(), s.seen.end(), 0u); s.tree_no = 1; }
     const size_t N = s.parent.size();
     // CSR adjacency, neighbour order = [parent, children in input order]
     s.nchild.assign(N, 0);
@@ -173,7 +221,6 @@ inline void parse_flatten_append(const std::string &text, size_t b, size_t e, co
     s.st.clear();
     s.st.push_back({r, -1, 0});
     uint32_t L = 0, cur_min = 0;
-    const size_t ids0 = batch.leaf_ids.size();
     while (!s.st.empty()) {
         FlatScratch::Frame &f = s.st.back();   // edited in place; re-read nothing from it after a push_back
         const int32_t x = f.x;
@@ -186,13 +233,15 @@ inline void parse_flatten_append(const std::string &text, size_t b, size_t e, co
                 s.ipar[x] = (int32_t)q;
             }
             if (nkids(x) == 0) {
-                if (s.qidx[x] >= 0) s.key = s.quoted[s.qidx[x]];
-                else s.key.assign(text, s.lab_b[x], s.lab_e[x] - s.lab_b[x]);
-                const auto it = name_to_id.find(s.key);
-                if (it == name_to_id.end()) throw UnknownTaxon("unknown taxon '" + s.key + "' in evaluation tree " + std::to_string(batch.n_trees));
+                const char *lp = s.qidx[x] >= 0 ? s.quoted[s.qidx[x]].data() : text.data() + s.lab_b[x];
+                const size_t ln = s.qidx[x] >= 0 ? s.quoted[s.qidx[x]].size() : (size_t)(s.lab_e[x] - s.lab_b[x]);
+                const int64_t id = s.names.find(lp, ln);
+                if (id < 0) throw UnknownTaxon("unknown taxon '" + std::string(lp, ln) + "' in evaluation tree " + std::to_string(batch.n_trees));
+                if (s.seen[(size_t)id] == s.tree_no) throw std::runtime_error("duplicate taxon in evaluation tree " + std::to_string(batch.n_trees));
+                s.seen[(size_t)id] = s.tree_no;
                 if (L > 0) batch.adj_depth.push_back((uint16_t)std::min<uint32_t>(cur_min, 0xFFFFu));
                 cur_min = 1u << 30;
-                batch.leaf_ids.push_back((uint16_t)it->second);
+                batch.leaf_ids.push_back((uint16_t)id);
                 ++L;
                 s.end[x] = L;
                 s.st.pop_back();
@@ -211,10 +260,6 @@ inline void parse_flatten_append(const std::string &text, size_t b, size_t e, co
         }
     }
     if (L > 0) batch.adj_depth.push_back(0);
-    s.tmp.assign(batch.leaf_ids.begin() + ids0, batch.leaf_ids.end());
-    std::sort(s.tmp.begin(), s.tmp.end());
-    if (std::adjacent_find(s.tmp.begin(), s.tmp.end()) != s.tmp.end())
-        throw std::runtime_error("duplicate taxon in evaluation tree " + std::to_string(batch.n_trees));
     batch.leaf_off.push_back((uint32_t)batch.leaf_ids.size());
     // leaf ranges of the links of the inner nodes: only the scatter kernel reads them
     for (size_t x = 0; want_ranges && x < N && L > 0; ++x) {

@@ -120,8 +120,12 @@ struct qs_ctx {
     unsigned long long *score_log = nullptr;     // log_cap records of 4 words + 1 word counter behind them
     uint64_t score_log_cap = 0;
     bool score_log_active = false;               // set by qs_score around its pass 1
-    uint32_t tune_score_passes = 0;              // QS_TUNE_SCORE_PASSES: 0 / 1 = two passes over the table (default), 2 = single read (measured slower)
+    uint32_t tune_score_passes = 0;              // QS_TUNE_SCORE_PASSES: 0 = automatic (default), 1 = two passes over the table, 2 = single read
+    void *score_acc = nullptr, *score_acc_host = nullptr;   // qs_score's accumulators on the device + their pinned host copy (cached)
+    size_t score_acc_cap = 0, score_acc_host_cap = 0;
+    uint64_t last_score_estimate = 0;            // automatic single-read mode: predicted log records of the last qs_score (sample x S)
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
+    uint32_t tune_score_sample = 64u | 65536u;             // QS_TUNE_SCORE_SAMPLE: pre-pass of the single-read scoring (0 = none; S | by-round bit 16)
     uint64_t tune_score_log_cap = 0;             // QS_TUNE_SCORE_LOG_CAP: records the log may hold (0 = 8 M); tests force overflows
 };
 
@@ -334,11 +338,16 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             return QS_OK;
         case QS_TUNE_PANEL_SLICE_BYTES: c->tune_slice_bytes = value; return QS_OK;
         case QS_TUNE_TABLE_TREES: c->table_trees_hint = value; return QS_OK;
+        case QS_TUNE_SCORE_SAMPLE: {
+            const uint64_t S = value & 0xFFFFu;
+            if (value >> 17 || (value && (S < 2 || (S & (S - 1))))) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_SAMPLE takes 0 or a power of two in [2, 32768], optionally | 65536 (whole rounds)");
+            c->tune_score_sample = (uint32_t)value; return QS_OK;
+        }
         case QS_TUNE_SCORE_LOG_CAP:
             if (value > (1ull << 26)) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOG_CAP takes at most 2^26 records");
             c->tune_score_log_cap = value; return QS_OK;
         case QS_TUNE_SCORE_PASSES:
-            if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_PASSES takes 0 / 1 (two passes) or 2 (single read)");
+            if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_PASSES takes 0 (automatic), 1 (two passes) or 2 (single read)");
             c->tune_score_passes = (uint32_t)value; return QS_OK;
         case QS_TUNE_COOP:
             if (value > 2) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_COOP takes 0 (default: off), 1 (on) or 2 (off)");
@@ -455,6 +464,8 @@ extern "C" void qs_destroy(qs_ctx *c) {
     for (BatchSlab &sl : c->slabs) { (void)hipFree(sl.p); if (sl.last_use) (void)hipEventDestroy(sl.last_use); }
     for (hipEvent_t e : c->score_ev) if (e) (void)hipEventDestroy(e);
     if (c->score_log) (void)hipFree(c->score_log);
+    if (c->score_acc) (void)hipFree(c->score_acc);
+    if (c->score_acc_host) (void)hipHostFree(c->score_acc_host);
     delete c->ref_cache;
     delete c;
 }
@@ -1285,7 +1296,7 @@ static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t 
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
     sd.cand_limit = c->tune_cand_slots; sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
     sd.frame = R.bifurcating ? 0 : 1;
-    sd.bundle_plo = sd.bundle_pcnt = sd.bundle_rounds = nullptr; sd.n_rounds = 0;
+    sd.bundle_plo = sd.bundle_pcnt = sd.bundle_rounds = nullptr; sd.n_rounds = 0; sd.sample = 0;
 }
 
 // the bundle kernel's rounds for the rank range sd covers (own table, table shard or view): planned on the host, cached
@@ -1362,8 +1373,30 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     if (c->score_log_active && c->tune_score_kernel == 0 && c->bundle[0].n_parts == 0 && c->score_log) {
         sd.list = c->score_log; sd.list_count = c->score_log + 4 * c->score_log_cap; sd.list_cap = c->score_log_cap;
         QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+        if (c->tune_score_sample) {   // minima-only pre-pass over a sample of the table: the bound the logging pass starts from
+            ScoreDevice pre = sd;
+            pre.list = nullptr; pre.list_count = nullptr; pre.list_cap = 0; pre.sample = c->tune_score_sample;
+            QS_HIP(c, launch_score_pass1(c->stream, pre, 0, c->n_cu, nullptr, nullptr, 0, 0.0));
+            if (c->tune_score_passes != 2) {
+                // automatic mode: a second, disjoint sample counts what the logging pass would log of it; the full pass
+                // logs only if S x that count fits the log with room to spare, else pass 1 runs plain and pass 2 follows
+                pre.list_count = sd.list_count; pre.sample = c->tune_score_sample | (1u << 17);
+                QS_HIP(c, launch_score_pass1(c->stream, pre, 0, c->n_cu, nullptr, nullptr, 0, c->tune_score_tol));
+                unsigned long long hits = 0;
+                QS_HIP(c, hipMemcpyAsync(&hits, sd.list_count, 8, hipMemcpyDeviceToHost, c->stream));
+                QS_HIP(c, hipStreamSynchronize(c->stream));
+                c->last_score_estimate = hits * (c->tune_score_sample & 0xFFFFu);
+                // The static bounds of the sample over-predict: the full pass also lowers the minima as it goes and a lane keeps
+                // its own running minimum (measured: 12.8 M predicted / 2.2 M logged at 512 taxa x 10000 random trees, 3.7 M /
+                // 0.75 M at 256 taxa; reference + NNI trees: 90 M predicted, log of 8 M overflows): go ahead up to 3 x the log.
+                if ((double)c->last_score_estimate > 3.0 * (double)c->score_log_cap) {
+                    c->score_log_active = false;
+                    sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
+                } else QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+            }
+        }
         // waves reserve whole chunks of records: what they leave unwritten must read as "no record" (key = all ones)
-        QS_HIP(c, hipMemsetAsync(c->score_log, 0xFF, (size_t)c->score_log_cap * 32, c->stream));
+        if (c->score_log_active) QS_HIP(c, hipMemsetAsync(c->score_log, 0xFF, (size_t)c->score_log_cap * 32, c->stream));
     } else c->score_log_active = false;   // (partial rows / scan kernel: the caller falls back to two passes)
     QS_HIP(c, launch_score_pass1(c->stream, sd, c->tune_score_kernel, c->n_cu, c->bundle[0].part_lo, c->bundle[0].part_n, c->bundle[0].n_parts, c->tune_score_tol));
     // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
@@ -1596,10 +1629,26 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     const clk::time_point t_all = clk::now();
     for (hipEvent_t &e : c->score_ev) if (!e) QS_HIP(c, hipEventCreate(&e));
     for (float &x : c->score_ms) x = 0;
-    DevPtr sums, mn, cand;
-    QS_HIP(c, hipMalloc(&sums.p, np * 3 * 8));
-    QS_HIP(c, hipMalloc(&mn.p, np * 8));
-    QS_HIP(c, hipMalloc(&cand.p, np * kCand * 8));
+    // the accumulators (sums, minima, candidate slots: 24 MB at 512 taxa) and their pinned host copy live in the context: three
+    // hipMalloc / hipFree pairs and a pageable 22 MB copy per call were 1 ms of a 15 ms call
+    struct Ptr { void *p; } sums{nullptr}, mn{nullptr}, cand{nullptr};
+    {
+        const size_t need_dev = np * (size_t)(3 + 1 + kCand) * 8, need_host = np * (size_t)(3 + kCand) * 8;
+        if (c->score_acc_cap < need_dev) {
+            QS_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->score_acc) (void)hipFree(c->score_acc);
+            c->score_acc = nullptr; c->score_acc_cap = 0;
+            QS_HIP(c, hipMalloc(&c->score_acc, need_dev));
+            c->score_acc_cap = need_dev;
+        }
+        if (c->score_acc_host_cap < need_host) {
+            if (c->score_acc_host) (void)hipHostFree(c->score_acc_host);
+            c->score_acc_host = nullptr; c->score_acc_host_cap = 0;
+            QS_HIP(c, hipHostMalloc(&c->score_acc_host, need_host, hipHostMallocDefault));
+            c->score_acc_host_cap = need_host;
+        }
+        sums.p = c->score_acc; mn.p = (char *)c->score_acc + np * 3 * 8; cand.p = (char *)c->score_acc + np * 4 * 8;
+    }
     {   // the cached pieces both passes need (reference tree + LCA matrix, log table, bundle plans): built here so that
         // the first call's set-up cost shows as its own phase and the events below bracket kernels only
         const RefHost *Rp = nullptr;
@@ -1616,7 +1665,12 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     // overflows 8 M records there (the bound a lane sees is too stale to prune), at 256 taxa 2.3 + 0.3 ms against 2.6 ms for
     // both plain passes (profiles/r03_experiments.md section 6).
     c->last_score_log = 0;
-    if (c->tune_score_passes == 2 && c->tune_score_kernel == 0) {
+    // 0 = automatic: single read for tables from 1 GB (below that the two extra launches cost more than the second pass) when
+    // the sampled estimate says the log will hold; 1 = two passes; 2 = single read whatever the estimate (falls back on overflow)
+    const bool want_single = c->tune_score_passes == 2 || (c->tune_score_passes == 0 && c->tune_score_sample != 0 && !c->view_table &&
+                                                            qs_table_bytes(c) >= (1ull << 30));
+    c->last_score_estimate = 0;
+    if (want_single && c->tune_score_kernel == 0) {
         const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
         if (c->score_log && c->score_log_cap != want_cap) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
         if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1) * 8) == hipSuccess) c->score_log_cap = want_cap;
@@ -1660,15 +1714,15 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     rc = qs_score_overflow(c, ref, (const int64_t *)mn.p, (const int64_t *)cand.p, &extra, &n_extra);   // synchronises the stream
     if (rc != QS_OK) return rc;
     struct FreeHost { int64_t *p; ~FreeHost() { free(p); } } free_extra{extra};
-    std::vector<int64_t> hs(np * 3), hc(np * kCand);
-    QS_HIP(c, hipMemcpyAsync(hs.data(), sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
-    QS_HIP(c, hipMemcpyAsync(hc.data(), cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
+    int64_t *hs = (int64_t *)c->score_acc_host, *hc = hs + np * 3;
+    QS_HIP(c, hipMemcpyAsync(hs, sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+    QS_HIP(c, hipMemcpyAsync(hc, cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
     QS_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipEventElapsedTime(&c->score_ms[2], c->score_ev[0], c->score_ev[1]);
     (void)hipEventElapsedTime(&c->score_ms[3], c->score_ev[1], c->score_ev[2]);
     c->score_ms[4] = ms_since(t_ov);            // waiting for the passes + overflow pass (if any) + the accumulators' way back
     const clk::time_point t_fin = clk::now();
-    rc = qs_score_finish(c, ref, flags, hs.data(), hc.data(), 1, extra, n_extra, lqic, qpic, eqpic, is_bifurcating);
+    rc = qs_score_finish(c, ref, flags, hs, hc, 1, extra, n_extra, lqic, qpic, eqpic, is_bifurcating);
     c->score_ms[5] = ms_since(t_fin);
     c->score_ms[0] = ms_since(t_all);
     return rc;
@@ -1680,6 +1734,7 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
 // [5] qs_score_finish (host libm + min-propagation).
 // Records the candidate log of the most recent qs_score held (single-read mode); 0 = it took two passes over the table.
 extern "C" uint64_t qs_last_score_log(const qs_ctx *c) { return c ? c->last_score_log : 0; }
+extern "C" uint64_t qs_last_score_estimate(const qs_ctx *c) { return c ? c->last_score_estimate : 0; }
 
 extern "C" int qs_last_score_ms(qs_ctx *c, float out_ms[6]) {
     if (!c || !out_ms) return QS_ERR_ARG;

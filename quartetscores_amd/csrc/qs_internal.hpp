@@ -116,6 +116,8 @@ struct ScoreDevice {
     const uint32_t *bundle_pcnt;
     const uint32_t *bundle_rounds; // n_rounds x (b / 16, pair group)
     uint32_t n_rounds;
+    uint32_t sample;               // pass 1, bundle kernel: 0 = every chunk; else the minima-only pre-pass of the single-read scoring:
+                                   //    bits 0..15 = S (a power of two): one chunk (bit 16 clear) or one round (bit 16 set) in S
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
                                    //    order of the multifurcating / raw-QIC loops (QSC:551-558, 661-668)
 };

@@ -452,7 +452,22 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
     constexpr uint32_t kLogChunk = 64;                  // records a wave reserves at a time in the candidate log (pass 1, single-read scoring)
     unsigned long long wbase = 0;                       // the wave's current chunk: next free record, records left (wave-uniform)
     uint32_t wleft = 0;
-    for (uint32_t round = blockIdx.x; round < sd.n_rounds; round += gridDim.x) {
+    // The minima-only pre-pass of the single-read scoring (sd.sample): a sample of the table -- one 96-byte chunk of every row
+    // in S, or one round in S -- lowers pair_min to the sample's minimum and adds NOTHING to the sums, so that the logging
+    // pass that follows starts every run with a bound close to the final minimum (min is idempotent: taking the sample's
+    // quartets twice changes nothing).
+    // Estimate mode (bit 17): the same over ANOTHER sample (offset S/2), with the logging condition evaluated against the
+    // bounds the first pre-pass left and the hits only counted (sd.list_count += hits): S x that count predicts the log of
+    // the full pass, and the host falls back to two plain passes when it would not fit (tie-heavy tables: reference + NNI
+    // trees put thousands of quartets with one and the same triple at a node pair's bound).
+    const bool sampling = PASS == 1 && sd.sample != 0;
+    const bool by_round = (sd.sample >> 16) & 1u;
+    const bool estimate = sampling && ((sd.sample >> 17) & 1u);
+    const uint32_t s_n = sd.sample & 0xFFFFu, s_off = estimate ? s_n / 2 : 0u;
+    const uint32_t smask = by_round ? 0xFFFFFFFFu : s_n - 1u;                               // chunk sampling: mask of S
+    const uint32_t rstep = sampling && by_round ? s_n : 1u;
+    unsigned long long west = 0;                         // estimate mode: hits of this wave (wave-uniform)
+    for (uint32_t round = blockIdx.x * rstep + (by_round ? s_off : 0u); round < sd.n_rounds; round += gridDim.x * rstep) {
         const uint32_t rk = sd.bundle_rounds[2 * round], rg = sd.bundle_rounds[2 * round + 1];
         const uint32_t b = __builtin_amdgcn_readfirstlane(rk * kBundleWaves + wave);
         const uint32_t pcnt = b < n ? sd.bundle_pcnt[b] : 0u;
@@ -478,13 +493,17 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             // min(the node pair's minimum as this lane last saw it in memory, the lane's own running minimum of the run).
             // Both bounds are >= the pair's FINAL minimum, so every quartet within tol of the final minimum is in the log;
             // score_log_kernel filters the log against the final minima afterwards -- the table is read once, not twice.
-            const bool logging = PASS == 1 && sd.list != nullptr;
+            const bool logging = PASS == 1 && (sd.list != nullptr || estimate);
             // (wave-uniform) stop logging once the log is full: the counter is looked at once per round
-            bool log_on = logging && __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(sd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sd.list_cap)) != 0;
+            bool log_on = estimate || (logging && __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(sd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sd.list_cap)) != 0);
             double bound = -kHuge;                  // nothing is logged before the first node pair (a run may start unresolved: key stays empty)
             QicCache qc = {0xFFFFFFFFu, 0.0, 0.0};
             uint32_t end = 0;
             for (uint32_t a0 = 0; a0 < b; a0 += CH) {                   // uniform
+                if (sampling) {                                         // uniform: the pre-pass takes one chunk in S and classifies afresh there
+                    if (smask != 0xFFFFFFFFu && (((a0 / CH) + round + s_off) & smask) != 0) continue;
+                    end = a0;
+                }
                 if (a0 + CH <= b) {                                     // uniform: the whole chunk lies in the row
                     constexpr int NV = CH * 3 * (int)sizeof(CT) / 16;   // 16-byte loads: 6 (u32 cells) / 3 (u16 cells)
                     const qs_u32x4_a2 *src = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)a0);
@@ -536,12 +555,21 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                         const uint32_t n0 = q[u][0], n1 = q[u][1], n2 = q[u][2];
                         const double qic = bundle_qic(t1, sd, qc, n0, n1, n2, first_is_n0);
                         if (PASS == 1) {
-                            S0 += n0; S1 += n1; S2 += n2;
+                            if (!sampling) { S0 += n0; S1 += n1; S2 += n2; }
                             if (logging) {
                                 const bool near = qic <= fmin(bound, mn) + tol;
-                                const bool hit = near && !(hprev && n0 == h0 && n1 == h1 && n2 == h2);
-                                const unsigned long long hits = log_on ? __ballot(hit) : 0ull;
-                                if (hits) {
+                                // (everything else only in the rare wave step that holds a near quartet at all: with bounds from the
+                                // pre-pass the common step costs the comparison above and the ballot of `near`)
+                                const unsigned long long nears = __ballot(near);
+                                bool hit = false;
+                                unsigned long long hits = 0ull;
+                                if (nears) {
+                                    hit = near && !(hprev && n0 == h0 && n1 == h1 && n2 == h2);
+                                    hits = log_on ? __ballot(hit) : 0ull;
+                                    if (near) { h0 = n0; h1 = n1; h2 = n2; }
+                                }
+                                if (estimate) west += (unsigned long long)__builtin_popcountll(hits);
+                                else if (hits) {
                                     // The wave writes into a chunk of kLogChunk records it has reserved with ONE atomic on the log's
                                     // counter (a single counter word takes ~88 updates per microsecond: one update per logging wave
                                     // instruction made pass 1 4.5x slower). Records of a chunk that stay unwritten keep the key the
@@ -565,7 +593,6 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                         wbase += cnt; wleft -= cnt;
                                     }
                                 }
-                                if (near) { h0 = n0; h1 = n1; h2 = n2; }
                                 hprev = near;
                             }
                             mn = fmin(mn, qic);
@@ -607,6 +634,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             __syncthreads();
         }
     }
+    if (estimate && lane == 0 && west) atomicAdd(sd.list_count, west);
 }
 
 // The rounds of the bundle kernel for the rank range [r0, r1) of an n-taxon table (host). For every b the rows (b,c,d)

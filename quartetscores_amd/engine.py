@@ -189,6 +189,10 @@ class Context:
         """Records the last score() logged in single-read mode; 0 = the table was read twice."""
         return int(self.L.qs_last_score_log(self.h))
 
+    def last_score_estimate(self) -> int:
+        """Automatic scoring mode: the log size the last score() predicted from its sample; 0 = no estimate ran."""
+        return int(self.L.qs_last_score_estimate(self.h))
+
     def last_count_launches(self) -> int:
         return int(self.L.qs_last_count_launches(self.h))
 

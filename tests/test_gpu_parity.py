@@ -947,7 +947,11 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
     o.score()
     want = o.scores_by_bipartition()
     results = {}
-    for mode, tuning in (("single", {_lib.QS_TUNE_SCORE_PASSES: 2}), ("two", {}),
+    # "single": with the default pre-pass (minima of one chunk in 16 of every row); without one; one chunk in 2; one round in 4
+    for mode, tuning in (("single", {_lib.QS_TUNE_SCORE_PASSES: 2}), ("two", {_lib.QS_TUNE_SCORE_PASSES: 1}), ("auto", {}),
+                         ("single_nopre", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 0}),
+                         ("single_s2", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 2}),
+                         ("single_r4", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 4 | 65536}),
                          ("overflow", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 16})):
         for k_, v_ in tuning.items():
             monkeypatch.setitem(eng.DEFAULT_TUNING, k_, v_)
@@ -959,7 +963,10 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
         for k_ in tuning:
             monkeypatch.delitem(eng.DEFAULT_TUNING, k_)
     assert results["single"][4] > 0 and results["two"][4] == 0 and results["overflow"][4] == 0
-    for mode in ("two", "overflow"):
+    for mode in ("single_nopre", "single_s2", "single_r4"):
+        assert results[mode][4] > 0, mode
+    assert results["auto"][4] == 0          # (a table below 1 GB: the automatic mode reads it twice)
+    for mode in ("two", "auto", "overflow", "single_nopre", "single_s2", "single_r4"):
         for i in range(3):
             assert np.array_equal(results["single"][i], results[mode][i], equal_nan=True), (mode, i)
     qsc_like = results["single"]
@@ -979,6 +986,45 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
         assert set(got) == set(want)
         for k_ in got:
             assert got[k_] == want[k_], (sorted(k_), got[k_], want[k_])
+
+
+@pytest.mark.parametrize("kind", ["random", "nni", "identical"])
+def test_automatic_scoring_mode_on_a_gigabyte_table(eng, kind):
+    """qs_score's default on a table of 1.2 GB (224 taxa): a minima-only pre-pass over one round in 64, a second sample
+    that predicts the candidate log, then ONE read of the table -- or, when the prediction says the log would not hold
+    (identical trees, where every quartet ties its node pair's minimum, and a log of 65536 records), two plain passes. Scores bit for bit
+    those of the forced two-pass mode in every case."""
+    from quartetscores_amd import native_ingest
+    n, m = 224, 96
+    ref_nw = native_ingest.synth_trees(n, 1, 610).decode().strip()
+    if kind == "identical":
+        text = (ref_nw + "\n").encode() * m
+    else:
+        text = native_ingest.synth_trees(n, m, 611, kind="nni" if kind == "nni" else "random", ref_text=ref_nw if kind == "nni" else None)
+    ref = flatten.flatten_reference(ref_nw)
+    batch, _ = native_ingest.ingest_text(ref_nw, text, want_ranges=False)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    assert ctx.table_bytes >= 1 << 30
+    ctx.count_trees(batch)
+    got = {}
+    if kind == "identical":     # a small log: the sample must predict that it will not hold
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_LOG_CAP, 1 << 16)
+    for mode in (1, 0, 2):
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_PASSES, mode)
+        lq, qp, eqp, bif = ctx.score(ref)
+        got[mode] = (lq.copy(), qp.copy(), eqp.copy(), ctx.last_score_log(), ctx.last_score_estimate())
+    ctx.close()
+    assert got[1][3] == 0 and got[1][4] == 0
+    assert got[0][4] > 0 or kind == "identical" or got[0][3] > 0        # the automatic mode made an estimate
+    if kind == "random":
+        assert got[0][3] > 0 and got[2][3] > 0                           # ... and read the table once
+    if kind == "identical":
+        assert got[0][3] == 0 and got[0][4] > 3 * (1 << 16)              # predicted overflow: two passes
+        assert got[2][3] == 0                                            # forced single read: the log overflows, pass 2 follows
+    for mode in (0, 2):
+        for i in range(3):
+            assert np.array_equal(got[1][i], got[mode][i], equal_nan=True), (mode, i)
 
 
 def test_two_cell_wire_format(eng):
