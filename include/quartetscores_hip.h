@@ -283,8 +283,15 @@ int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, 
  *   qs_score_pass1 : sums_dev[3*P] = per node pair, 64-bit sums of (q1,q2,q3) over THIS context's quartets;
  *                    min_dev[P]   = the smallest device-evaluated QIC, order-preserving int64 encoding
  *                    -> reduce over shards: SUM on sums_dev, MIN on min_dev (plain int64 reductions)
+ *                    For tables from 1 GB (QS_TUNE_SCORE_PASSES) this pass also LOGS, in the context, every quartet within
+ *                    the tolerance of the bound it knows for its node pair -- a superset of what pass 2 can ask for as long
+ *                    as min_dev there is <= this context's own minima (it is: the MIN over the shards) -- so that
  *   qs_score_pass2 : cand_dev[QS_SCORE_CAND_SLOTS*P] = distinct gcd-reduced count triples of this context
- *                    whose QIC is within 1e-12 of min_dev (-1 = empty slot) -> all-gather over shards
+ *                    whose QIC is within 1e-12 of min_dev (-1 = empty slot) -> all-gather over shards.
+ *                    Filters the log of the qs_score_pass1 that preceded it on the same context, table / view and
+ *                    reference (the table is then read ONCE); reads the table again if there is no such log (any
+ *                    qs_count_* / qs_table_* / qs_set_tuning / qs_score_set_view call in between discards it, and the
+ *                    caller must not write into an attached table between the two passes) or if the log overflowed.
  *                    A node pair with more than 8 such triples (or one whose reduced counts need more than 21
  *                    bits) is MARKED in cand_dev instead of failing the run:
  *   qs_score_overflow: lists every near-minimal quartet (key, q1, q2, q3; 4 int64 per entry, sorted, distinct) of

@@ -119,7 +119,10 @@ struct qs_ctx {
     // single-read scoring (qs_score): pass 1 logs candidate (node pair, triple) records, score_log_kernel filters them
     unsigned long long *score_log = nullptr;     // log_cap records of 4 words + 1 word counter behind them
     uint64_t score_log_cap = 0;
-    bool score_log_active = false;               // set by qs_score around its pass 1
+    bool log_valid = false;                      // the candidate log holds the last qs_score_pass1 of (log_table, log_rank_lo, log_n_tuples, log_ref)
+    const void *log_table = nullptr, *log_ref = nullptr;
+    uint64_t log_rank_lo = 0, log_n_tuples = 0;
+    double log_tol = 0.0;
     uint32_t tune_score_passes = 0;              // QS_TUNE_SCORE_PASSES: 0 = automatic (default), 1 = two passes over the table, 2 = single read
     void *score_acc = nullptr, *score_acc_host = nullptr;   // qs_score's accumulators on the device + their pinned host copy (cached)
     size_t score_acc_cap = 0, score_acc_host_cap = 0;
@@ -316,6 +319,7 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
 }
 
 extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c) return QS_ERR_ARG;
     switch (key) {
         case QS_TUNE_SCORE_CAND_SLOTS:
@@ -520,6 +524,7 @@ extern "C" void *qs_table_device_ptr(const qs_ctx *c) { return c ? c->table : nu
 extern "C" uint64_t qs_trees_counted(const qs_ctx *c) { return c ? c->trees_counted : 0; }
 
 extern "C" int qs_table_alloc(qs_ctx *c) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c) return QS_ERR_ARG;
     QS_HIP(c, hipSetDevice(c->device));
     if (c->table && c->table_owned) { (void)hipFree(c->table); c->table = nullptr; }
@@ -536,6 +541,7 @@ extern "C" int qs_table_alloc(qs_ctx *c) {
 }
 
 extern "C" int qs_table_attach(qs_ctx *c, void *device_ptr, uint64_t bytes) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c || !device_ptr) return fail(c, QS_ERR_ARG, "qs_table_attach: NULL");
     // 16-bit cells are updated through their 32-bit word (packed half-word atomics of the scatter kernel, word-wise
     // collectives): the buffer must cover whole words
@@ -549,6 +555,7 @@ extern "C" int qs_table_attach(qs_ctx *c, void *device_ptr, uint64_t bytes) {
 }
 
 extern "C" int qs_table_clear(qs_ctx *c) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_table_clear: no table");
     QS_HIP(c, hipSetDevice(c->device));
     QS_HIP(c, hipMemsetAsync(c->table, 0, (size_t)qs_table_bytes(c), c->stream));
@@ -566,6 +573,7 @@ extern "C" int qs_table_download(qs_ctx *c, void *host_dst, uint64_t bytes) {
 }
 
 extern "C" int qs_table_upload(qs_ctx *c, const void *host_src, uint64_t bytes) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c || !c->table) return fail(c, QS_ERR_STATE, "qs_table_upload: no table");
     if (bytes > qs_table_bytes(c)) return fail(c, QS_ERR_ARG, "qs_table_upload: too many bytes");
     QS_HIP(c, hipSetDevice(c->device));
@@ -585,6 +593,7 @@ extern "C" int qs_table_pack16(qs_ctx *c, void *dst_device, uint64_t dst_bytes) 
 }
 
 extern "C" int qs_wire_attach(qs_ctx *c, void *dst_device, uint64_t dst_bytes) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c) return QS_ERR_ARG;
     if (!dst_device) { c->wire_out = nullptr; c->wire_trees = 0; return QS_OK; }
     if (dst_bytes < c->n_tuples * 4) return fail(c, QS_ERR_ARG, "qs_wire_attach: destination smaller than " + std::to_string(c->n_tuples * 4) + " bytes");
@@ -604,6 +613,7 @@ extern "C" int qs_table_pack16x2(qs_ctx *c, void *dst_device, uint64_t dst_bytes
 }
 
 extern "C" int qs_unpack16x2(qs_ctx *c, const void *src_device, uint64_t n_tuples, uint32_t total_trees, void *dst_device) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c || !src_device || !dst_device) return fail(c, QS_ERR_ARG, "qs_unpack16x2: NULL argument");
     if (total_trees > 0xFFFFu) return fail(c, QS_ERR_OVERFLOW, "qs_unpack16x2: more than 65535 trees");
     QS_HIP(c, hipSetDevice(c->device));
@@ -624,6 +634,7 @@ extern "C" int qs_table_pack32x2(qs_ctx *c, void *dst_device, uint64_t dst_bytes
 }
 
 extern "C" int qs_unpack32x2(qs_ctx *c, const void *src_device, uint64_t n_tuples, uint64_t total_trees, void *dst_device) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c || !src_device || !dst_device) return fail(c, QS_ERR_ARG, "qs_unpack32x2: NULL argument");
     if (total_trees > 0xFFFFFFFFull) return fail(c, QS_ERR_OVERFLOW, "qs_unpack32x2: more than 2^32 - 1 trees");
     QS_HIP(c, hipSetDevice(c->device));
@@ -918,6 +929,7 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
 }
 
 extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c || !b) return fail(c, QS_ERR_ARG, "qs_count_batch: NULL argument");
     if (algo & QS_COUNT_WIRE16X2) return count_batch_wire(c, b, algo);
     if (!c->table) return fail(c, QS_ERR_STATE, "qs_count_batch: no table (qs_table_alloc / qs_table_attach first)");
@@ -1247,6 +1259,7 @@ static int get_ref(qs_ctx *c, const qs_ref_tree *ref, bool want_dev, const RefHo
         if (c->ref_lca_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ref_lca_dev); (void)hipFree(c->ref_next_dev); (void)hipFree(c->root_pairs_dev); c->ref_lca_dev = nullptr; c->ref_next_dev = nullptr; c->root_pairs_dev = nullptr; }
         delete c->ref_cache;
         c->ref_cache = R = fresh;
+        c->log_valid = false;
     }
     if (want_dev && !c->ref_lca_dev) {
         QS_HIP(c, hipMalloc(&c->ref_lca_dev, R->lca.size() * 4));
@@ -1346,6 +1359,7 @@ extern "C" uint64_t qs_score_pair_slots(const qs_ref_tree *ref) {
 }
 
 extern "C" int qs_score_set_view(qs_ctx *c, const void *table_dev, uint32_t count_bits, uint64_t rank_lo, uint64_t n_tuples) {
+    if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
     if (!c) return QS_ERR_ARG;
     if (!table_dev) { c->view_table = nullptr; c->view_bits = 0; c->view_rank_lo = c->view_n = 0; return QS_OK; }
     if (count_bits != 16 && count_bits != 32) return fail(c, QS_ERR_ARG, "qs_score_set_view: count_bits must be 16 or 32");
@@ -1370,7 +1384,27 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_sums = (unsigned long long *)sums_dev; sd.pair_min = (long long *)min_dev;
     { int rc_b = ensure_bundle_plan(c, sd, 1); if (rc_b != QS_OK) return rc_b; }
-    if (c->score_log_active && c->tune_score_kernel == 0 && c->bundle[0].n_parts == 0 && c->score_log) {
+    // Single-read scoring: this pass also LOGS every quartet whose device QIC is within the tolerance of the bound it knows for
+    // its node pair (the pair's minimum in memory, lowered beforehand by a minima-only pre-pass over a sample of the table, and
+    // the lane's own running minimum) -- a superset of the quartets within the tolerance of ANY later minimum <= this table's,
+    // so the qs_score_pass2 that follows filters the log instead of reading the table again, also when its min_dev holds the
+    // minima over several shards / GPUs (QuartetScoreComputer.hpp:417-469 evaluates log_score of every quartet once, too).
+    // QS_TUNE_SCORE_PASSES: 0 = automatic (tables from 1 GB, whole rows, bundle kernel; a second sample predicts the log and
+    // the pass runs plain when it would not hold), 1 = never, 2 = always (pass 2 reads the table if the log overflows).
+    c->log_valid = false;
+    c->last_score_estimate = 0;
+    const uint64_t scored_bytes = sd.n_tuples * 3 * (uint64_t)(sd.count_bits / 8);
+    const bool want_log = c->tune_score_kernel == 0 && c->bundle[0].n_parts == 0 && sd.n_rounds > 0 &&
+                          (c->tune_score_passes == 2 || (c->tune_score_passes == 0 && c->tune_score_sample != 0 && scored_bytes >= (1ull << 30)));
+    bool logging = false;
+    if (want_log) {
+        const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
+        if (c->score_log && c->score_log_cap != want_cap) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
+        if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1) * 8) == hipSuccess) c->score_log_cap = want_cap;
+        else if (!c->score_log) (void)hipGetLastError();   // no room for the log: two passes
+        logging = c->score_log != nullptr;
+    }
+    if (logging) {
         sd.list = c->score_log; sd.list_count = c->score_log + 4 * c->score_log_cap; sd.list_cap = c->score_log_cap;
         QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
         if (c->tune_score_sample) {   // minima-only pre-pass over a sample of the table: the bound the logging pass starts from
@@ -1378,8 +1412,7 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
             pre.list = nullptr; pre.list_count = nullptr; pre.list_cap = 0; pre.sample = c->tune_score_sample;
             QS_HIP(c, launch_score_pass1(c->stream, pre, 0, c->n_cu, nullptr, nullptr, 0, 0.0));
             if (c->tune_score_passes != 2) {
-                // automatic mode: a second, disjoint sample counts what the logging pass would log of it; the full pass
-                // logs only if S x that count fits the log with room to spare, else pass 1 runs plain and pass 2 follows
+                // automatic mode: a second, disjoint sample counts what the logging pass would log of it
                 pre.list_count = sd.list_count; pre.sample = c->tune_score_sample | (1u << 17);
                 QS_HIP(c, launch_score_pass1(c->stream, pre, 0, c->n_cu, nullptr, nullptr, 0, c->tune_score_tol));
                 unsigned long long hits = 0;
@@ -1390,14 +1423,18 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
                 // its own running minimum (measured: 12.8 M predicted / 2.2 M logged at 512 taxa x 10000 random trees, 3.7 M /
                 // 0.75 M at 256 taxa; reference + NNI trees: 90 M predicted, log of 8 M overflows): go ahead up to 3 x the log.
                 if ((double)c->last_score_estimate > 3.0 * (double)c->score_log_cap) {
-                    c->score_log_active = false;
+                    logging = false;
                     sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
                 } else QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
             }
         }
         // waves reserve whole chunks of records: what they leave unwritten must read as "no record" (key = all ones)
-        if (c->score_log_active) QS_HIP(c, hipMemsetAsync(c->score_log, 0xFF, (size_t)c->score_log_cap * 32, c->stream));
-    } else c->score_log_active = false;   // (partial rows / scan kernel: the caller falls back to two passes)
+        if (logging) {
+            QS_HIP(c, hipMemsetAsync(c->score_log, 0xFF, (size_t)c->score_log_cap * 32, c->stream));
+            c->log_valid = true;                 // until the table, the view or the tuning changes (invalidate_log)
+            c->log_table = sd.table; c->log_rank_lo = sd.rank_lo; c->log_n_tuples = sd.n_tuples; c->log_ref = Rp; c->log_tol = c->tune_score_tol;
+        }
+    }
     QS_HIP(c, launch_score_pass1(c->stream, sd, c->tune_score_kernel, c->n_cu, c->bundle[0].part_lo, c->bundle[0].part_n, c->bundle[0].n_parts, c->tune_score_tol));
     // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
     if (c->root_pairs_dev) QS_HIP(c, launch_root_pair_sums(c->stream, sd, c->root_pairs_dev, (uint32_t)R.root_pairs.size(), R.root_items));
@@ -1419,6 +1456,22 @@ extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *
     ScoreDevice sd;
     fill_score_device(c, R, c->ref_lca_dev, sd);
     sd.pair_min = (long long *)min_dev; sd.pair_cand = (unsigned long long *)cand_dev;
+    c->last_score_log = 0;
+    if (c->log_valid && c->log_table == sd.table && c->log_rank_lo == sd.rank_lo && c->log_n_tuples == sd.n_tuples && c->log_ref == Rp &&
+        c->log_tol == c->tune_score_tol) {
+        // the preceding qs_score_pass1 over this very table logged its candidates: filter the log against min_dev
+        c->log_valid = false;
+        unsigned long long n_rec = 0;
+        QS_HIP(c, hipMemcpyAsync(&n_rec, c->score_log + 4 * c->score_log_cap, 8, hipMemcpyDeviceToHost, c->stream));
+        QS_HIP(c, hipStreamSynchronize(c->stream));
+        if (n_rec <= c->score_log_cap) {
+            sd.list = c->score_log; sd.list_cap = c->score_log_cap;
+            QS_HIP(c, launch_score_log(c->stream, sd, c->tune_score_tol, n_rec));
+            c->last_score_log = n_rec;
+            return QS_OK;
+        }
+        // (the log overflowed: read the table)
+    }
     { int rc_b = ensure_bundle_plan(c, sd, 2); if (rc_b != QS_OK) return rc_b; }
     QS_HIP(c, launch_score_pass2(c->stream, sd, c->tune_score_tol, c->tune_score_kernel, c->n_cu, c->bundle[1].part_lo, c->bundle[1].part_n, c->bundle[1].n_parts));
     return QS_OK;   // asynchronous; node pairs whose slots did not suffice are marked in cand_dev (qs_score_overflow)
@@ -1658,55 +1711,12 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
         if (rc0 != QS_OK) return rc0;
     }
     c->score_ms[1] = ms_since(t_all);
-    // Single-read scoring (QS_TUNE_SCORE_PASSES = 2): pass 1 also logs every quartet that is near-minimal for its node pair AT
-    // THAT MOMENT (a superset of the finally near-minimal ones), and a filter over the log replaces the second pass over the
-    // table (QuartetScoreComputer.hpp:417-469 evaluates log_score of every quartet once, too); two passes if the log
-    // overflows. NOT the default: measured on MI355X the logging pass 1 takes 12.4 ms instead of 10.3 at 512 taxa and its log
-    // overflows 8 M records there (the bound a lane sees is too stale to prune), at 256 taxa 2.3 + 0.3 ms against 2.6 ms for
-    // both plain passes (profiles/r03_experiments.md section 6).
-    c->last_score_log = 0;
-    // 0 = automatic: single read for tables from 1 GB (below that the two extra launches cost more than the second pass) when
-    // the sampled estimate says the log will hold; 1 = two passes; 2 = single read whatever the estimate (falls back on overflow)
-    const bool want_single = c->tune_score_passes == 2 || (c->tune_score_passes == 0 && c->tune_score_sample != 0 && !c->view_table &&
-                                                            qs_table_bytes(c) >= (1ull << 30));
-    c->last_score_estimate = 0;
-    if (want_single && c->tune_score_kernel == 0) {
-        const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
-        if (c->score_log && c->score_log_cap != want_cap) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
-        if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1) * 8) == hipSuccess) c->score_log_cap = want_cap;
-        else if (!c->score_log) (void)hipGetLastError();
-        c->score_log_active = c->score_log != nullptr;
-    }
     QS_HIP(c, hipEventRecord(c->score_ev[0], c->stream));
-    int rc = qs_score_pass1(c, ref, (int64_t *)sums.p, (int64_t *)mn.p);
-    const bool logged = c->score_log_active;
-    c->score_log_active = false;
+    int rc = qs_score_pass1(c, ref, (int64_t *)sums.p, (int64_t *)mn.p);     // (may log its candidates: see there)
     if (rc != QS_OK) return rc;
     QS_HIP(c, hipEventRecord(c->score_ev[1], c->stream));
-    bool need_pass2 = true;
-    if (logged) {
-        unsigned long long n_rec = 0;
-        QS_HIP(c, hipMemcpyAsync(&n_rec, c->score_log + 4 * c->score_log_cap, 8, hipMemcpyDeviceToHost, c->stream));
-        QS_HIP(c, hipStreamSynchronize(c->stream));
-        if (n_rec <= c->score_log_cap) {
-            const RefHost *Rp = nullptr;
-            rc = get_ref(c, ref, true, &Rp);
-            if (rc != QS_OK) return rc;
-            QS_HIP(c, hipMemsetAsync(cand.p, 0xFF, np * kCand * 8, c->stream));
-            QS_HIP(c, hipMemsetAsync(c->dev_flags + 1, 0, 4, c->stream));
-            ScoreDevice sd;
-            fill_score_device(c, *Rp, c->ref_lca_dev, sd);
-            sd.pair_min = (long long *)mn.p; sd.pair_cand = (unsigned long long *)cand.p;
-            sd.list = c->score_log; sd.list_cap = c->score_log_cap;
-            QS_HIP(c, launch_score_log(c->stream, sd, c->tune_score_tol, n_rec));
-            c->last_score_log = n_rec;
-            need_pass2 = false;
-        }
-    }
-    if (need_pass2) {
-        rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);
-        if (rc != QS_OK) return rc;
-    }
+    rc = qs_score_pass2(c, ref, (const int64_t *)mn.p, (int64_t *)cand.p);   // a filter over that log, or the second read
+    if (rc != QS_OK) return rc;
     QS_HIP(c, hipEventRecord(c->score_ev[2], c->stream));
     const clk::time_point t_ov = clk::now();
     int64_t *extra = nullptr;

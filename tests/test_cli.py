@@ -432,8 +432,11 @@ def test_cpp_cli_table_shards_match_the_whole_table_run(tmp_path, trees, rooted,
             assert "table shard(s) by largest taxon id" in p.stdout and "Finished computing scores." in p.stdout
             if extra[1] == "1":
                 assert "every shard stays on its GPU" in p.stdout
-            else:
-                assert ("kept in host memory" in p.stdout) == ("recount" not in extra)
+            elif "--spill" in extra:
+                assert ("kept in host memory" in p.stdout) == ("host" in extra)
+                assert ("counted again" in p.stdout) == ("recount" in extra)
+            else:   # automatic: whichever is cheaper (a host round trip of the table against counting the trees again)
+                assert ("kept in host memory" in p.stdout) != ("counted again" in p.stdout)
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "x.nwk"), "--table-shards", "2", "-q", str(tmp_path / "x.txt"))
     assert p.returncode == 1 and "need the whole table" in p.stderr
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "y.nwk"), "--table-shards", "2", "--spill", "disk")

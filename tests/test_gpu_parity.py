@@ -564,11 +564,14 @@ def test_D5_u32_wrap_of_qp_sums(eng, golden):
         assert hit == 1
 
 
+@pytest.mark.parametrize("logged", [False, True])
 @pytest.mark.parametrize("count_bits", [32, 16])
-def test_table_sharded_counting_and_scoring(eng, count_bits):
+def test_table_sharded_counting_and_scoring(eng, count_bits, logged):
     """BASELINE configs[4] in miniature: the table is split by the largest taxon id into shards
     (here 3 contexts on one GPU stand in for 3 GPUs); every shard sees all trees; the per-node-pair
-    accumulators are combined exactly as distributed.score_sharded does with collectives."""
+    accumulators are combined exactly as distributed.score_sharded does with collectives.
+    logged: every shard's pass 1 keeps its candidate log (forced: the shards are far below 1 GB) and its pass 2 filters
+    that log against the minima over ALL shards instead of reading the shard again -- same scores."""
     import torch
     from quartetscores_amd import distributed
     n, m, G = 40, 50, 3
@@ -584,6 +587,7 @@ def test_table_sharded_counting_and_scoring(eng, count_bits):
         ctx.table_alloc()
         ctx.count_trees(batch)
         T = ctx.table_download()
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_PASSES, 2 if logged else 1)
         r0, r1 = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
         assert T.shape[0] == r1 - r0 and (T.astype(np.uint64) == full[r0:r1]).all()
         # lookups outside the shard read as zero, inside as the oracle
@@ -597,7 +601,13 @@ def test_table_sharded_counting_and_scoring(eng, count_bits):
     for ctx in ctxs:
         c_ = torch.empty(8 * ctx.score_pair_slots(ref), dtype=torch.int64, device="cuda")
         ctx.score_pass2(ref, mins, c_)
+        assert (ctx.last_score_log() > 0) == logged
         cands.append(c_.cpu().numpy())                      # all_gather
+        if logged:      # a second pass 2 without a new pass 1 reads the table (the log is spent): same candidates
+            c2 = torch.empty_like(c_)
+            ctx.score_pass2(ref, mins, c2)
+            assert ctx.last_score_log() == 0
+            assert np.array_equal(np.sort(c2.cpu().numpy().reshape(-1, 8), axis=1), np.sort(cands[-1].reshape(-1, 8), axis=1))
     lq, qp, eqp, bif = ctxs[0].score_finish(ref, sums.cpu().numpy(), np.stack(cands))
     # the same numbers as the unsharded path and as the oracle
     whole = eng.Context(n, 32)
