@@ -118,7 +118,7 @@ struct qs_ctx {
     uint64_t table_trees_hint = 0;               // QS_TUNE_TABLE_TREES: trees behind an attached / uploaded / viewed table
     // single-read scoring (qs_score): pass 1 logs candidate (node pair, triple) records, score_log_kernel filters them
     unsigned long long *score_log = nullptr;     // log_cap records of 4 words + 1 word counter behind them
-    uint64_t score_log_cap = 0;
+    uint64_t score_log_cap = 0, score_log_pairs = 0;
     bool log_valid = false;                      // the candidate log holds the last qs_score_pass1 of (log_table, log_rank_lo, log_n_tuples, log_ref)
     const void *log_table = nullptr, *log_ref = nullptr;
     uint64_t log_rank_lo = 0, log_n_tuples = 0;
@@ -128,6 +128,7 @@ struct qs_ctx {
     size_t score_acc_cap = 0, score_acc_host_cap = 0;
     uint64_t last_score_estimate = 0;            // automatic single-read mode: predicted log records of the last qs_score (sample x S)
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
+    uint32_t tune_score_dedupe = 1;              // QS_TUNE_SCORE_DEDUPE: the logging pass skips a quartet that repeats its node pair's last logged triple
     uint32_t tune_score_sample = 64u | 65536u;             // QS_TUNE_SCORE_SAMPLE: pre-pass of the single-read scoring (0 = none; S | by-round bit 16)
     uint64_t tune_score_log_cap = 0;             // QS_TUNE_SCORE_LOG_CAP: records the log may hold (0 = 8 M); tests force overflows
 };
@@ -347,6 +348,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             if (value >> 17 || (value && (S < 2 || (S & (S - 1))))) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_SAMPLE takes 0 or a power of two in [2, 32768], optionally | 65536 (whole rounds)");
             c->tune_score_sample = (uint32_t)value; return QS_OK;
         }
+        case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
         case QS_TUNE_SCORE_LOG_CAP:
             if (value > (1ull << 26)) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOG_CAP takes at most 2^26 records");
             c->tune_score_log_cap = value; return QS_OK;
@@ -1307,7 +1309,7 @@ static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t 
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
     if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
-    sd.cand_limit = c->tune_cand_slots; sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
+    sd.cand_limit = c->tune_cand_slots; sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0; sd.last_trip = nullptr;
     sd.frame = R.bifurcating ? 0 : 1;
     sd.bundle_plo = sd.bundle_pcnt = sd.bundle_rounds = nullptr; sd.n_rounds = 0; sd.sample = 0;
 }
@@ -1400,13 +1402,19 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     if (want_log) {
         const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
         if (c->score_log && c->score_log_cap != want_cap) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
-        if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1) * 8) == hipSuccess) c->score_log_cap = want_cap;
+        // behind the records: the counter word, then one word per node pair (the pair's last logged triple)
+        if (c->score_log && c->score_log_pairs < np) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
+        if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1 + np) * 8) == hipSuccess) { c->score_log_cap = want_cap; c->score_log_pairs = np; }
         else if (!c->score_log) (void)hipGetLastError();   // no room for the log: two passes
         logging = c->score_log != nullptr;
     }
     if (logging) {
         sd.list = c->score_log; sd.list_count = c->score_log + 4 * c->score_log_cap; sd.list_cap = c->score_log_cap;
         QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+        if (c->tune_score_dedupe) {   // the tie filter (one word per node pair behind the log's counter)
+            sd.last_trip = sd.list_count + 1;
+            QS_HIP(c, hipMemsetAsync(sd.last_trip, 0xFF, np * 8, c->stream));
+        }
         if (c->tune_score_sample) {   // minima-only pre-pass over a sample of the table: the bound the logging pass starts from
             ScoreDevice pre = sd;
             pre.list = nullptr; pre.list_count = nullptr; pre.list_cap = 0; pre.sample = c->tune_score_sample;
@@ -1419,13 +1427,17 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
                 QS_HIP(c, hipMemcpyAsync(&hits, sd.list_count, 8, hipMemcpyDeviceToHost, c->stream));
                 QS_HIP(c, hipStreamSynchronize(c->stream));
                 c->last_score_estimate = hits * (c->tune_score_sample & 0xFFFFu);
-                // The static bounds of the sample over-predict: the full pass also lowers the minima as it goes and a lane keeps
-                // its own running minimum (measured: 12.8 M predicted / 2.2 M logged at 512 taxa x 10000 random trees, 3.7 M /
-                // 0.75 M at 256 taxa; reference + NNI trees: 90 M predicted, log of 8 M overflows): go ahead up to 3 x the log.
-                if ((double)c->last_score_estimate > 3.0 * (double)c->score_log_cap) {
+                // The static bounds of the sample over-predict: the full pass also lowers the minima as it goes, a lane keeps its
+                // own running minimum, and the tie filter has seen 64 x more of every node pair (measured, predicted / logged:
+                // 12.6 M / 1.6 M at 512 taxa x 10000 random trees, 3.7 M / 0.75 M at 256 taxa, 19 M / 1.0 M at 512 taxa x 10000
+                // reference + NNI trees; without the tie filter those predict 90 M and do overflow 8 M): go ahead up to 6 x the log.
+                if ((double)c->last_score_estimate > 6.0 * (double)c->score_log_cap) {
                     logging = false;
                     sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0;
-                } else QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+                } else {
+                    QS_HIP(c, hipMemsetAsync(sd.list_count, 0, 8, c->stream));
+                    if (sd.last_trip) QS_HIP(c, hipMemsetAsync(sd.last_trip, 0xFF, np * 8, c->stream));   // (the estimate logged nothing)
+                }
             }
         }
         // waves reserve whole chunks of records: what they leave unwritten must read as "no record" (key = all ones)

@@ -107,6 +107,8 @@ struct ScoreDevice {
     unsigned long long *list;      // pass 3 (qs_score_overflow): 4 words (key, q1, q2, q3) per near-minimal quartet of a marked pair;
                                    // pass 1 with list != NULL: the candidate log of the single-read scoring (same records)
     unsigned long long *list_count, list_cap;
+    unsigned long long *last_trip; // logging pass 1: per node pair the packed (q1 << 42 | q2 << 21 | q3) of the record logged last for it (all
+                                   // ones = none), or NULL: a quartet whose triple equals it is not logged again (ties at the bound)
     uint32_t *flags;               // [0] bit 0: a pair's candidate slots overflowed, bit 1: a reduced triple did not fit the packed slot
     const uint16_t *ref_next; // n*n: for a < b the first a' > a with lca(a',b) != lca(a,b), b if there is none
     const double *logk;            // log(k) (0 at k = 0) for k < tbl_n: integer arguments of the device QIC

@@ -563,13 +563,30 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                 const unsigned long long nears = __ballot(near);
                                 bool hit = false;
                                 unsigned long long hits = 0ull;
+                                unsigned long long packed = 0;
                                 if (nears) {
                                     hit = near && !(hprev && n0 == h0 && n1 == h1 && n2 == h2);
+                                    // Ties at the bound: in a table of similar trees thousands of quartets of a node pair carry one
+                                    // and the same triple, and every lane's every run would log it once (90 M records at 512 taxa x
+                                    // 10000 reference + NNI trees). The pair's last LOGGED triple is kept in memory; a quartet that
+                                    // repeats it adds nothing to the candidates (they are sets of triples). A stale value read through
+                                    // the L1 is an older logged triple of this pass or "none": skipping stays sound.
+                                    if (sd.last_trip != nullptr && log_on) {
+                                        if (hit) {
+                                            uint32_t q1, q2, q3;
+                                            permute_counts(code, n0, n1, n2, q1, q2, q3);
+                                            // (three counts below 2^21 pack without loss; anything larger is simply never filtered: all ones)
+                                            packed = ((q1 | q2 | q3) >> 21) ? ~0ull : ((unsigned long long)q1 << 42) | ((unsigned long long)q2 << 21) | q3;
+                                            if (packed != ~0ull && sd.last_trip[key] == packed) hit = false;
+                                        }
+                                    }
                                     hits = log_on ? __ballot(hit) : 0ull;
                                     if (near) { h0 = n0; h1 = n1; h2 = n2; }
                                 }
-                                if (estimate) west += (unsigned long long)__builtin_popcountll(hits);
-                                else if (hits) {
+                                if (estimate) {
+                                    west += (unsigned long long)__builtin_popcountll(hits);
+                                    if (hit && sd.last_trip != nullptr) sd.last_trip[key] = packed;   // (cleared again before the full pass)
+                                } else if (hits) {
                                     // The wave writes into a chunk of kLogChunk records it has reserved with ONE atomic on the log's
                                     // counter (a single counter word takes ~88 updates per microsecond: one update per logging wave
                                     // instruction made pass 1 4.5x slower). Records of a chunk that stay unwritten keep the key the
@@ -589,6 +606,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                             permute_counts(code, n0, n1, n2, q1, q2, q3);
                                             unsigned long long *rec = sd.list + 4 * (wbase + (unsigned long long)__builtin_popcountll(hits & ((1ull << lane) - 1ull)));
                                             rec[0] = key; rec[1] = q1; rec[2] = q2; rec[3] = q3;
+                                            if (sd.last_trip != nullptr) sd.last_trip[key] = packed;
                                         }
                                         wbase += cnt; wleft -= cnt;
                                     }

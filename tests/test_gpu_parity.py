@@ -962,6 +962,7 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
                          ("single_nopre", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 0}),
                          ("single_s2", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 2}),
                          ("single_r4", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 4 | 65536}),
+                         ("single_noties", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_DEDUPE: 0}),
                          ("overflow", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 16})):
         for k_, v_ in tuning.items():
             monkeypatch.setitem(eng.DEFAULT_TUNING, k_, v_)
@@ -1002,7 +1003,7 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
 def test_automatic_scoring_mode_on_a_gigabyte_table(eng, kind):
     """qs_score's default on a table of 1.2 GB (224 taxa): a minima-only pre-pass over one round in 64, a second sample
     that predicts the candidate log, then ONE read of the table -- or, when the prediction says the log would not hold
-    (identical trees, where every quartet ties its node pair's minimum, and a log of 65536 records), two plain passes. Scores bit for bit
+    (identical trees, where every quartet ties its node pair's minimum, and a log of 8192 records), two plain passes. Scores bit for bit
     those of the forced two-pass mode in every case."""
     from quartetscores_amd import native_ingest
     n, m = 224, 96
@@ -1019,7 +1020,7 @@ def test_automatic_scoring_mode_on_a_gigabyte_table(eng, kind):
     ctx.count_trees(batch)
     got = {}
     if kind == "identical":     # a small log: the sample must predict that it will not hold
-        ctx.set_tuning(_lib.QS_TUNE_SCORE_LOG_CAP, 1 << 16)
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_LOG_CAP, 1 << 13)
     for mode in (1, 0, 2):
         ctx.set_tuning(_lib.QS_TUNE_SCORE_PASSES, mode)
         lq, qp, eqp, bif = ctx.score(ref)
@@ -1030,7 +1031,7 @@ def test_automatic_scoring_mode_on_a_gigabyte_table(eng, kind):
     if kind == "random":
         assert got[0][3] > 0 and got[2][3] > 0                           # ... and read the table once
     if kind == "identical":
-        assert got[0][3] == 0 and got[0][4] > 3 * (1 << 16)              # predicted overflow: two passes
+        assert got[0][3] == 0 and got[0][4] > 6 * (1 << 13)              # predicted overflow: two passes
         assert got[2][3] == 0                                            # forced single read: the log overflows, pass 2 follows
     for mode in (0, 2):
         for i in range(3):

@@ -23,10 +23,12 @@ for case in cases:
     ctx.count_batch(hb)
     ctx.sync()
     base = None
-    for name, passes, sample in (("two passes", 1, 0), ("automatic (default)", 0, 64 | 65536), ("single, no pre-pass", 2, 0), ("single, chunk 1/8", 2, 8), ("single, chunk 1/16", 2, 16),
+    for name, passes, sample in (("two passes", 1, 0), ("automatic (default)", 0, 64 | 65536), ("automatic, no tie filter", 0, 64 | 65536 | (1 << 30)), ("single, no pre-pass", 2, 0), ("single, chunk 1/8", 2, 8), ("single, chunk 1/16", 2, 16),
                                  ("single, chunk 1/32", 2, 32), ("single, chunk 1/64", 2, 64), ("single, round 1/16", 2, 16 | 65536),
                                  ("single, round 1/32", 2, 32 | 65536), ("single, round 1/64", 2, 64 | 65536)):
         ctx.set_tuning(_lib.QS_TUNE_SCORE_PASSES, passes)
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_DEDUPE, 0 if sample >> 30 else 1)
+        sample &= (1 << 30) - 1
         ctx.set_tuning(_lib.QS_TUNE_SCORE_SAMPLE, sample)
         best = None
         for _ in range(4):
@@ -37,5 +39,5 @@ for case in cases:
         if base is None:
             base = sc
         same = all(np.array_equal(x, y, equal_nan=True) for x, y in zip(base[:3], sc[:3]))
-        print(f"n={n} m={m}{' nni' if nni else ''} {name:22s}: qs_score {best[0]:7.3f} ms | pass 1 {best[2]:7.3f} then {best[3]:7.3f} | wait+d2h {best[4]:6.3f} finish {best[5]:6.3f} | log {ctx.last_score_log():9d} records (predicted {ctx.last_score_estimate():9d}) | {'same scores' if same else 'SCORES DIFFER'}", flush=True)
+        print(f"n={n} m={m}{' nni' if nni else ''} {name:26s}: qs_score {best[0]:7.3f} ms | pass 1 {best[2]:7.3f} then {best[3]:7.3f} | wait+d2h {best[4]:6.3f} finish {best[5]:6.3f} | log {ctx.last_score_log():9d} records (predicted {ctx.last_score_estimate():9d}) | {'same scores' if same else 'SCORES DIFFER'}", flush=True)
     ctx.close()
