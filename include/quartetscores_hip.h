@@ -276,6 +276,11 @@ int qs_lookup(qs_ctx *ctx, uint64_t nq, const uint16_t *abcd, uint64_t *out3);
  */
 int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, double *qpic, double *eqpic,
              int *is_bifurcating);
+/* Optional: what a first qs_score / qs_score_pass1 does before its kernels (reference tree and LCA matrix on the device, log
+ * table for n_trees_total trees, round tables, accumulators with their pinned host copy, the candidate log), ahead of time.
+ * May be called while count kernels of this context are still in flight (from the context's host thread): it uses the
+ * copy stream and never waits for the count stream. The CLI calls it behind its last qs_count_batch. */
+int qs_score_prepare(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t n_trees_total);
 
 /*
  * The same computation in steps, for table-sharded contexts (qs_create with a [d_lo,d_hi) shard) and

@@ -28,7 +28,7 @@ EXPORTS = [
     "qs_batch_upload", "qs_batch_free", "qs_count_batch", "qs_count_trees", "qs_sync", "qs_trees_counted", "qs_lookup",
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
-    "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate",
+    "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
 ]
 
 
@@ -124,6 +124,8 @@ def load():
     L.qs_score_pair_slots.argtypes = [C.POINTER(RefTreeC)]
     L.qs_score_set_view.restype = i32
     L.qs_score_set_view.argtypes = [vp, vp, u32, u64, u64]
+    L.qs_score_prepare.restype = i32
+    L.qs_score_prepare.argtypes = [vp, C.POINTER(RefTreeC), u64]
     L.qs_score_pass1.restype = i32
     L.qs_score_pass1.argtypes = [vp, C.POINTER(RefTreeC), vp, vp]
     L.qs_score_pass2.restype = i32

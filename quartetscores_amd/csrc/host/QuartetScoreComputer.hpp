@@ -196,6 +196,14 @@ private:
                     progress++;
                 }
             }
+            {   // the scoring set-up (reference tree on the device, round tables, accumulators, candidate log) while the device
+                // still counts: this thread would only wait. Optional -- a failure here shows up again in qs_score.
+                qs_ref_tree rt;
+                rt.n_nodes = (uint32_t)ref_.parent.size(); rt.n_taxa = (uint32_t)ref_.names.size();
+                rt.parent = ref_.parent.data(); rt.leaf_node = ref_.leaf_node.data();
+                (void)qs_score_prepare(ctx_, &rt, (uint64_t)m);
+                trace_mark(opt, "host: scoring set-up done behind the enqueued counts");
+            }
             if (qs_sync(ctx_) != QS_OK) fail();
             trace_mark(opt, "host: all counts done (device synchronised)");
         } catch (...) {
@@ -364,6 +372,12 @@ public:
                      (opt.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u),
                      lq.data(), qp.data(), eqp.data(), &bif) != QS_OK)
             throw std::runtime_error(qs_last_error(quartetCounterLookup->context()));
+        if (opt.trace) {
+            float ph[6] = {0, 0, 0, 0, 0, 0};
+            (void)qs_last_score_ms(quartetCounterLookup->context(), ph);
+            std::fprintf(stderr, "[trace] qs_score %.2f ms: set-up %.2f, pass 1 %.2f, pass 2 / log filter %.2f, wait + copies %.2f, host finish %.2f; log %llu records\n",
+                         ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], (unsigned long long)qs_last_score_log(quartetCounterLookup->context()));
+        }
         // edge e = edge above node e+1 (preorder)
         LQICScores.assign(lq.begin() + 1, lq.end());
         if (bif) {

@@ -71,7 +71,7 @@ public:
         ncclResult_t comm_rc = ncclSuccess;
         std::promise<void> comm_done;
         comm_ready_ = comm_done.get_future().share();
-        std::thread comm_init([&] { comm_rc = ncclCommInitAll(comms_.data(), G_, devs.data()); comm_done.set_value(); });
+        std::thread comm_init([&] { trace_mark(opt_, "rccl thread: ncclCommInitAll starts"); comm_rc = ncclCommInitAll(comms_.data(), G_, devs.data()); trace_mark(opt_, "rccl thread: communicators ready"); comm_done.set_value(); });
         try {
             try { count(evalTreesPath, m); } catch (...) { comm_init.join(); throw; }
             comm_init.join();

@@ -107,6 +107,7 @@ struct qs_ctx {
     // tree batches go to the device through two pinned staging buffers on a copy stream of their own:
     // qs_batch_upload returns once the batch is in pinned memory, the copy of batch k+1 overlaps the counting of batch k
     hipStream_t copy_stream = nullptr;
+    hipStream_t prep_stream = nullptr;           // qs_score_prepare: uploads of the scoring set-up go here instead of `stream` (which may hold count kernels)
     void *pin[2] = {nullptr, nullptr};
     size_t pin_cap[2] = {0, 0};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};   // recorded after the last copy out of the buffer
@@ -1266,11 +1267,12 @@ static int get_ref(qs_ctx *c, const qs_ref_tree *ref, bool want_dev, const RefHo
     if (want_dev && !c->ref_lca_dev) {
         QS_HIP(c, hipMalloc(&c->ref_lca_dev, R->lca.size() * 4));
         QS_HIP(c, hipMalloc(&c->ref_next_dev, R->next.size() * 2));
-        QS_HIP(c, hipMemcpyAsync(c->ref_lca_dev, R->lca.data(), R->lca.size() * 4, hipMemcpyHostToDevice, c->stream));
-        QS_HIP(c, hipMemcpyAsync(c->ref_next_dev, R->next.data(), R->next.size() * 2, hipMemcpyHostToDevice, c->stream));
+        hipStream_t up = c->prep_stream ? c->prep_stream : c->stream;
+        QS_HIP(c, hipMemcpyAsync(c->ref_lca_dev, R->lca.data(), R->lca.size() * 4, hipMemcpyHostToDevice, up));
+        QS_HIP(c, hipMemcpyAsync(c->ref_next_dev, R->next.data(), R->next.size() * 2, hipMemcpyHostToDevice, up));
         if (!R->root_pairs.empty()) {
             QS_HIP(c, hipMalloc(&c->root_pairs_dev, R->root_pairs.size() * sizeof(RootPairHost)));
-            QS_HIP(c, hipMemcpyAsync(c->root_pairs_dev, R->root_pairs.data(), R->root_pairs.size() * sizeof(RootPairHost), hipMemcpyHostToDevice, c->stream));
+            QS_HIP(c, hipMemcpyAsync(c->root_pairs_dev, R->root_pairs.data(), R->root_pairs.size() * sizeof(RootPairHost), hipMemcpyHostToDevice, up));
         }
     }
     *out = R;
@@ -1296,7 +1298,11 @@ static int ensure_score_tables(qs_ctx *c) {
     lk[0] = 0.0;
     for (uint32_t k = 1; k < want; ++k) lk[k] = std::log((double)k);
     QS_HIP(c, hipMalloc(&c->dev_logk, (size_t)want * 8));
-    QS_HIP(c, hipMemcpy(c->dev_logk, lk.data(), (size_t)want * 8, hipMemcpyHostToDevice));
+    {   // (not the null stream: that one waits for count kernels still running on `stream`)
+        hipStream_t up = c->prep_stream ? c->prep_stream : c->stream;
+        QS_HIP(c, hipMemcpyAsync(c->dev_logk, lk.data(), (size_t)want * 8, hipMemcpyHostToDevice, up));
+        QS_HIP(c, hipStreamSynchronize(up));
+    }
     c->tbl_n = want;
     return QS_OK;
 }
@@ -1327,11 +1333,12 @@ static int ensure_bundle_plan(qs_ctx *c, ScoreDevice &sd, int pass) {
         plan_bundles(c->n, r0, r1, score_bundle_waves(pass), plan);
         const size_t words = 2 * (size_t)c->n + plan.rounds.size();
         if (hipMalloc(&c->bundle_dev[w], std::max<size_t>(words, 1) * 4) != hipSuccess) return fail(c, QS_ERR_OOM, "qs_score: round table of the bundle kernel");
-        QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w], plan.plo.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
-        QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w] + c->n, plan.pcnt.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
+        hipStream_t up = c->prep_stream ? c->prep_stream : c->stream;
+        QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w], plan.plo.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, up));
+        QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w] + c->n, plan.pcnt.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, up));
         if (!plan.rounds.empty())
-            QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w] + 2 * (size_t)c->n, plan.rounds.data(), plan.rounds.size() * 4, hipMemcpyHostToDevice, c->stream));
-        QS_HIP(c, hipStreamSynchronize(c->stream));   // (the host vectors may be re-planned by the next call)
+            QS_HIP(c, hipMemcpyAsync(c->bundle_dev[w] + 2 * (size_t)c->n, plan.rounds.data(), plan.rounds.size() * 4, hipMemcpyHostToDevice, up));
+        QS_HIP(c, hipStreamSynchronize(up));   // (the host vectors may be re-planned by the next call)
         c->bundle_r0[w] = r0; c->bundle_r1[w] = r1;
     }
     sd.bundle_plo = c->bundle_dev[w]; sd.bundle_pcnt = c->bundle_dev[w] + c->n; sd.bundle_rounds = c->bundle_dev[w] + 2 * (size_t)c->n;
@@ -1370,6 +1377,37 @@ extern "C" int qs_score_set_view(qs_ctx *c, const void *table_dev, uint32_t coun
     return QS_OK;
 }
 
+// qs_score's accumulators on the device and their pinned host copy, cached in the context
+static int ensure_score_accumulators(qs_ctx *c, size_t np) {
+    const size_t need_dev = np * (size_t)(3 + 1 + kCand) * 8, need_host = np * (size_t)(3 + kCand) * 8;
+    if (c->score_acc_cap < need_dev) {
+        if (c->score_acc) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_acc); }
+        c->score_acc = nullptr; c->score_acc_cap = 0;
+        QS_HIP(c, hipMalloc(&c->score_acc, need_dev));
+        c->score_acc_cap = need_dev;
+    }
+    if (c->score_acc_host_cap < need_host) {
+        if (c->score_acc_host) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->score_acc_host); }
+        c->score_acc_host = nullptr; c->score_acc_host_cap = 0;
+        QS_HIP(c, hipHostMalloc(&c->score_acc_host, need_host, hipHostMallocDefault));
+        c->score_acc_host_cap = need_host;
+    }
+    return QS_OK;
+}
+
+// the candidate log of the single-read scoring: records, the counter word, one word per node pair (tie filter)
+static bool ensure_score_log(qs_ctx *c, size_t np) {
+    const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
+    if (c->score_log && (c->score_log_cap != want_cap || c->score_log_pairs < np)) {
+        (void)hipStreamSynchronize(c->stream); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; c->score_log_pairs = 0;
+    }
+    if (!c->score_log) {
+        if (hipMalloc((void **)&c->score_log, (want_cap * 4 + 1 + np) * 8) == hipSuccess) { c->score_log_cap = want_cap; c->score_log_pairs = np; }
+        else (void)hipGetLastError();   // no room for the log: two passes
+    }
+    return c->score_log != nullptr;
+}
+
 extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_dev, int64_t *min_dev) {
     if (!c || !sums_dev || !min_dev) return fail(c, QS_ERR_ARG, "qs_score_pass1: NULL");
     if (!c->table && !c->view_table) return fail(c, QS_ERR_STATE, "qs_score_pass1: no table");
@@ -1400,13 +1438,7 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
                           (c->tune_score_passes == 2 || (c->tune_score_passes == 0 && c->tune_score_sample != 0 && scored_bytes >= (1ull << 30)));
     bool logging = false;
     if (want_log) {
-        const uint64_t want_cap = c->tune_score_log_cap ? c->tune_score_log_cap : (1ull << 23);   // 8 M records = 256 MB
-        if (c->score_log && c->score_log_cap != want_cap) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
-        // behind the records: the counter word, then one word per node pair (the pair's last logged triple)
-        if (c->score_log && c->score_log_pairs < np) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->score_log); c->score_log = nullptr; c->score_log_cap = 0; }
-        if (!c->score_log && hipMalloc((void **)&c->score_log, (want_cap * 4 + 1 + np) * 8) == hipSuccess) { c->score_log_cap = want_cap; c->score_log_pairs = np; }
-        else if (!c->score_log) (void)hipGetLastError();   // no room for the log: two passes
-        logging = c->score_log != nullptr;
+        logging = ensure_score_log(c, np);
     }
     if (logging) {
         sd.list = c->score_log; sd.list_count = c->score_log + 4 * c->score_log_cap; sd.list_cap = c->score_log_cap;
@@ -1451,6 +1483,45 @@ extern "C" int qs_score_pass1(qs_ctx *c, const qs_ref_tree *ref, int64_t *sums_d
     // rooted reference (degree-2 root): the sums of the node pairs (root, v) as the reference enumerates them (quirk Q5)
     if (c->root_pairs_dev) QS_HIP(c, launch_root_pair_sums(c->stream, sd, c->root_pairs_dev, (uint32_t)R.root_pairs.size(), R.root_items));
     return QS_OK;   // asynchronous on the context's stream
+}
+
+// Everything a first qs_score pays before its kernels -- reference tree + LCA matrix on the device, log table, the bundle
+// kernel's round tables, the accumulators with their pinned host copy, the candidate log, the kernels' code objects' first
+// use of the device-to-host copy path -- done ahead of time. Safe while count kernels of this context are still running (same
+// host thread): the uploads go through the copy stream, nothing waits for `stream`. The CLI calls it after the last batch
+// is enqueued, where the host would only wait: the scoring phase of 512 taxa x 10000 trees drops from 28 to ~15 ms.
+extern "C" int qs_score_prepare(qs_ctx *c, const qs_ref_tree *ref, uint64_t n_trees_total) {
+    if (!c || !ref) return fail(c, QS_ERR_ARG, "qs_score_prepare: NULL");
+    QS_HIP(c, hipSetDevice(c->device));
+    if (!c->copy_stream) QS_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    struct Restore { qs_ctx *c; ~Restore() { c->prep_stream = nullptr; } } restore{c};
+    c->prep_stream = c->copy_stream;
+    const bool had_ref = c->ref_lca_dev != nullptr;
+    const RefHost *Rp = nullptr;
+    int rc = get_ref(c, ref, !had_ref || true, &Rp);
+    if (rc != QS_OK) return rc;
+    const size_t np = (size_t)Rp->n_inner * Rp->n_inner;
+    if (np == 0) return fail(c, QS_ERR_ARG, "qs_score_prepare: bad reference tree");
+    const uint64_t keep_hint = c->table_trees_hint;
+    c->table_trees_hint = std::max<uint64_t>(c->table_trees_hint, n_trees_total);   // size the log table for the finished table
+    rc = ensure_score_tables(c);
+    c->table_trees_hint = keep_hint;
+    if (rc != QS_OK) return rc;
+    ScoreDevice sd;
+    fill_score_device(c, *Rp, c->ref_lca_dev, sd);
+    rc = ensure_bundle_plan(c, sd, 1);
+    if (rc == QS_OK) rc = ensure_bundle_plan(c, sd, 2);
+    if (rc != QS_OK) return rc;
+    rc = ensure_score_accumulators(c, np);
+    if (rc != QS_OK) return rc;
+    const uint64_t scored_bytes = sd.n_tuples * 3 * (uint64_t)(sd.count_bits / 8);
+    if (c->tune_score_kernel == 0 && c->bundle[0].n_parts == 0 && (c->tune_score_passes == 2 || (c->tune_score_passes == 0 && c->tune_score_sample != 0 && scored_bytes >= (1ull << 30))))
+        (void)ensure_score_log(c, np);
+    for (hipEvent_t &e : c->score_ev) if (!e) QS_HIP(c, hipEventCreate(&e));
+    // first use of the pinned accumulator copy by the device (the first device-to-host copy into freshly pinned memory took 7 ms)
+    QS_HIP(c, hipMemcpyAsync(c->score_acc_host, c->score_acc, np * (size_t)(3 + kCand) * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    QS_HIP(c, hipStreamSynchronize(c->copy_stream));
+    return QS_OK;
 }
 
 extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *min_dev, int64_t *cand_dev) {
@@ -1697,23 +1768,8 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     // the accumulators (sums, minima, candidate slots: 24 MB at 512 taxa) and their pinned host copy live in the context: three
     // hipMalloc / hipFree pairs and a pageable 22 MB copy per call were 1 ms of a 15 ms call
     struct Ptr { void *p; } sums{nullptr}, mn{nullptr}, cand{nullptr};
-    {
-        const size_t need_dev = np * (size_t)(3 + 1 + kCand) * 8, need_host = np * (size_t)(3 + kCand) * 8;
-        if (c->score_acc_cap < need_dev) {
-            QS_HIP(c, hipStreamSynchronize(c->stream));
-            if (c->score_acc) (void)hipFree(c->score_acc);
-            c->score_acc = nullptr; c->score_acc_cap = 0;
-            QS_HIP(c, hipMalloc(&c->score_acc, need_dev));
-            c->score_acc_cap = need_dev;
-        }
-        if (c->score_acc_host_cap < need_host) {
-            if (c->score_acc_host) (void)hipHostFree(c->score_acc_host);
-            c->score_acc_host = nullptr; c->score_acc_host_cap = 0;
-            QS_HIP(c, hipHostMalloc(&c->score_acc_host, need_host, hipHostMallocDefault));
-            c->score_acc_host_cap = need_host;
-        }
-        sums.p = c->score_acc; mn.p = (char *)c->score_acc + np * 3 * 8; cand.p = (char *)c->score_acc + np * 4 * 8;
-    }
+    { int rc_a = ensure_score_accumulators(c, np); if (rc_a != QS_OK) return rc_a; }
+    sums.p = c->score_acc; mn.p = (char *)c->score_acc + np * 3 * 8; cand.p = (char *)c->score_acc + np * 4 * 8;
     {   // the cached pieces both passes need (reference tree + LCA matrix, log table, bundle plans): built here so that
         // the first call's set-up cost shows as its own phase and the events below bracket kernels only
         const RefHost *Rp = nullptr;
@@ -1736,10 +1792,15 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
     rc = qs_score_overflow(c, ref, (const int64_t *)mn.p, (const int64_t *)cand.p, &extra, &n_extra);   // synchronises the stream
     if (rc != QS_OK) return rc;
     struct FreeHost { int64_t *p; ~FreeHost() { free(p); } } free_extra{extra};
+    // The accumulators come home through the COPY stream (the count stream is idle: qs_score_overflow has just synchronised
+    // it). The first large device-to-host copy enqueued on a stream that has run kernels costs ~8 ms on the host, once per
+    // stream (tools/d2h_cold.hip); a stream that only ever copies does not pay it -- that was most of a first call's
+    // "wait + copies" phase.
     int64_t *hs = (int64_t *)c->score_acc_host, *hc = hs + np * 3;
-    QS_HIP(c, hipMemcpyAsync(hs, sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->stream));
-    QS_HIP(c, hipMemcpyAsync(hc, cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->stream));
-    QS_HIP(c, hipStreamSynchronize(c->stream));
+    if (!c->copy_stream) QS_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    QS_HIP(c, hipMemcpyAsync(hs, sums.p, np * 3 * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    QS_HIP(c, hipMemcpyAsync(hc, cand.p, np * kCand * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    QS_HIP(c, hipStreamSynchronize(c->copy_stream));
     (void)hipEventElapsedTime(&c->score_ms[2], c->score_ev[0], c->score_ev[1]);
     (void)hipEventElapsedTime(&c->score_ms[3], c->score_ev[1], c->score_ev[2]);
     c->score_ms[4] = ms_since(t_ov);            // waiting for the passes + overflow pass (if any) + the accumulators' way back

@@ -227,6 +227,12 @@ class Context:
         del keep
         return lq, qp, eqp, bool(bif.value)
 
+    def score_prepare(self, ref: flatten.RefTree, n_trees_total: int = 0):
+        """qs_score_prepare: the set-up of a first score() ahead of time (allowed while count kernels are in flight)."""
+        s, keep = self._ref_struct(ref)
+        self._chk(self.L.qs_score_prepare(self.h, C.byref(s), int(n_trees_total)))
+        del keep
+
     # scoring in steps (table shards / multi-GPU); buffers are torch int64 CUDA tensors owned by the caller
     def score_pair_slots(self, ref: flatten.RefTree) -> int:
         s, keep = self._ref_struct(ref)

@@ -1038,6 +1038,41 @@ def test_automatic_scoring_mode_on_a_gigabyte_table(eng, kind):
             assert np.array_equal(got[1][i], got[mode][i], equal_nan=True), (mode, i)
 
 
+def test_score_prepare_behind_enqueued_counts(eng):
+    """qs_score_prepare (the CLI calls it behind its last qs_count_batch, while the device still counts): same scores as a
+    context that never heard of it, for a bifurcating, a rooted and a multifurcating reference; calling it twice, or after
+    the count has finished, changes nothing."""
+    from quartetscores_amd import native_ingest
+    n, m = 150, 600
+    text = native_ingest.synth_trees(n, m, 621)
+    for kind in ("binary", "rooted", "multifurcating"):
+        if kind == "multifurcating":
+            ref_nw = synth.tree_set(n, 1, 622, collapse=0.3)[0]
+        else:
+            ref_nw = synth.random_tree(n, np.random.default_rng(623), names=[f"t{i}" for i in range(n)], rooted=(kind == "rooted"))
+        ref = flatten.flatten_reference(ref_nw)
+        batch, _ = native_ingest.ingest_text(ref_nw, text, want_ranges=False)
+        res = []
+        for prepare in (False, True):
+            ctx = eng.Context(n, 32)
+            ctx.table_alloc()
+            hb = ctx.batch_upload(batch, with_nodes=False)
+            ctx.count_batch(hb)                      # asynchronous
+            if prepare:
+                ctx.score_prepare(ref, m)            # ... the set-up of the scoring behind it
+                ctx.score_prepare(ref, m)
+            sc = ctx.score(ref)
+            if prepare:
+                ctx.score_prepare(ref, m)
+                sc2 = ctx.score(ref)
+                assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(sc[:3], sc2[:3]))
+            res.append(sc)
+            ctx.close()
+        assert res[0][3] == res[1][3]
+        for i in range(3):
+            assert np.array_equal(res[0][i], res[1][i], equal_nan=True), (kind, i)
+
+
 def test_two_cell_wire_format(eng):
     """qs_table_pack16x2 / qs_unpack16x2: one word per tuple for batches of binary trees holding all taxa; the words
     of several ranks add without carries; the unpacked table equals the three-cell one; anything else is refused."""
