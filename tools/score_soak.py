@@ -1,5 +1,8 @@
 """Randomised soak of the score kernels: bundle kernel vs scan kernel (sums bit for bit, final scores identical) on random
-tables, taxon counts, cell widths, reference shapes and ragged views.   python tools/score_soak.py [cases] [seed]"""
+tables, taxon counts, cell widths, reference shapes and ragged views; single-read scoring (random pre-pass samples, tie
+filter on / off, log sizes that overflow or not, automatic mode) against two plain passes -- whole calls and the
+pass 1 / pass 2 steps with minima LOWERED between them (what a MIN over several shards does): same candidate sets.
+    python tools/score_soak.py [cases] [seed]"""
 import os
 import sys
 
@@ -50,7 +53,45 @@ for case in range(cases):
     def same(x, y):
         return (x[0] == y[0]).all() and all(np.array_equal(u, v, equal_nan=True) for u, v in zip(x[1][:3], y[1][:3]))
 
+    ctx.set_tuning(_lib.QS_TUNE_SCORE_PASSES, 1)
     ok = same(steps(0), steps(1))
+    # ---- single-read modes against two passes (bundle kernel, whole table)
+    ctx.set_tuning(_lib.QS_TUNE_SCORE_KERNEL, 0)
+    base = ctx.score(ref)
+    why = ""
+    for _ in range(4):
+        passes = int(rng.choice([0, 2, 2, 2]))
+        sample = int(rng.choice([0, 2, 4, 16, 4 | 65536, 64 | 65536, 2 | 65536]))
+        dedupe = int(rng.integers(0, 2))
+        cap = int(rng.choice([0, 64, 4096, 1 << 16]))
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_PASSES, passes)
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_SAMPLE, sample)
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_DEDUPE, dedupe)
+        ctx.set_tuning(_lib.QS_TUNE_SCORE_LOG_CAP, cap)
+        got = ctx.score(ref)
+        if not all(np.array_equal(u, v, equal_nan=True) for u, v in zip(base[:3], got[:3])):
+            ok = False
+            why += f" [score passes={passes} sample={sample} dedupe={dedupe} cap={cap} log={ctx.last_score_log()}]"
+        # the steps, with the minima lowered for a random subset of the node pairs between pass 1 and pass 2
+        sums = torch.empty(3 * P, dtype=torch.int64, device="cuda"); mins = torch.empty(P, dtype=torch.int64, device="cuda")
+        c_log = torch.empty(8 * P, dtype=torch.int64, device="cuda"); c_plain = torch.empty_like(c_log)
+        ctx.score_pass1(ref, sums, mins)
+        lower = torch.from_numpy(rng.random(P) < 0.3).cuda()
+        big = mins < (1 << 62)
+        mins2 = torch.where(lower & big, mins - int(rng.choice([1, 1 << 20, 1 << 40])), mins)
+        ctx.score_pass2(ref, mins2, c_log)
+        logged = ctx.last_score_log()
+        ctx.score_pass2(ref, mins2, c_plain)          # (the log is spent: this one reads the table)
+        a_, b_ = np.sort(c_log.cpu().numpy().reshape(-1, 8), axis=1), np.sort(c_plain.cpu().numpy().reshape(-1, 8), axis=1)
+        # a node pair whose 8 slots did not suffice carries the overflow marker (-2) in both; WHICH of its triples made it into
+        # the slots depends on the order of arrival (qs_score_overflow lists them all): those rows are compared by the marker only
+        ov_a, ov_b = (a_ == -2).any(axis=1), (b_ == -2).any(axis=1)
+        diff = (ov_a != ov_b) | (~ov_a & (a_ != b_).any(axis=1))
+        if ctx.last_score_log() != 0 or diff.any():
+            ok = False
+            why += f" [steps passes={passes} sample={sample} dedupe={dedupe} cap={cap} log={logged}: candidate sets differ in {int(diff.sum())} pairs]"
+    for key, val in ((_lib.QS_TUNE_SCORE_PASSES, 1), (_lib.QS_TUNE_SCORE_SAMPLE, 64 | 65536), (_lib.QS_TUNE_SCORE_DEDUPE, 1), (_lib.QS_TUNE_SCORE_LOG_CAP, 0)):
+        ctx.set_tuning(key, val)
     full = torch.from_numpy(np.ascontiguousarray(T.astype(dt)).reshape(-1).view(np.uint8)).cuda()
     item = 3 * (bits // 8)
     for _ in range(4):
@@ -69,6 +110,6 @@ for case in range(cases):
     ctx.score_set_view(None, 0, 0, 0)
     ctx.close()
     bad += not ok
-    print(f"case {case}: n={n} u{bits} {kind} m={m} seed={seed}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {case}: n={n} u{bits} {kind} m={m} seed={seed}: {'ok' if ok else 'MISMATCH' + why}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
