@@ -129,6 +129,7 @@ struct qs_ctx {
     size_t score_acc_cap = 0, score_acc_host_cap = 0;
     uint64_t last_score_estimate = 0;            // automatic single-read mode: predicted log records of the last qs_score (sample x S)
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
+    uint32_t tune_score_load = 0;                // QS_TUNE_SCORE_LOAD: 0 = a lane loads its row in 16-byte pieces, 1 = eight lanes load a row's chunk (LDS hand-over)
     uint32_t tune_score_dedupe = 1;              // QS_TUNE_SCORE_DEDUPE: the logging pass skips a quartet that repeats its node pair's last logged triple
     uint32_t tune_score_sample = 64u | 65536u;             // QS_TUNE_SCORE_SAMPLE: pre-pass of the single-read scoring (0 = none; S | by-round bit 16)
     uint64_t tune_score_log_cap = 0;             // QS_TUNE_SCORE_LOG_CAP: records the log may hold (0 = 8 M); tests force overflows
@@ -349,6 +350,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             if (value >> 17 || (value && (S < 2 || (S & (S - 1))))) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_SAMPLE takes 0 or a power of two in [2, 32768], optionally | 65536 (whole rounds)");
             c->tune_score_sample = (uint32_t)value; return QS_OK;
         }
+        case QS_TUNE_SCORE_LOAD: if (value > 1) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 or 1"); c->tune_score_load = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
         case QS_TUNE_SCORE_LOG_CAP:
             if (value > (1ull << 26)) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOG_CAP takes at most 2^26 records");
@@ -1310,7 +1312,8 @@ static int ensure_score_tables(qs_ctx *c) {
 static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t *lca_dev, ScoreDevice &sd) {
     sd.logk = c->dev_logk; sd.tbl_n = c->tbl_n;
     // as much of the log table as fits goes to LDS (every tuple sum of up to 15743 trees); larger arguments are range-checked
-    sd.lds_n = (uint32_t)std::min<uint64_t>(c->tbl_n, score_scan_max_lds_log());
+    sd.coop_load = c->tune_score_load;
+    sd.lds_n = (uint32_t)std::min<uint64_t>(c->tbl_n, score_scan_max_lds_log(c->tune_score_load != 0 && c->tune_score_kernel == 0));
     sd.ref_lca = lca_dev; sd.ref_next = c->ref_next_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
     if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }

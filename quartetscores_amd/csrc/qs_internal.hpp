@@ -118,6 +118,7 @@ struct ScoreDevice {
     const uint32_t *bundle_pcnt;
     const uint32_t *bundle_rounds; // n_rounds x (b / 16, pair group)
     uint32_t n_rounds;
+    uint32_t coop_load;            // bundle kernel: 1 = a row's 96-byte chunk is loaded by eight lanes and handed over through LDS (QS_TUNE_SCORE_LOAD)
     uint32_t sample;               // pass 1, bundle kernel: 0 = every chunk; else the minima-only pre-pass of the single-read scoring:
                                    //    bits 0..15 = S (a power of two): one chunk (bit 16 clear) or one round (bit 16 set) in S
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
@@ -126,7 +127,7 @@ struct ScoreDevice {
 constexpr int kCand = 8;
 constexpr unsigned long long kCandEmpty = ~0ull;
 constexpr unsigned long long kCandOverflow = ~0ull - 1; // in the LAST slot of a node pair: its slots did not suffice (qs_score_overflow)
-uint32_t score_scan_max_lds_log();
+uint32_t score_scan_max_lds_log(bool coop_load = false);
 // kernel: 0 = bundle kernel (a wave walks 64 rows with the same b in lockstep; needs sd.bundle_* = plan_bundles of the
 // rank range, and the partial rows at its ends, which go through the scan kernel), 1 = scan kernel (lane = 8 consecutive ranks)
 struct BundlePlan { std::vector<uint32_t> plo, pcnt, rounds; uint64_t part_lo[2], part_n[2]; int n_parts; };

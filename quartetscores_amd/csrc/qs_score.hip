@@ -168,11 +168,12 @@ __device__ __forceinline__ ScanSeg scan_classify(const ScoreDevice &sd, uint32_t
     return r;
 }
 
-struct ScanLds {
-    uint32_t key[kSSlots];
-    unsigned long long sum[kSSlots * 3];
-    long long mn[kSSlots];
+template <int HS> struct HashLds {
+    uint32_t key[HS];
+    unsigned long long sum[HS * 3];
+    long long mn[HS];
 };
+using ScanLds = HashLds<kSSlots>;
 
 __device__ __forceinline__ void scan_global_add(const ScoreDevice &sd, uint32_t key, unsigned long long s1, unsigned long long s2,
                                                 unsigned long long s3, long long mn) {
@@ -181,9 +182,10 @@ __device__ __forceinline__ void scan_global_add(const ScoreDevice &sd, uint32_t 
     atomicAdd(&sd.pair_sums[(size_t)key * 3 + 2], s3);
     atomicMin(&sd.pair_min[key], mn);
 }
-__device__ __forceinline__ void scan_flush(ScanLds &h, const ScoreDevice &sd, uint32_t key, unsigned long long s1, unsigned long long s2,
-                                           unsigned long long s3, long long mn) {
-    uint32_t slot = (key * 2654435761u) >> 22; // 10 bits
+template <int HS> __device__ __forceinline__ void scan_flush(HashLds<HS> &h, const ScoreDevice &sd, uint32_t key, unsigned long long s1,
+                                                             unsigned long long s2, unsigned long long s3, long long mn) {
+    static_assert((HS & (HS - 1)) == 0 && HS >= 64, "hash slots: a power of two");
+    uint32_t slot = (key * 2654435761u) >> (32 - __builtin_ctz((unsigned)HS)); // log2(HS) bits
 #pragma unroll 1
     for (int probe = 0; probe < 8; ++probe) {
         const uint32_t old = atomicCAS(&h.key[slot], kKeyEmpty, key);
@@ -194,7 +196,7 @@ __device__ __forceinline__ void scan_flush(ScanLds &h, const ScoreDevice &sd, ui
             atomicMin(&h.mn[slot], mn);
             return;
         }
-        slot = (slot + 1) & (kSSlots - 1);
+        slot = (slot + 1) & (HS - 1);
     }
     scan_global_add(sd, key, s1, s2, s3, mn); // crowded neighbourhood: straight to memory
 }
@@ -428,17 +430,30 @@ typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
 typedef qs_u32x4 qs_u32x4_a2 __attribute__((aligned(2)));   // rows start at any tuple: 4-byte (u32 cells) or 2-byte (u16 cells) aligned
 constexpr int kBundleWaves1 = QS_BUNDLE_W1, kBundleWaves2 = QS_BUNDLE_W2;
 
-template <typename CT, int PASS, int WAVES>
+// COOP (QS_TUNE_SCORE_LOAD = 1): the 96-byte chunk of a row is loaded by EIGHT lanes (12 bytes each, one load instruction
+// covers 8 rows x 96 contiguous bytes instead of 64 x 16 scattered ones) into a per-wave staging area in LDS, from which
+// every lane reads its own row's chunk back. The L1 sustains ~64 misses per CU whatever their size: the per-lane 16-byte
+// loads make one L2 request per load, this makes one per 64-byte segment. The hash shrinks to 512 slots to make room.
+constexpr int kBundleHashCoop = 512;
+constexpr int kStageRow = 96;                          // bytes per row and chunk in the staging area
+template <int PASS, int WAVES, bool COOP> constexpr size_t bundle_lds_fixed() {
+    return (PASS == 1 ? (COOP ? sizeof(HashLds<kBundleHashCoop>) : sizeof(ScanLds)) : 0) + (COOP ? (size_t)WAVES * kWave * kStageRow : 0);
+}
+typedef uint32_t qs_u32x3 __attribute__((ext_vector_type(3)));
+typedef qs_u32x3 qs_u32x3_a2 __attribute__((aligned(2)));
+template <typename CT, int PASS, int WAVES, bool COOP>
 __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice sd, double tol) {
     static_assert(PASS == 1 || PASS == 2, "pass 3 stays on score_scan_kernel");
     constexpr int kBundleWaves = WAVES, kBThreads = WAVES * kWave;
+    constexpr int HS = COOP ? kBundleHashCoop : kSSlots;
     extern __shared__ __align__(16) unsigned char scan_smem[];
-    ScanLds &hash = *reinterpret_cast<ScanLds *>(scan_smem);                   // used by pass 1 only
-    double *t1 = reinterpret_cast<double *>(scan_smem + (PASS == 1 ? sizeof(ScanLds) : 0));   // k log k
+    HashLds<HS> &hash = *reinterpret_cast<HashLds<HS> *>(scan_smem);           // used by pass 1 only
+    unsigned char *stage_all = scan_smem + (PASS == 1 ? sizeof(HashLds<HS>) : 0);   // COOP: WAVES x 64 rows x 96 bytes
+    double *t1 = reinterpret_cast<double *>(scan_smem + bundle_lds_fixed<PASS, WAVES, COOP>());   // k log k
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     for (uint32_t i = tid; i < sd.lds_n; i += kBThreads) t1[i] = (double)i * sd.logk[i];
     if (PASS == 1) {
-        for (uint32_t t = tid; t < (uint32_t)kSSlots; t += kBThreads) {
+        for (uint32_t t = tid; t < (uint32_t)HS; t += kBThreads) {
             hash.key[t] = kKeyEmpty;
             hash.sum[3 * t] = hash.sum[3 * t + 1] = hash.sum[3 * t + 2] = 0;
             hash.mn[t] = kSortableMax;
@@ -478,6 +493,17 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             unrank2(p, c, d);
             c += b + 1; d += b + 1;
             const CT *row = table + (rank4(0, b, c, d) - sd.rank_lo) * 3;
+            // COOP: in load instruction i this lane fetches piece (lane & 7) of the chunk of row 8 i + lane / 8
+            unsigned long long rb[COOP ? 8 : 1];
+            unsigned char *stg = stage_all + (size_t)wave * (kWave * kStageRow);
+            if (COOP) {
+                const unsigned long long rp = (unsigned long long)(uintptr_t)row;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int src = 8 * i + (int)(lane >> 3);
+                    rb[i] = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(rp >> 32), src, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)rp, src, kWave);
+                }
+            }
             const uint32_t e12 = L[(size_t)c * n + b], e23 = L[(size_t)d * n + c];
             const uint32_t *__restrict__ lrow = L + (size_t)b * n;
             const uint16_t *__restrict__ nrow = sd.ref_next + (size_t)b * n;
@@ -506,10 +532,34 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                 }
                 if (a0 + CH <= b) {                                     // uniform: the whole chunk lies in the row
                     constexpr int NV = CH * 3 * (int)sizeof(CT) / 16;   // 16-byte loads: 6 (u32 cells) / 3 (u16 cells)
-                    const qs_u32x4_a2 *src = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)a0);
+                    static_assert(!COOP || NV * 16 == kStageRow, "cooperative loads: chunks of 96 bytes");
                     uint32_t w[NV * 4];
+                    if (COOP) {
+                        const uint32_t boff = a0 * 3u * (uint32_t)sizeof(CT) + 12u * (lane & 7u);
+                        qs_u32x3 part[8];
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) { const qs_u32x4 v = src[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+                        for (int i = 0; i < 8; ++i) part[i] = *reinterpret_cast<const qs_u32x3_a2 *>((uintptr_t)(rb[i] + boff));
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            *reinterpret_cast<qs_u32x3 *>(stg + (8 * i + (lane >> 3)) * kStageRow + 12u * (lane & 7u)) = part[i];
+                        // the rows were written by other lanes of this wave: LDS operations of a wave complete in order, the
+                        // fences only keep the compiler from moving the reads in front of the writes
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) {
+                            const qs_u32x4 v = *reinterpret_cast<const qs_u32x4 *>(stg + lane * kStageRow + 16 * j);
+                            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    } else {
+                        const qs_u32x4_a2 *src = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)a0);
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) { const qs_u32x4 v = src[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+                    }
 #pragma unroll
                     for (int u = 0; u < CH; ++u)
 #pragma unroll
@@ -640,7 +690,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
         }
         if (PASS == 1) {   // the hash holds the node pairs of this round: one slot per thread to memory
             __syncthreads();
-            for (uint32_t t = tid; t < (uint32_t)kSSlots; t += kBThreads) {
+            for (uint32_t t = tid; t < (uint32_t)HS; t += kBThreads) {
                 const uint32_t k = hash.key[t];
                 if (k != kKeyEmpty) {
                     scan_global_add(sd, k, hash.sum[3 * t], hash.sum[3 * t + 1], hash.sum[3 * t + 2], hash.mn[t]);
@@ -734,8 +784,10 @@ template <typename CT, int PASS> static hipError_t launch_bundle(hipStream_t s, 
                                                                  const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
     constexpr int WAVES = PASS == 1 ? kBundleWaves1 : kBundleWaves2;
     if (sd.n_rounds > 0) {
-        const size_t lds = (PASS == 1 ? sizeof(ScanLds) : 0) + (size_t)sd.lds_n * 8;
-        auto k = score_bundle_kernel<CT, PASS, WAVES>;
+        const bool coop = sd.coop_load != 0;
+        const size_t lds = (coop ? bundle_lds_fixed<PASS, WAVES, true>() : bundle_lds_fixed<PASS, WAVES, false>()) + (size_t)sd.lds_n * 8;
+        if (lds > 160u * 1024u) return hipErrorInvalidValue;   // (lds_n is capped by score_scan_max_lds_log(coop))
+        auto k = coop ? score_bundle_kernel<CT, PASS, WAVES, true> : score_bundle_kernel<CT, PASS, WAVES, false>;
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         dim3 block(WAVES * kWave), grid(std::min<uint32_t>(sd.n_rounds, (uint32_t)std::max(1, n_cu)));
@@ -888,7 +940,12 @@ hipError_t launch_root_pair_sums(hipStream_t s, const ScoreDevice &sd, const voi
     return hipGetLastError();
 }
 
-uint32_t score_scan_max_lds_log() { return kScanMaxLdsLog; }
+// entries of the k log k table the kernels keep in LDS; with cooperative loads the staging areas take 48-60 KB of it
+uint32_t score_scan_max_lds_log(bool coop_load) {
+    constexpr size_t fixed = bundle_lds_fixed<1, kBundleWaves1, true>() > bundle_lds_fixed<2, kBundleWaves2, true>() ? bundle_lds_fixed<1, kBundleWaves1, true>()
+                                                                                                                    : bundle_lds_fixed<2, kBundleWaves2, true>();
+    return coop_load ? (uint32_t)((160u * 1024u - fixed - 256u) / 8u) : kScanMaxLdsLog;
+}
 
 // The same per quartet, but item i = the i-th 4-subset in LEXICOGRAPHIC order of its sorted lookup ids (a outermost, d
 // innermost): the order in which printRawQICScores walks the reference's Euler-tour leaves

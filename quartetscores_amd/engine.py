@@ -36,6 +36,10 @@ def count_bits_for(m: int) -> int:
 
 # qs_set_tuning values applied to every new Context (tests and A/B runs set entries here; empty in production)
 DEFAULT_TUNING = {}
+# A/B runs of whole test files / tools without editing them: QS_PY_TUNING="14=1,10=2" (key=value pairs of qs_set_tuning). This is
+# the PYTHON harness' switch; the library itself reads no environment variables.
+for _kv in filter(None, os.environ.get("QS_PY_TUNING", "").split(",")):
+    DEFAULT_TUNING[int(_kv.split("=")[0])] = int(_kv.split("=")[1])
 
 
 class Context:
