@@ -179,8 +179,10 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_SCORE_LOG_CAP 11u     /* records the candidate log of the single-read scoring may hold (0 = 8 M = 256 MB); tests force overflows */
 #define QS_TUNE_SCORE_SAMPLE 12u      /* single-read scoring: the pre-pass takes one round in S (value = S | 65536; default S = 64) or one 96-byte
                                        * chunk of every row in S (value = S); S a power of two; 0 = no pre-pass (and no automatic mode) */
-#define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel: 0 = every lane loads its own row in 16-byte pieces, 1 = eight lanes load the 96-byte chunk
-                                       * of a row together and hand it over through LDS (fewer, fuller requests to the L2) */
+#define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel, shape of the table loads: 0 (default) = every lane loads its own row in 16-byte pieces;
+                                       * 2 = ... and requests the next chunk before it processes the current one; 1 = eight lanes load the
+                                       * 96-byte chunk of a row together and hand it over through LDS; 3 = 1 with the next chunk requested
+                                       * ahead. All exact; 1-3 measured slower on MI355X (profiles/r03_experiments.md 12): A/B switches */
 #define QS_TUNE_SCORE_DEDUPE 13u      /* single-read scoring: 1 (default) = a quartet that repeats the triple logged last for its node pair is
                                        * not logged again (tables of similar trees put thousands of equal triples at a pair's bound); 0 = off */
 #define QS_TUNE_COOP 9u               /* binary full batches: 1 = run the tiles with two a-blocks through count_bitslice4_kernel, whose

@@ -350,7 +350,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             if (value >> 17 || (value && (S < 2 || (S & (S - 1))))) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_SAMPLE takes 0 or a power of two in [2, 32768], optionally | 65536 (whole rounds)");
             c->tune_score_sample = (uint32_t)value; return QS_OK;
         }
-        case QS_TUNE_SCORE_LOAD: if (value > 1) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 or 1"); c->tune_score_load = (uint32_t)value; return QS_OK;
+        case QS_TUNE_SCORE_LOAD: if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3"); c->tune_score_load = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
         case QS_TUNE_SCORE_LOG_CAP:
             if (value > (1ull << 26)) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOG_CAP takes at most 2^26 records");
@@ -1313,7 +1313,7 @@ static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t 
     sd.logk = c->dev_logk; sd.tbl_n = c->tbl_n;
     // as much of the log table as fits goes to LDS (every tuple sum of up to 15743 trees); larger arguments are range-checked
     sd.coop_load = c->tune_score_load;
-    sd.lds_n = (uint32_t)std::min<uint64_t>(c->tbl_n, score_scan_max_lds_log(c->tune_score_load != 0 && c->tune_score_kernel == 0));
+    sd.lds_n = (uint32_t)std::min<uint64_t>(c->tbl_n, score_scan_max_lds_log((c->tune_score_load == 1 || c->tune_score_load == 3) && c->tune_score_kernel == 0));
     sd.ref_lca = lca_dev; sd.ref_next = c->ref_next_dev; sd.n = c->n; sd.n_inner = R.n_inner; sd.d_lo = c->d_lo; sd.d_hi = c->d_hi;
     sd.rank_lo = c->rank_lo; sd.n_tuples = c->n_tuples; sd.table = c->table; sd.count_bits = (int)c->count_bits;
     if (c->view_table) { sd.rank_lo = c->view_rank_lo; sd.n_tuples = c->view_n; sd.table = const_cast<void *>(c->view_table); sd.count_bits = (int)c->view_bits; }

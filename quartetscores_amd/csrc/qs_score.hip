@@ -436,13 +436,16 @@ constexpr int kBundleWaves1 = QS_BUNDLE_W1, kBundleWaves2 = QS_BUNDLE_W2;
 // loads make one L2 request per load, this makes one per 64-byte segment. The hash shrinks to 512 slots to make room.
 constexpr int kBundleHashCoop = 512;
 constexpr int kStageRow = 96;                          // bytes per row and chunk in the staging area
-template <int PASS, int WAVES, bool COOP> constexpr size_t bundle_lds_fixed() {
+template <int PASS, int WAVES, bool COOP> constexpr size_t bundle_lds_fixed() {   // COOP = load mode 1
     return (PASS == 1 ? (COOP ? sizeof(HashLds<kBundleHashCoop>) : sizeof(ScanLds)) : 0) + (COOP ? (size_t)WAVES * kWave * kStageRow : 0);
 }
 typedef uint32_t qs_u32x3 __attribute__((ext_vector_type(3)));
 typedef qs_u32x3 qs_u32x3_a2 __attribute__((aligned(2)));
-template <typename CT, int PASS, int WAVES, bool COOP>
+// LM = 2 (QS_TUNE_SCORE_LOAD = 2): the per-lane loads of the NEXT chunk are issued before the current chunk is processed (two
+// chunks of every row in flight; tools/row_bw.hip: the bare access pattern reads 4.75 TB/s with one chunk in flight, 5.67 with two).
+template <typename CT, int PASS, int WAVES, int LM>
 __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice sd, double tol) {
+    constexpr bool COOP = LM == 1 || LM == 3, PF = LM == 2, CPF = LM == 3;   // 3 = cooperative loads, next chunk requested ahead
     static_assert(PASS == 1 || PASS == 2, "pass 3 stays on score_scan_kernel");
     constexpr int kBundleWaves = WAVES, kBThreads = WAVES * kWave;
     constexpr int HS = COOP ? kBundleHashCoop : kSSlots;
@@ -525,6 +528,10 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             double bound = -kHuge;                  // nothing is logged before the first node pair (a run may start unresolved: key stays empty)
             QicCache qc = {0xFFFFFFFFu, 0.0, 0.0};
             uint32_t end = 0;
+            constexpr int NVP = CH * 3 * (int)sizeof(CT) / 16;
+            qs_u32x4 nx[PF ? NVP : 1];                  // PF: the next chunk, already requested
+            qs_u32x3 nxp[CPF ? 8 : 1];                  // CPF: the same for the cooperative loads
+            bool nx_valid = false;                      // (uniform)
             for (uint32_t a0 = 0; a0 < b; a0 += CH) {                   // uniform
                 if (sampling) {                                         // uniform: the pre-pass takes one chunk in S and classifies afresh there
                     if (smask != 0xFFFFFFFFu && (((a0 / CH) + round + s_off) & smask) != 0) continue;
@@ -537,8 +544,21 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                     if (COOP) {
                         const uint32_t boff = a0 * 3u * (uint32_t)sizeof(CT) + 12u * (lane & 7u);
                         qs_u32x3 part[8];
+                        if (CPF && nx_valid) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) part[i] = *reinterpret_cast<const qs_u32x3_a2 *>((uintptr_t)(rb[i] + boff));
+                            for (int i = 0; i < 8; ++i) part[i] = nxp[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) part[i] = *reinterpret_cast<const qs_u32x3_a2 *>((uintptr_t)(rb[i] + boff));
+                        }
+                        if (CPF) {
+                            nx_valid = !(sampling && smask != 0xFFFFFFFFu) && a0 + 2 * CH <= b;
+                            if (nx_valid) {
+                                const uint32_t boffn = boff + (uint32_t)(CH * 3 * sizeof(CT));
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) nxp[i] = *reinterpret_cast<const qs_u32x3_a2 *>((uintptr_t)(rb[i] + boffn));
+                            }
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
                             *reinterpret_cast<qs_u32x3 *>(stg + (8 * i + (lane >> 3)) * kStageRow + 12u * (lane & 7u)) = part[i];
@@ -555,6 +575,25 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    } else if (PF) {
+                        qs_u32x4 cur[NV];
+                        if (nx_valid) {
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) cur[j] = nx[j];
+                        } else {
+                            const qs_u32x4_a2 *src = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)a0);
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) cur[j] = src[j];
+                        }
+                        // (a pre-pass that takes one chunk in S skips chunks: nothing to request ahead there)
+                        nx_valid = !(sampling && smask != 0xFFFFFFFFu) && a0 + 2 * CH <= b;
+                        if (nx_valid) {
+                            const qs_u32x4_a2 *srcn = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)(a0 + CH));
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) nx[j] = srcn[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) { w[4 * j] = cur[j].x; w[4 * j + 1] = cur[j].y; w[4 * j + 2] = cur[j].z; w[4 * j + 3] = cur[j].w; }
                     } else {
                         const qs_u32x4_a2 *src = reinterpret_cast<const qs_u32x4_a2 *>(row + 3 * (size_t)a0);
 #pragma unroll
@@ -784,10 +823,11 @@ template <typename CT, int PASS> static hipError_t launch_bundle(hipStream_t s, 
                                                                  const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
     constexpr int WAVES = PASS == 1 ? kBundleWaves1 : kBundleWaves2;
     if (sd.n_rounds > 0) {
-        const bool coop = sd.coop_load != 0;
+        const bool coop = sd.coop_load == 1 || sd.coop_load == 3;
         const size_t lds = (coop ? bundle_lds_fixed<PASS, WAVES, true>() : bundle_lds_fixed<PASS, WAVES, false>()) + (size_t)sd.lds_n * 8;
         if (lds > 160u * 1024u) return hipErrorInvalidValue;   // (lds_n is capped by score_scan_max_lds_log(coop))
-        auto k = coop ? score_bundle_kernel<CT, PASS, WAVES, true> : score_bundle_kernel<CT, PASS, WAVES, false>;
+        auto k = sd.coop_load == 1 ? score_bundle_kernel<CT, PASS, WAVES, 1> : sd.coop_load == 3 ? score_bundle_kernel<CT, PASS, WAVES, 3>
+                 : (sd.coop_load == 2 ? score_bundle_kernel<CT, PASS, WAVES, 2> : score_bundle_kernel<CT, PASS, WAVES, 0>);
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         dim3 block(WAVES * kWave), grid(std::min<uint32_t>(sd.n_rounds, (uint32_t)std::max(1, n_cu)));
