@@ -596,6 +596,17 @@ def main():
             else "reduce-scattered shard per rank" if (reduce_mode == "scatter" and steps > 0) \
             else ("qs_score: one read (sampled bounds, candidate log)" if (score_phases or {}).get("log_records") else "qs_score: two passes")
 
+    # the score kernels are HBM-bound: the warm call's table pass(es) against the 8 TB/s peak (6-7 TB/s is what a plain streaming
+    # read reaches on this chip: tools/read_bw.hip); `reads_of_table` = 1 when pass 2 was a filter over pass 1's candidate log
+    score_roofline = None
+    if score_phases and score_phases.get("pass1"):
+        one_read = bool(score_phases.get("log_records"))
+        t_ms = score_phases["pass1"] + (0.0 if one_read else score_phases.get("pass2", 0.0))
+        moved = ctx.table_bytes * (1 if one_read else 2)
+        score_roofline = {"bound": "hbm", "achieved": round(moved / t_ms * 1e-6, 1), "peak": 8000.0, "unit": "GB/s",
+                          "frac": round(moved / t_ms * 1e-6 / 8000.0, 4), "reads_of_table": 1 if one_read else 2,
+                          "table_pass_ms": round(t_ms, 3), "note": "pass 1 incl. the two samples" if one_read else "pass 1 + pass 2"}
+
     parity = None
     if binary_full_trees:              # tuples sum to m only when every tree resolves every quartet
         parity = True
@@ -738,6 +749,7 @@ def main():
             "score_phase_ms_cold": score_cold_ms,
             "score_phases_ms": score_phases,
             "score_phases_ms_cold": score_phases_cold,
+            "score_roofline": score_roofline,
             "input_generation_s": gen_s,
         },
     }

@@ -3,7 +3,8 @@
 # the out-of-core demo, CLI timings (incl. --trace), rooted reference, table shards on one GPU.
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r03_final; mkdir -p "$OUT"; export TMPDIR=/tmp
-bash tools/score_pmc.sh r03_score_single 512 10000 0 > "$OUT/score_pmc.log" 2>&1; echo "score pmc rc $?" | tee "$OUT/summary_b.txt"
+timeout -k 10 600 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; echo "bench default rc $?" | tee "$OUT/summary_b.txt"
+bash tools/score_pmc.sh r03_score_single 512 10000 0 > "$OUT/score_pmc.log" 2>&1; echo "score pmc rc $?" | tee -a "$OUT/summary_b.txt"
 timeout -k 10 400 python3 tools/score_soak.py 120 11 > "$OUT/score_soak.txt" 2>&1; echo "score soak rc $?" | tee -a "$OUT/summary_b.txt"; tail -1 "$OUT/score_soak.txt"
 timeout -k 10 600 bash tools/out_of_core_demo.sh 1200 40 > "$OUT/out_of_core.txt" 2>&1; echo "ooc rc $?" | tee -a "$OUT/summary_b.txt"
 tail -6 "$OUT/out_of_core.txt"
