@@ -66,7 +66,7 @@ struct FlatScratch {
     std::vector<int32_t> qidx;            // -1, or index into `quoted` (labels that needed unescaping)
     std::vector<std::string> quoted;
     std::vector<uint32_t> adj_off, nchild, fill;
-    std::vector<int32_t> adj, dist, prev, order, dfs_par, ipar;
+    std::vector<int32_t> adj, dist, du, prev, order, dfs_par, ipar;
     std::vector<uint32_t> start, end, depth;
     struct Frame { int32_t x, par; uint32_t k; };
     std::vector<Frame> st;
@@ -77,12 +77,24 @@ struct FlatScratch {
 namespace detail {
 
 inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+// character classes of the scanner: 1 = ends an unquoted label or a branch length ( ( ) , : ; [ and white space ), 2 = white space or '['
+// (what skip() has to look at). Labels and branch lengths are ~70 % of a Newick file: one table look-up per character.
+struct CharClass {
+    unsigned char t[256];
+    constexpr CharClass() : t() {
+        for (int i = 0; i < 256; ++i) t[i] = 0;
+        t[(unsigned char)'('] = 1; t[(unsigned char)')'] = 1; t[(unsigned char)','] = 1; t[(unsigned char)':'] = 1; t[(unsigned char)';'] = 1;
+        t[(unsigned char)'['] = 3; t[(unsigned char)' '] = 3; t[(unsigned char)'\t'] = 3; t[(unsigned char)'\n'] = 3; t[(unsigned char)'\r'] = 3;
+    }
+};
+static constexpr CharClass kCharClass{};
 
 // Newick text [b, e) -> s.parent / label spans. Same dialect and errors as NewickReader::parse_one.
 inline void parse_flat(const std::string &text, size_t b, size_t e, FlatScratch &s) {
     s.parent.clear(); s.lab_b.clear(); s.lab_e.clear(); s.qidx.clear(); s.quoted.clear();
     size_t i = b;
     auto skip = [&]() {
+        if (i < e && !(kCharClass.t[(unsigned char)text[i]] & 2)) return;   // (the usual case: nothing to skip)
         while (i < e) {
             const char c = text[i];
             if (is_ws(c)) ++i;
@@ -115,11 +127,7 @@ inline void parse_flat(const std::string &text, size_t b, size_t e, FlatScratch 
             return;
         }
         const size_t j0 = i;
-        while (i < e) {
-            const char c = text[i];
-            if (c == '(' || c == ')' || c == ',' || c == ':' || c == ';' || c == '[' || is_ws(c)) break;
-            ++i;
-        }
+        while (i < e && !kCharClass.t[(unsigned char)text[i]]) ++i;
         s.lab_b[node] = (uint32_t)j0; s.lab_e[node] = (uint32_t)i;
     };
     int32_t cur = add(-1);
@@ -145,7 +153,7 @@ inline void parse_flat(const std::string &text, size_t b, size_t e, FlatScratch 
             if (i < e && text[i] != '(' && text[i] != ')' && text[i] != ',' && text[i] != ':' && text[i] != ';') label(cur);
         } else if (c == ':') {
             ++i; skip();
-            while (i < e && text[i] != '(' && text[i] != ')' && text[i] != ',' && text[i] != ';' && text[i] != '[' && !is_ws(text[i])) ++i;
+            while (i < e && (!kCharClass.t[(unsigned char)text[i]] || text[i] == ':')) ++i;   // (a ':' inside a branch length does not end it)
         } else if (c == ';') {
             ++i;
             break;
@@ -184,26 +192,30 @@ inline void parse_flatten_append(const std::string &text, size_t b, size_t e, co
     auto nb = [&](int32_t x, uint32_t k) { return s.adj[s.adj_off[x] + k]; };
 
     int32_t r = 0;
-    if (recentre && N > 2) { // middle of a longest path (two BFS passes), as detail::centre
-        s.dist.resize(N); s.prev.resize(N);
-        auto bfs = [&](int32_t src) {
-            std::fill(s.dist.begin(), s.dist.end(), -1);
-            s.order.clear();
-            s.dist[src] = 0; s.prev[src] = -1;
-            s.order.push_back(src);
-            for (size_t k = 0; k < s.order.size(); ++k) {
-                const int32_t x = s.order[k];
-                for (uint32_t q = 0; q < deg(x); ++q) {
-                    const int32_t y = nb(x, q);
-                    if (s.dist[y] < 0) { s.dist[y] = s.dist[x] + 1; s.prev[y] = x; s.order.push_back(y); }
-                }
-            }
-            return s.order.back();
-        };
-        const int32_t u = bfs(0);
-        const int32_t v = bfs(u);
-        int32_t len = s.dist[v], x = v;        // path v .. u has len + 1 nodes; centre = element (len + 1) / 2 from v
-        for (int32_t step = 0; step < (len + 1) / 2; ++step) x = s.prev[x];
+    if (recentre && N > 2) {
+        // Middle of a longest path, the node detail::centre finds with its two BFS passes -- without the queues. Nodes are
+        // numbered in pre-order (a parent before its children, children in input order), so a BFS from node 0 visits every
+        // level in increasing index: its last node u is the LAST deepest node of a linear sweep. The distances from u follow in a
+        // second sweep (on the chain u..root directly, elsewhere parent + 1). Every node farthest from u ends a longest path, and
+        // all of them share the path's first half from u -- so the element (len + 1) / 2 steps from v does not depend on which
+        // farthest v is taken (for an even length it is the tree's centre, for an odd one the end of the central edge on u's side).
+        s.dist.resize(N); s.du.assign(N, -1);
+        s.dist[0] = 0;
+        int32_t u = 0;
+        for (size_t x = 1; x < N; ++x) { s.dist[x] = s.dist[s.parent[x]] + 1; if (s.dist[x] >= s.dist[u]) u = (int32_t)x; }
+        s.order.clear();                                   // the chain u .. root: order[i] = the node at distance i from u
+        for (int32_t x = u; x >= 0; x = s.parent[x]) { s.du[x] = (int32_t)s.order.size(); s.order.push_back(x); }
+        int32_t v = u;
+        for (size_t x = 0; x < N; ++x) {
+            if (s.du[x] < 0) s.du[x] = s.du[s.parent[x]] + 1;
+            if (s.du[x] >= s.du[v]) v = (int32_t)x;
+        }
+        const int32_t len = s.du[v];
+        int32_t x = v;
+        for (int32_t step = 0; step < (len + 1) / 2; ++step) {
+            const int32_t dx = s.du[x];
+            x = ((size_t)dx < s.order.size() && s.order[dx] == x) ? s.order[dx - 1] : s.parent[x];   // one step towards u
+        }
         r = x;
         if (deg(r) == 1) r = nb(r, 0);
     }

@@ -106,6 +106,42 @@ def test_cpp_host_flattening_matches_python_host(tmp_path):
     assert p.returncode == 1 and "unknown taxon 'zzz'" in p.stderr and "tree 70" in p.stderr
 
 
+def test_native_ingest_on_deep_and_decorated_trees_matches_python_host():
+    """The C++ ingest finds the centre of a tree with two linear sweeps over its pre-order arrays instead of two BFS passes,
+    and scans labels / branch lengths through a character table: the arrays must stay those of the Python flattening (which
+    runs the BFS) on random trees of several sizes, ladders (the longest possible paths, centre ties), ladder + NNI trees,
+    multifurcating / partial / rooted trees, and with branch lengths, comments, quoted labels and white space in the text."""
+    import sys
+    import numpy as np
+    from quartetscores_amd import flatten, native_ingest, synth
+    sys.setrecursionlimit(100000)
+    for n, m, kw in ((5, 120, {}), (8, 120, {}), (19, 150, {}), (19, 80, dict(collapse=0.3, dropout=0.2)), (19, 40, dict(rooted=True)),
+                     (64, 80, {}), (150, 60, {}), (150, 30, dict(collapse=0.4)), (150, 30, dict(dropout=0.3)), (300, 12, {})):
+        ref_nw = synth.reference_tree(n, 300 + n)
+        trees = synth.tree_set(n, m, 400 + n, **kw)
+        if 19 <= n <= 150:
+            lad = f"(t{n - 2},t{n - 1})"
+            for i in range(n - 3, -1, -1):
+                lad = f"(t{i},{lad})"
+            trees.append(lad + ";")
+            trees += list(synth.nni_tree_set(lad + ";", 15, 5))
+        rng = np.random.default_rng(n)
+
+        def deco(t):
+            t = "".join(ch + (" " if ch in ",)" and rng.random() < 0.3 else "") for ch in t)
+            if rng.random() < 0.5:
+                t = t.replace(")", "):0.%d" % rng.integers(1, 99999), 3)
+            if rng.random() < 0.3:
+                t = t.replace("t1,", "'t1'[a comment],", 1)
+            return t
+        trees = [deco(t) for t in trees]
+        ref = flatten.flatten_reference(ref_nw)
+        want = flatten.flatten_eval_trees(trees, ref.name_to_id)
+        got, _ = native_ingest.ingest_text(ref_nw, ("\n".join(trees) + "\n").encode(), threads=3)
+        for f in ("leaf_off", "leaf_ids", "adj_depth", "node_off", "rng_off", "ranges"):
+            assert np.array_equal(getattr(got, f), getattr(want, f)), (n, kw, f)
+
+
 def test_native_ingest_binding_matches_python_host(tmp_path):
     """quartetscores_amd.native_ingest (libquartetscores_host.so = the C++ host's ingest behind a C interface) gives
     the Python flattening's arrays, for any tree range and thread count; errors carry the tree index."""
