@@ -21,6 +21,7 @@
 #include <limits>
 #include <memory>
 #include <sstream>
+#include <future>
 #include <thread>
 #include <stdexcept>
 #include <tuple>
@@ -172,10 +173,18 @@ private:
         std::vector<qs_device_batch *> in_flight;
         unsigned progress = 1;
         const float onePercent = (float)m / 100;
+        // Batch k + 1 is parsed and flattened (on the host threads) while this thread validates, stages and enqueues batch k:
+        // with many small trees (256 taxa x 100000: 25 batches) the two used to alternate and the ingest bound the phase.
+        std::future<BatchFlat> ahead;
+        auto flatten_ahead = [&](size_t i0) {
+            const EvalFile *file = ef.get();
+            return std::async(std::launch::async, [this, file, i0, &opt] { return flatten_batch(*file, i0, opt); });
+        };
         try {
             for (size_t i0 = 0; i0 < spans.size(); i0 += opt.batch_trees) {
                 const size_t i1 = std::min(spans.size(), i0 + opt.batch_trees);
-                BatchFlat b = i0 == 0 ? std::move(first) : flatten_batch(*ef, i0, opt);
+                BatchFlat b = i0 == 0 ? std::move(first) : ahead.get();
+                if (i1 < spans.size()) ahead = flatten_ahead(i1);
                 qs_tree_batch hb;
                 hb.n_trees = b.n_trees; hb.leaf_off = b.leaf_off.data(); hb.leaf_ids = b.leaf_ids.data();
                 hb.adj_depth = b.adj_depth.data();
@@ -207,6 +216,7 @@ private:
             if (qs_sync(ctx_) != QS_OK) fail();
             trace_mark(opt, "host: all counts done (device synchronised)");
         } catch (...) {
+            if (ahead.valid()) { try { (void)ahead.get(); } catch (...) {} }   // (the worker still reads the evaluation file)
             (void)qs_sync(ctx_);
             for (auto *db : in_flight) qs_batch_free(ctx_, db);
             throw;
