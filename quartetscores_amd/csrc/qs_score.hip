@@ -421,7 +421,9 @@ __device__ __forceinline__ double bundle_qic(const double *__restrict__ t1, cons
 #define QS_BUNDLE_CH16 16   /* u16 cells: 16 tuples = the same 96 bytes (1024-taxon shard: 8.3 -> 7.6 ms in pass 1) */
 #endif
 #ifndef QS_BUNDLE_W1
-#define QS_BUNDLE_W1 8
+#define QS_BUNDLE_W1 12   /* round 3: the LOGGING pass 1 (the default from 1 GB) wants more waves than the plain one: 8 / 10 / 12 / 14 / 16 waves =
+                           * 12.4 / 11.8 / 11.7 / 12.1 / 12.1 ms incl. the samples at 512 taxa, 14.0 / 12.8 / 12.3 / 12.4 / 12.4 on reference + NNI trees;
+                           * the plain pass 1: 9.95 / 9.89 / 10.08 / 10.56 / 10.02 (profiles/r03_experiments.md 13) */
 #endif
 #ifndef QS_BUNDLE_W2
 #define QS_BUNDLE_W2 10

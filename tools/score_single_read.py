@@ -8,6 +8,8 @@ import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quartetscores_amd import _lib, engine, flatten, native_ingest
+if os.environ.get('QS_LIB'):   # kernel experiments: another build of the library (tools/Makefile exp)
+    _lib.LIB_PATH = os.path.abspath(os.environ['QS_LIB'])
 
 cases = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(512, 10000), (512, 10000, 1), (256, 12500)]
 for case in cases:
