@@ -60,7 +60,7 @@ struct qs_ctx {
     // first use; [0] binary tiling (16x8), [1] general / partial tiling (8x8). NULL = (d,c)-major (identity).
     uint32_t *perm[2] = {nullptr, nullptr};
     bool perm_built[2] = {false, false};
-    uint32_t tile_chunk = 4, tile_cblock = 16;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major
+    uint32_t tile_chunk = 2, tile_cblock = 16;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major (round 3: chunk 4 -> 2, -1 %)
     uint32_t tile_cgroup = 0;                          // > 1: c innermost in groups of this many (the waves of a workgroup share M[ab], M[bd])
     // binary tiling, cooperative workgroups (count_bitslice4_kernel): launch slots in groups of 4 tiles of one (a-blocks,
     // b-block, d-block) with consecutive c (bit 31 = shadow tile: takes part, does not store), and the list of the tiles
@@ -152,7 +152,15 @@ static uint32_t slice_groups(const qs_ctx *c, size_t group_bytes, uint32_t n_tot
     size_t g;
     bool balance = false;
     if (c->tune_slice_bytes) g = (size_t)c->tune_slice_bytes / group_bytes;
-    else if (ab_major) { g = std::min<size_t>(128, (2048ull << 20) / group_bytes); balance = true; }
+    else if (ab_major) {
+        // Every slice costs a pass over the table (read + write of every tuple), a larger slice a larger L2 working set. Measured
+        // on the round-3 kernel (profiles/r03_experiments.md 14): 512 taxa x 30000 trees best at 256 groups per slice (670 MB;
+        // 128: +3.5 %, 512: +0.7 %), 256 taxa x 100000 best at 512 groups (334 MB; 128: +3 %, 1024: +1.5 %), a 34 GB shard of 1024
+        // taxa x 5000 trees best in ONE slice of 157 groups (1.65 GB; two slices: +5 %): 256 groups, but at least 350 MB worth.
+        g = std::max<size_t>(256, (350ull << 20) / group_bytes);
+        g = std::min<size_t>(g, std::max<size_t>(1, (4096ull << 20) / group_bytes));
+        balance = true;
+    }
     else g = std::min<size_t>(std::max<size_t>(96ull << 20, 32 * group_bytes), 384ull << 20) / group_bytes;
     g = std::min<size_t>(std::max<size_t>(g, 1), std::max<uint32_t>(n_total, 1));
     if (balance) { const size_t slices = (n_total + g - 1) / g; g = (n_total + slices - 1) / std::max<size_t>(slices, 1); }

@@ -48,7 +48,7 @@ def tuple_sums_equal(torch, table, nq, bits, m):
     return True
 
 
-def check_full_size(eng, cfg_no, n, m, bits, d_lo=0, d_hi=0, expect_slices=True):
+def check_full_size(eng, cfg_no, n, m, bits, d_lo=0, d_hi=0, expect_slices=True, slice_bytes=0):
     """Property gates + brute-force lookups for one (shard of a) table at full size; returns (ctx, table, extras)."""
     import torch
     ref_nw, ref, text, batch = workload(cfg_no, n, m)
@@ -58,6 +58,8 @@ def check_full_size(eng, cfg_no, n, m, bits, d_lo=0, d_hi=0, expect_slices=True)
     assert nq == ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo)
     table = torch.zeros((ctx.table_bytes + 3) // 4, dtype=torch.int32, device="cuda")
     ctx.table_attach(table)
+    if slice_bytes:     # (a workload whose one depth class fits one default slice: keep the read-modify-write path in the test)
+        ctx.set_tuning(_lib.QS_TUNE_PANEL_SLICE_BYTES, slice_bytes)
     hb = ctx.batch_upload(batch, with_nodes=False)
     ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE | eng.QS_COUNT_TIMED)
     ctx.sync()
@@ -176,7 +178,7 @@ def test_configs4_shard_1024_taxa_5000_trees_u16(eng):
     """One of the 8 table shards of BASELINE configs[4] (34 GB of u16 cells; every GPU counts all 5000 trees)."""
     n, m = 1024, 5000
     d_lo, d_hi = distributed.shard_of_largest_id(n, 8, 3)
-    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 4, n, m, 16, d_lo, d_hi)
+    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 4, n, m, 16, d_lo, d_hi, slice_bytes=900_000_000)
     assert 33e9 < ctx.table_bytes < 35e9
     # the shard's part of the scoring (u16 cells, a plan restricted to d in [d_lo, d_hi)): both kernels, same sums
     a, b = score_steps(ctx, ref, 0), score_steps(ctx, ref, 1)
