@@ -163,7 +163,7 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_PANEL_KERNEL 3u      /* 0 = automatic, 1 = always the general bit-plane panel builder */
 #define QS_TUNE_TILE_ORDER 4u        /* launch order of the count kernel's tiles: 0 = (d,c)-major (the order of the table);
                                       * chunk | cblock << 16 = (a,b)-major: b-block, chunks of `chunk` a-blocks, blocks of
-                                      * `cblock` values of c, d-blocks (default 2 | 16 << 16) */
+                                      * `cblock` values of c, d-blocks (default 2 | 32 << 16) */
 #define QS_TUNE_SCORE_CAND_SLOTS 5u   /* candidate slots score pass 2 fills per node pair, 1..8 (default 8; tests force overflows) */
 #define QS_TUNE_SCORE_KERNEL 7u       /* score passes 1 and 2: 0 = bundle kernel (default; a wave walks 64 table rows with the same second id in lockstep), 1 = scan kernel (a lane walks 8 consecutive ranks; A/B and tests) */
 #define QS_TUNE_SCORE_TOL_EXP 6u      /* pass 2 keeps count triples whose device QIC is within 10^-value of the pair's minimum (default 12) */

@@ -60,7 +60,7 @@ struct qs_ctx {
     // first use; [0] binary tiling (16x8), [1] general / partial tiling (8x8). NULL = (d,c)-major (identity).
     uint32_t *perm[2] = {nullptr, nullptr};
     bool perm_built[2] = {false, false};
-    uint32_t tile_chunk = 2, tile_cblock = 16;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major (round 3: chunk 4 -> 2, -1 %)
+    uint32_t tile_chunk = 2, tile_cblock = 32;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major (round 3: 4 | 16 -> 2 | 32, -1.5 %)
     uint32_t tile_cgroup = 0;                          // > 1: c innermost in groups of this many (the waves of a workgroup share M[ab], M[bd])
     // binary tiling, cooperative workgroups (count_bitslice4_kernel): launch slots in groups of 4 tiles of one (a-blocks,
     // b-block, d-block) with consecutive c (bit 31 = shadow tile: takes part, does not store), and the list of the tiles
