@@ -179,6 +179,8 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_SCORE_LOG_CAP 11u     /* records the candidate log of the single-read scoring may hold (0 = 8 M = 256 MB); tests force overflows */
 #define QS_TUNE_SCORE_SAMPLE 12u      /* single-read scoring: the pre-pass takes one round in S (value = S | 65536; default S = 64) or one 96-byte
                                        * chunk of every row in S (value = S); S a power of two; 0 = no pre-pass (and no automatic mode) */
+#define QS_TUNE_CLASS_PCT 15u         /* batches are counted class by class of depth bits; a class holding less than this share of the trees (and
+                                       * at least 1024 trees otherwise) is merged into the next deeper one: every class costs a table pass (default 10) */
 #define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel, shape of the table loads: 0 (default) = every lane loads its own row in 16-byte pieces;
                                        * 2 = ... and requests the next chunk before it processes the current one; 1 = eight lanes load the
                                        * 96-byte chunk of a row together and hand it over through LDS; 3 = 1 with the next chunk requested

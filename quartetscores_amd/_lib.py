@@ -18,7 +18,7 @@ QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64, QS_SCORE_ROOT_AS_EDGE = 0, 1, 2
 QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
-QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD, QS_TUNE_CLASS_PCT = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares

@@ -129,6 +129,7 @@ struct qs_ctx {
     size_t score_acc_cap = 0, score_acc_host_cap = 0;
     uint64_t last_score_estimate = 0;            // automatic single-read mode: predicted log records of the last qs_score (sample x S)
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
+    uint32_t tune_class_pct = 10;                // QS_TUNE_CLASS_PCT: a depth class below this share of the batch's trees is merged into the next one
     uint32_t tune_score_load = 0;                // QS_TUNE_SCORE_LOAD: 0 = a lane loads its row in 16-byte pieces, 1 = eight lanes load a row's chunk (LDS hand-over)
     uint32_t tune_score_dedupe = 1;              // QS_TUNE_SCORE_DEDUPE: the logging pass skips a quartet that repeats its node pair's last logged triple
     uint32_t tune_score_sample = 64u | 65536u;             // QS_TUNE_SCORE_SAMPLE: pre-pass of the single-read scoring (0 = none; S | by-round bit 16)
@@ -358,6 +359,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             if (value >> 17 || (value && (S < 2 || (S & (S - 1))))) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_SAMPLE takes 0 or a power of two in [2, 32768], optionally | 65536 (whole rounds)");
             c->tune_score_sample = (uint32_t)value; return QS_OK;
         }
+        case QS_TUNE_CLASS_PCT: if (value > 100) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_CLASS_PCT takes 0 .. 100"); c->tune_class_pct = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_LOAD: if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3"); c->tune_score_load = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
         case QS_TUNE_SCORE_LOG_CAP:
@@ -804,7 +806,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
         std::vector<uint8_t> cls(nt);
         for (uint32_t t = 0; t < nt; ++t) { cls[t] = (uint8_t)cls_of(tree_depth[t]); cnt[cls[t]]++; mx[cls[t]] = std::max<uint32_t>(mx[cls[t]], tree_depth[t]); }
         uint32_t remap[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-        const uint32_t small = std::max<uint32_t>(1024, nt / 10);
+        const uint32_t small = std::max<uint32_t>(1024, (uint32_t)((uint64_t)nt * c->tune_class_pct / 100));
         for (uint32_t bb = 4; bb < top_bits; ++bb) {
             if (cnt[bb] == 0 || cnt[bb] >= small) continue;
             uint32_t up = bb + 1;

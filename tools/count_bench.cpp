@@ -65,6 +65,7 @@ int main(int argc, char **argv) {
         if (qs_create(&c, n, bits, 0, 0, nullptr, dlo, dhi) != QS_OK) { fprintf(stderr, "qs_create: %s\n", qs_last_error(nullptr)); return 1; }
         if (const char *sb = getenv("CB_SLICE_BYTES")) qs_set_tuning(c, QS_TUNE_PANEL_SLICE_BYTES, (uint64_t)atoll(sb));
         if (const char *co = getenv("CB_COOP")) qs_set_tuning(c, QS_TUNE_COOP, (uint64_t)atoll(co));
+        if (const char *cp = getenv("CB_CLASS_PCT")) qs_set_tuning(c, QS_TUNE_CLASS_PCT, (uint64_t)atoll(cp));
         if (const char *to = getenv("CB_TILE_ORDER")) if (qs_set_tuning(c, QS_TUNE_TILE_ORDER, (uint64_t)atoll(to)) != QS_OK) { fprintf(stderr, "tile order: %s\n", qs_last_error(c)); return 1; }
         if (qs_table_alloc(c) != QS_OK) { fprintf(stderr, "alloc: %s\n", qs_last_error(c)); return 1; }
         qs_device_batch *db = nullptr;
