@@ -495,9 +495,15 @@ extern "C" void qs_destroy(qs_ctx *c) {
 // batch of n_trees_hint trees. Purely an optimisation: qs_count_batch builds whatever is missing. The reference does the
 // equivalent set-up in the table's constructor (QuartetCounterLookup.hpp:245-273).
 static size_t Stager_padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }   // = Stager::padded (batches, below)
+static int prepare_staging(qs_ctx *c, uint64_t n_trees_hint);
 extern "C" int qs_prepare(qs_ctx *c, uint64_t n_trees_hint) {
     if (!c) return QS_ERR_ARG;
     QS_HIP(c, hipSetDevice(c->device));
+    // the staging allocations (two pinned buffers + a device slab: ~10 ms) on a helper thread beside the launch order (~15 ms of
+    // host work): they touch different members of the context
+    std::thread staging;
+    if (n_trees_hint) staging = std::thread([c, n_trees_hint] { (void)prepare_staging(c, n_trees_hint); });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_staging{staging};
     const uint32_t *order = nullptr;
     int rc = tile_order(c, 0, &order);
     if (rc != QS_OK) return rc;
@@ -507,12 +513,16 @@ extern "C" int qs_prepare(qs_ctx *c, uint64_t n_trees_hint) {
         if (hipMalloc(&c->panel, (size_t)groups * group_bytes) == hipSuccess) c->panel_bytes = (size_t)groups * group_bytes;
         else { c->panel = nullptr; (void)hipGetLastError(); }       // not fatal here: the count reports it if it persists
     }
-    if (n_trees_hint) {
+    return QS_OK;
+}
+static int prepare_staging(qs_ctx *c, uint64_t n_trees_hint) {
+    if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return QS_ERR_HIP; }
+    {
         // both pinned staging buffers and one device slab for batches of that many full trees (qs_batch_upload's Stager
         // would allocate them on first use: hipHostMalloc + hipMalloc, tens of ms in front of the first count)
         const uint64_t nt = std::min<uint64_t>(n_trees_hint, 1u << 22);
         const size_t need = Stager_padded(((size_t)nt + 1) * 4) + 2 * Stager_padded((size_t)nt * c->n * 2) + Stager_padded((size_t)nt * 4);
-        if (!c->copy_stream) QS_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { c->copy_stream = nullptr; (void)hipGetLastError(); return QS_ERR_HIP; }
         for (int slot = 0; slot < 2; ++slot)
             if (c->pin_cap[slot] < need) {
                 if (c->pin[slot]) { (void)hipHostFree(c->pin[slot]); c->pin[slot] = nullptr; c->pin_cap[slot] = 0; }
