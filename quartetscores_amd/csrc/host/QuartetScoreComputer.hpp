@@ -166,7 +166,9 @@ private:
     // batch boundaries: [0, first_batch_trees), then steps of batch_trees
     static size_t batch_end(size_t i0, size_t n, const DeviceOptions &opt) {
         const size_t first = std::max<size_t>(1, std::min(opt.first_batch_trees ? opt.first_batch_trees : opt.batch_trees, opt.batch_trees));
-        return std::min(n, i0 == 0 ? first : i0 + std::max<size_t>(1, opt.batch_trees));
+        size_t i1 = std::min(n, i0 == 0 ? first : i0 + std::max<size_t>(1, opt.batch_trees));
+        if (n - i1 < opt.batch_trees / 4) i1 = n;   // no small last batch: every batch costs a pass over the table
+        return i1;
     }
     BatchFlat flatten_batch(const EvalFile &ef, size_t i0, const DeviceOptions &opt) const {
         const size_t i1 = batch_end(i0, ef.spans.size(), opt);

@@ -224,7 +224,9 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
     const uint32_t cmax = d_hi >= 2 ? d_hi - 2 : 0;          // largest c of any tile
     const uint32_t Tmax = T_of(cmax);
     const uint32_t cblock = c->tile_cblock ? c->tile_cblock : cmax + 1;
-    for (uint32_t Bk = 1; Bk < Tmax; ++Bk) {                 // off-diagonal tiles under b-block Bk
+    // off-diagonal tiles under b-block Bk. (Building the lists of several Bk on helper threads was tried: in the CLI, where 8 host
+    // threads flatten the first batch at the same time, the set-up thread then was ready after 27-30 ms instead of 24.)
+    auto emit_Bk = [&](uint32_t Bk, std::vector<uint32_t> &out) {
         // binary: tile Bk^2/4 + j = a-blocks (2j, 2j+1); general: tile C(Bk,2) + j = a-block j (unrank2 in the kernel)
         const uint32_t base = bin ? (Bk * Bk) / 4 : Bk * (Bk - 1) / 2;
         const uint32_t nj = bin ? ((Bk + 1) * (Bk + 1)) / 4 - base : Bk;
@@ -237,7 +239,7 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
                     if (c->tile_cgroup <= 1) {
                         for (uint32_t cc = cb; cc < cb + cblock && cc + 1 < d1; ++cc) {
                             const uint32_t id = dp[k] + cp[cc] + base;
-                            for (uint32_t j = j0; j < j1; ++j) perm.push_back(id + j);
+                            for (uint32_t j = j0; j < j1; ++j) out.push_back(id + j);
                         }
                     } else {
                         // c innermost in groups of `cgroup`: the waves of a workgroup (consecutive slots) then hold the SAME
@@ -245,11 +247,12 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
                         for (uint32_t c4 = cb; c4 < cb + cblock && c4 + 1 < d1; c4 += c->tile_cgroup)
                             for (uint32_t j = j0; j < j1; ++j)
                                 for (uint32_t cc = c4; cc < c4 + c->tile_cgroup && cc < cb + cblock && cc + 1 < d1; ++cc)
-                                    perm.push_back(dp[k] + cp[cc] + base + j);
+                                    out.push_back(dp[k] + cp[cc] + base + j);
                     }
                 }
         }
-    }
+    };
+    for (uint32_t Bk = 1; Bk < Tmax; ++Bk) emit_Bk(Bk, perm);
     for (uint32_t kd = 0; kd < (Tmax + 1) / 2; ++kd)          // diagonal tiles (two diagonal blocks each)
         for (uint32_t k = 0; k < n_dblk; ++k) {
             const uint32_t d1 = d_hi - k * kDB;
