@@ -505,7 +505,10 @@ extern "C" int qs_prepare(qs_ctx *c, uint64_t n_trees_hint) {
     // the staging allocations (two pinned buffers + a device slab: ~10 ms) on a helper thread beside the launch order (~15 ms of
     // host work): they touch different members of the context
     std::thread staging;
-    if (n_trees_hint) staging = std::thread([c, n_trees_hint] { (void)prepare_staging(c, n_trees_hint); });
+    if (n_trees_hint) {
+        try { staging = std::thread([c, n_trees_hint] { (void)prepare_staging(c, n_trees_hint); }); }
+        catch (...) { (void)prepare_staging(c, n_trees_hint); }   // (no thread to be had: do it here; nothing throws across the C boundary)
+    }
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_staging{staging};
     const uint32_t *order = nullptr;
     int rc = tile_order(c, 0, &order);
