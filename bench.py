@@ -85,8 +85,81 @@ def parse_args():
     ap.add_argument("--table-shards", type=int, default=0, help="table-sharded mode: split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=-1, help="table-sharded mode on fewer ranks than shards: which shard this rank owns (default: its rank)")
     ap.add_argument("--slice-bytes", type=int, default=0, help="qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES); 0 = automatic")
+    ap.add_argument("--via-launcher", action="store_true",
+                    help="go through the spawn path of --gpus N > 1 even at N = 1 (a fresh torch.distributed.run child; this process never touches the GPU)")
+    ap.add_argument("--dry-launch", action="store_true", help="print the child command of the spawn path as one JSON line and exit")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only the PARENT. It never
+# makes a HIP call (no torch.cuda.* beyond device_count(), which reads the topology without creating a context); it
+# starts ONE fresh child `python -m torch.distributed.run ... bench.py <same arguments>`, passes the child's stderr
+# through, relays rank 0's JSON line as its own last line of stdout and exits with the child's code. No retry.
+# ---------------------------------------------------------------------------------------------------------------
+LAUNCH_ONLY_FLAGS = ("--via-launcher", "--dry-launch")
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_command(n_gpus, argv, port=None):
+    """The command the driver itself uses for N > 1 (task contract), with this script's own arguments."""
+    rest = [a for a in argv if a not in LAUNCH_ONLY_FLAGS]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + rest
+
+
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising the runtime (device_count() only reads the topology)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def launch(args, argv):
+    cmd = child_command(args.gpus, argv)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "n_ranks": args.gpus, "visible_gpus": visible_gpus()}))
+        return 0
+    have = visible_gpus()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, {have} visible "
+                         "(no CPU fallback in quartetscores_amd); nothing was launched\n")
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+    env["QS_BENCH_LAUNCHED_BY_PARENT"] = "1"
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    line = None
+    for ln in p.stdout:                                     # relay progress as it comes, keep the JSON line for the end
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank child failed (rc {rc}, JSON line {'present' if line else 'absent'})\n")
+        return rc or 1
+    try:
+        doc = json.loads(line)
+        doc.setdefault("config", {})["launcher"] = {"spawned_by": "bench.py parent (subprocess, no GPU call in the parent)",
+                                                     "child_wall_s": round(time.perf_counter() - t0, 2), "ranks": args.gpus}
+        line = json.dumps(doc)
+    except ValueError:
+        pass
+    sys.stdout.flush()
+    print(line)
+    sys.stdout.flush()
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -270,6 +343,8 @@ def main():
     args = parse_args()
     if args.cpu_child:
         return cpu_child(args.cpu_child)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.via_launcher or args.dry_launch):
+        sys.exit(launch(args, sys.argv[1:]))     # parent only: BEFORE torch is imported, never after a GPU call
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -277,11 +352,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    if torch.cuda.device_count() == 0:   # (counting devices does not initialise the GPU)
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in quartetscores_amd)")
-    use_dist = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:   # (counting devices does not initialise the GPU)
+        raise SystemExit(f"bench.py rank {rank} needs GPU {local_rank}: {torch.cuda.device_count()} visible (no CPU fallback in quartetscores_amd)")
+    # a rank started by torch.distributed.run (WORLD_SIZE set) always takes the RCCL path, also with one rank
+    use_dist = "WORLD_SIZE" in os.environ or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
 
     from quartetscores_amd import _lib, distributed, engine, flatten, native_ingest, ranks, synth
 
@@ -326,7 +402,7 @@ def main():
 
     # cpu_baseline leg first, in a child process, BEFORE this process touches the GPU (N = 1 only)
     cpu_baseline = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and rank == 0:          # rank 0 only; the other ranks wait at the rendezvous meanwhile
         cpu_baseline = run_cpu_baseline(ref_nw, sample_text, n, m, ranks.n_quartets(n), args.cpu_budget_s)
 
     cli_e2e = None
@@ -336,12 +412,25 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # QS_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, collective) even with one rank
+    comm = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        c0_ = time.perf_counter()
         dist.init_process_group(backend="nccl", device_id=dev)
+        # proof that RCCL's communicator spans the ranks the line claims: an all-reduce of ones must give the world size
+        # on every rank (the first collective also completes the lazy parts of the communicator set-up)
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(dev)
+        comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "proof": int(ones.item()),
+                "proof_ok": int(ones.item()) == world == dist.get_world_size(),
+                "comm_init_ms": round((time.perf_counter() - c0_) * 1e3, 1),
+                "comm_init_note": "rank 0: init_process_group + first all-reduce; outside the timed region"}
+        if not comm["proof_ok"]:
+            raise SystemExit(f"bench.py rank {rank}: all-reduce of ones gave {comm['proof']}, expected {world}")
 
     stream = torch.cuda.current_stream(dev)
     d_lo, d_hi = 0, n
@@ -365,7 +454,9 @@ def main():
     #   --reduce all: every rank ends with the full table (the wording of BASELINE.json north_star).
     # Wire format: while the summed counts stay below 2^16 (the reference's own CINT rule, QuartetScores.cpp:115-147)
     # the u32 table travels as u16 cells, binary full batches as ONE word per tuple; else the table's own cells.
-    collective = use_dist and shards == 1
+    # (one rank under torch.distributed.run -- `--via-launcher` at N = 1 -- initialises RCCL and proves its communicator, but has
+    # no peer to combine a table with: the step is the N = 1 step)
+    collective = (world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1") and shards == 1
     total_trees_reduced = m_total if split else m * world
     tables = [table]
     wire_fmt = None
@@ -545,14 +636,22 @@ def main():
         tables[:] = [table]
         pending[:] = [None]
     collective_saved, collective = collective, False
-    # per-kernel durations: an extra, untimed pass that reads the HIP events after every step
-    kern = []
-    for _ in range(3 if one_ms >= 100 else max(3, min(steps, 10))):
-        step(timed=True)
-        kern.append(ctx.last_count_ms() + (ctx.last_count_launches(),))
-    panel_ms = float(np.mean([k[0] for k in kern]))
-    count_ms = float(np.mean([k[1] for k in kern]))                      # all count-kernel launches of one step
-    launches = int(kern[-1][3]) or 1
+    # per-kernel durations = the events qs_count_batch recorded around every launch of the LAST step of the timed region
+    # (the roofline's `avg_launch_ms`). A sub-millisecond step is too short for one sample: there, and only there, the
+    # average over a few extra event-bracketed steps is used and labelled `kernel_ms_source`.
+    last_launches = ctx.last_count_launches() if steps > 0 else 0
+    kernel_ms_source = "last step of the timed region"
+    if last_step_ms and last_launches and one_ms >= 5:
+        panel_ms, count_ms, launches = float(last_step_ms[0]), float(last_step_ms[1]), int(last_launches)
+    else:
+        kern = []
+        for _ in range(max(3, min(steps, 10))):
+            step(timed=True)
+            kern.append(ctx.last_count_ms() + (ctx.last_count_launches(),))
+        panel_ms = float(np.mean([k[0] for k in kern]))
+        count_ms = float(np.mean([k[1] for k in kern]))                  # all count-kernel launches of one step
+        launches = int(kern[-1][3]) or 1
+        kernel_ms_source = f"mean of {len(kern)} extra event-bracketed steps after the timed region"
     variant = ctx.last_count_variant()
 
     # ---- parity gates run with every measurement -------------------------------------------------------------
@@ -741,6 +840,7 @@ def main():
             "panel_kernels_ms_per_step": panel_ms,
             "count_kernels_ms_per_step": count_ms,
             "count_launches_per_step": launches,
+            "kernel_ms_source": kernel_ms_source,
             "prewarm_ms": args.prewarm_ms,
             "count_kernels_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
@@ -804,8 +904,12 @@ def main():
         roof["pmc_source"] = f"none under profiles/ for kernel source {kernel_source_sha()}"
     out["roofline"] = roof
 
-    if cpu_baseline is not None:                     # reported at N=1 only
+    if cpu_baseline is not None:                     # rank 0's host, at every N
         out["cpu_baseline"] = cpu_baseline
+    if comm is not None:
+        comm["collective_alone_ms"] = coll_alone_ms
+        comm["table_collective"] = reduce_mode
+        out["collective"] = comm
 
     if use_dist:
         dist.barrier()

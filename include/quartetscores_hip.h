@@ -66,7 +66,9 @@ enum {
     QS_ERR_STATE = -4,      /* call order (e.g. score before count) */
     QS_ERR_OVERFLOW = -5,   /* a counter would exceed count_bits, or candidate buffer overflow */
     QS_ERR_NO_DEVICE = -6,  /* no gfx950 device: the library does not fall back to the CPU */
-    QS_ERR_UNSUPPORTED = -7
+    QS_ERR_UNSUPPORTED = -7,
+    QS_ERR_REFERENCE_THROWS = -8 /* the reference itself ends with an uncaught std::runtime_error on this input; qs_last_error()
+                                  * is that exception's what() (QS_SCORE_SAVEMEM_LOOKUPS) */
 };
 
 /* qs_create flags */
@@ -99,6 +101,16 @@ enum {
  * EQP-IC minima below them. With QS_SCORE_ROOT_AS_EDGE the root is treated as a
  * subdivision of one edge instead: both root edges carry the scores of the unrooted internode. */
 #define QS_SCORE_ROOT_AS_EDGE 2u
+/* The reference's memory-efficient table (`-s`, QuartetCounterLookup.hpp:303-311) behind the lookups of a degree-2 root's node
+ * pairs. Those calls repeat an id (b == c or b == d); quartet_lookup_table.hpp:170-212 sorts the ids and :79-85 throws
+ * std::runtime_error when the resulting index lies behind the table -- which happens for EVERY rooted reference tree with
+ * four or more taxa (e.g. two ids equal to n-1 give C(n,4) + ...; pinned on the unmodified header, tests/test_oracle_reftable.py),
+ * so the reference's run ends with that uncaught exception. With this flag qs_score / qs_score_finish report exactly that:
+ * QS_ERR_REFERENCE_THROWS, qs_last_error() = the what() of the first throwing call in the reference's sequential order
+ * ("id = <index>, but quartet_lookup_.size() = <C(n,4)>"). Without it (default) the pairs (root, v) are scored as the
+ * reference's n^4 table scores them, where a repeated id reads a cell that is never incremented. No effect on unrooted
+ * reference trees or with QS_SCORE_ROOT_AS_EDGE. */
+#define QS_SCORE_SAVEMEM_LOOKUPS 4u
 
 /*
  * A batch of evaluation trees, flattened by the host (see quartetscores_amd/csrc/host
@@ -207,7 +219,10 @@ uint64_t qs_table_tuples(const qs_ctx *ctx); /* number of 4-sets owned = C(d_hi,
 uint64_t qs_table_bytes(const qs_ctx *ctx);  /* tuples * 3 * count_bits/8 (compare quartet_lookup_table.hpp:69-71) */
 int qs_table_alloc(qs_ctx *ctx);             /* hipMalloc + zero; QS_ERR_OOM if it does not fit */
 int qs_table_attach(qs_ctx *ctx, void *device_ptr, uint64_t bytes); /* caller-owned device memory, e.g. a torch tensor: 4-byte
-                                              * aligned, at least qs_table_bytes() rounded up to a multiple of 4 */
+                                              * aligned, at least qs_table_bytes() rounded up to a multiple of 4.
+                                              * (NULL, 0) detaches a caller-owned table after waiting for the context's
+                                              * stream: the caller may free it, e.g. once a reduce-scattered shard is
+                                              * the scoring view (qs_score_set_view) */
 void *qs_table_device_ptr(const qs_ctx *ctx);
 int qs_table_clear(qs_ctx *ctx);
 int qs_table_download(qs_ctx *ctx, void *host_dst, uint64_t bytes);

@@ -360,6 +360,11 @@ typedef struct {
      * report how many table increments were done; 0 = off (every parity test) */
     double budget_s, budget_t0;
     volatile int budget_hit;
+    /* quartet_lookup_table.hpp:79-85: the const get_tuple throws std::runtime_error when the index of the (sorted) ids
+     * lies behind the table; the reference does not catch it (the scoring loop dies). Restated as a sticky flag + the
+     * exception's text; qso_score returns -3. Reached only with REPEATED ids: savemem + a degree-2 reference root. */
+    volatile int threw;
+    char threw_what[128];
     unsigned long long incr_done;
     int prefault;
     int table_savemem, table_bits;
@@ -689,7 +694,17 @@ static void count_quartet_occurrences(const Oracle *o, size_t aIdx, size_t bIdx,
         uint64_t a = (uint64_t)o->ref_id_to_lookup[aIdx], b = (uint64_t)o->ref_id_to_lookup[bIdx];
         uint64_t c = (uint64_t)o->ref_id_to_lookup[cIdx], d = (uint64_t)o->ref_id_to_lookup[dIdx];
         uint64_t r = qso_rank(a, b, c, d);
-        if (r >= o->nq) { *q1 = *q2 = *q3 = 0; return; } /* reference throws (qlt:81-83); not reachable for distinct ids */
+        if (r >= o->nq) { /* quartet_lookup_table.hpp:81-83: throw std::runtime_error("id = ..., but quartet_lookup_.size() = ...") */
+            Oracle *w = (Oracle *)o;
+#pragma omp critical(qso_threw)
+            if (!w->threw) {
+                snprintf(w->threw_what, sizeof w->threw_what, "id = %llu, but quartet_lookup_.size() = %llu",
+                         (unsigned long long)r, (unsigned long long)o->nq);
+                w->threw = 1;
+            }
+            *q1 = *q2 = *q3 = 0;
+            return;
+        }
         *q1 = cell_get(o->compact, o->bits, r * 3 + (uint64_t)qso_slot(a, b, c, d));
         *q2 = cell_get(o->compact, o->bits, r * 3 + (uint64_t)qso_slot(a, c, b, d));
         *q3 = cell_get(o->compact, o->bits, r * 3 + (uint64_t)qso_slot(a, d, b, c));
@@ -704,8 +719,10 @@ static void count_quartet_occurrences(const Oracle *o, size_t aIdx, size_t bIdx,
 int qso_lookup(void *h, int a, int b, int c, int d, uint64_t *out3) {
     Oracle *o = (Oracle *)h;
     if (!o->fast && !o->compact) return -1;
+    o->threw = 0; o->threw_what[0] = 0;
     count_quartet_occurrences(o, (size_t)o->lookup_to_node[a], (size_t)o->lookup_to_node[b],
                               (size_t)o->lookup_to_node[c], (size_t)o->lookup_to_node[d], &out3[0], &out3[1], &out3[2]);
+    if (o->threw) { snprintf(o->err, sizeof o->err, "%s", o->threw_what); o->threw = 0; return -3; } /* the reference throws */
     return 0;
 }
 
@@ -897,6 +914,7 @@ static void process_node_pair(Oracle *o, size_t uIdx, size_t vIdx) {
                     size_t c = o->eulerTourLeaves[ci], d = o->eulerTourLeaves[di];
                     uint64_t q1, q2, q3;
                     count_quartet_occurrences(o, a, b, c, d, &q1, &q2, &q3);
+                    if (o->threw) return; /* the exception leaves processNodePair (and ends the reference's run) */
                     p1 += (unsigned)q1; p2 += (unsigned)q2; p3 += (unsigned)q3;
                     P1 += q1; P2 += q2; P3 += q3;
                     double qic = qso_log_score(q1, q2, q3);
@@ -974,6 +992,7 @@ int qso_score(void *h, int nthreads, int qp_exact64) {
     (void)nthreads;
 #endif
     o->qp_exact64 = qp_exact64;
+    o->threw = 0; o->threw_what[0] = 0;
     tree_information_init(o);
     free(o->LQ); free(o->QP); free(o->EQP);
     size_t ne = (size_t)(t->n_edges > 0 ? t->n_edges : 1);
@@ -992,12 +1011,16 @@ int qso_score(void *h, int nthreads, int qp_exact64) {
         for (int i = 0; i < t->n_nodes; i++) {
             if (node_is_leaf(t, i)) continue;
             for (int j = i + 1; j < t->n_nodes; j++) {
-                if (node_is_leaf(t, j)) continue;
+                if (node_is_leaf(t, j) || o->threw) continue;
                 process_node_pair(o, (size_t)i, (size_t)j);
             }
         }
     }
     o->t_score = now_s() - t0;
+    if (o->threw) { /* the reference terminates with this what() (uncaught std::runtime_error) */
+        snprintf(o->err, sizeof o->err, "%s", o->threw_what);
+        return -3;
+    }
     return 0;
 }
 

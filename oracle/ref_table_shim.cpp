@@ -15,6 +15,8 @@
 
 #include <cstdint>
 #include <cstddef>
+#include <cstring>
+#include <stdexcept>
 
 namespace {
 template <typename T> struct Box { QuartetLookupTable<T> t; };
@@ -101,6 +103,34 @@ void qsref_table_occurrences(void *h, int bits, uint64_t a, uint64_t b, uint64_t
     case 8: QSREF_OCC(uint8_t)
     case 16: QSREF_OCC(uint16_t)
     default: QSREF_OCC(uint32_t)
+    }
+}
+
+// The same lookup for ids that may REPEAT (a rooted reference tree makes QuartetScoreComputer.hpp:393-396 call
+// countQuartetOccurrences with b == c or b == d): the const get_tuple (quartet_lookup_table.hpp:79-85) throws
+// std::runtime_error when the index of the sorted ids falls behind the table. Returns 0 and the three cells, or 1 and
+// the exception's what() in msg -- no exception crosses the C boundary.
+#define QSREF_OCC_CHECKED(T)                                                        \
+    {                                                                               \
+        auto const &tab = ((Box<T> *)h)->t;                                         \
+        const auto &tuple = tab.get_tuple(a, b, c, d);                              \
+        out3[0] = tuple[tab.tuple_index(a, b, c, d)];                               \
+        out3[1] = tuple[tab.tuple_index(a, c, b, d)];                               \
+        out3[2] = tuple[tab.tuple_index(a, d, b, c)];                               \
+        if (index_out) *index_out = (uint64_t)(&tuple - &tab.get_tuple(0, 1, 2, 3)); \
+        return 0;                                                                   \
+    }
+int qsref_table_occurrences_checked(void *h, int bits, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t *out3,
+                                    uint64_t *index_out, char *msg, uint64_t msg_len) {
+    try {
+        switch (bits) {
+        case 8: QSREF_OCC_CHECKED(uint8_t)
+        case 16: QSREF_OCC_CHECKED(uint16_t)
+        default: QSREF_OCC_CHECKED(uint32_t)
+        }
+    } catch (std::runtime_error const &e) {
+        if (msg && msg_len) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
+        return 1;
     }
 }
 

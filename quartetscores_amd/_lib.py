@@ -9,12 +9,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libquartetscores_hip.so")
 
 QS_OK = 0
-QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEVICE, QS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEVICE, QS_ERR_UNSUPPORTED, QS_ERR_REFERENCE_THROWS = -1, -2, -3, -4, -5, -6, -7, -8
 QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER = 0, 1, 2
 QS_COUNT_OVERWRITE = 0x100
 QS_COUNT_TIMED = 0x200
 QS_COUNT_WIRE16X2 = 0x400
-QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64, QS_SCORE_ROOT_AS_EDGE = 0, 1, 2
+QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64, QS_SCORE_ROOT_AS_EDGE, QS_SCORE_SAVEMEM_LOOKUPS = 0, 1, 2, 4
 QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4

@@ -69,6 +69,8 @@ struct DeviceOptions {
     unsigned ingest_threads = 0; // host threads that parse + flatten (0 = hardware concurrency); the CLI's -t
     bool qp_exact64 = false;
     bool root_as_edge = false;   // QS_SCORE_ROOT_AS_EDGE: a degree-2 root as a subdivision of one edge (not the reference's quirk Q5)
+    bool savemem_lookups = false; // QS_SCORE_SAVEMEM_LOOKUPS (the CLI's -s): a rooted reference tree ends the run with the
+                                 // std::runtime_error the reference's compact table throws (quartet_lookup_table.hpp:79-85)
     std::string load_table, save_table; // count-table persistence
     bool trace = false;          // --trace: time stamps of the counting pipeline on stderr
 };
@@ -392,7 +394,8 @@ public:
         std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
         int bif = 0;
         if (qs_score(quartetCounterLookup->context(), &rt,
-                     (opt.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u),
+                     (opt.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u) |
+                         ((enforceSmallMem || opt.savemem_lookups) ? QS_SCORE_SAVEMEM_LOOKUPS : 0u),
                      lq.data(), qp.data(), eqp.data(), &bif) != QS_OK)
             throw std::runtime_error(qs_last_error(quartetCounterLookup->context()));
         if (opt.trace) {

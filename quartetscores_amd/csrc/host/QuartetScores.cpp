@@ -5,8 +5,10 @@
 //                 [--device N] [--algo gather|scatter] [--exact-qp] [--qic-binary raw.bin]
 //
 // -t sets the number of host threads that parse + flatten the evaluation trees (the reference's OpenMP
-// threads counted quartets; here that happens on the GPU). -s/--savemem is accepted and has no effect: the
-// GPU table is always the compact C(n,4)x3 layout with semantic (1x) counts.
+// threads counted quartets; here that happens on the GPU). -s/--savemem does not change the table: the GPU table
+// is always the compact C(n,4)x3 layout with semantic (1x) counts. It selects the reference's compact-table lookups
+// where those differ observably: with a ROOTED reference tree the reference's table throws (quartet_lookup_table.hpp:79-85)
+// and the run ends with that error, here as there (QS_SCORE_SAVEMEM_LOOKUPS).
 // --save-table / --load-table write / read the raw count table (resume without recounting).
 #include "QuartetScoreComputer.hpp"
 #include "multi_gpu.hpp"
@@ -42,7 +44,8 @@ void usage(std::ostream &os) {
           "   -q, --qic      Path to the file where to write the raw QIC scores for each quartet\n"
           "   -t, --threads  Maximum number of host threads for parsing the evaluation trees (0 = all)\n"
           "   -v, --verbose  Verbose mode\n"
-          "   -s, --savemem  Consume less memory (accepted; the GPU table is always the compact one)\n"
+          "   -s, --savemem  Consume less memory (the GPU table is always the compact one; with a ROOTED reference tree the run\n"
+          "                  ends with the reference's own std::runtime_error, see --root-as-edge)\n"
           "   --device N     HIP device ordinal (default 0)\n"
           "   --gpus N       split the evaluation trees over N GPUs of this node (devices --device .. --device+N-1) and\n"
           "                  combine the count tables with one RCCL collective over xGMI\n"
@@ -193,6 +196,7 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     a.dev.ingest_threads = (unsigned)a.threads;
+    a.dev.savemem_lookups = a.savemem;   // -s: the reference's compact table behind the lookups of a rooted reference tree
     trace_mark(a.dev, "main: arguments parsed");
     // HIP start-up (~0.1-0.2 s: driver, device, code objects) begins NOW on a helper thread, while this thread reads and
     // splits the Newick files; the counter's own set-up thread then finds the runtime initialised
@@ -211,14 +215,6 @@ int main(int argc, char *argv[]) {
             std::cout << std::endl;
         }
 
-        {   // a rooted reference tree (degree-2 root): say once which of the reference's two behaviours is reproduced
-            size_t root_children = 0;
-            for (size_t v = 1; v < referenceTree.node_count(); ++v) root_children += referenceTree.parent[v] == 0;
-            if (root_children == 2 && !a.dev.root_as_edge)
-                std::cerr << "Note: the reference tree is rooted. QP-IC of the two root edges and EQP-IC along root paths follow the reference's\n"
-                             "      runtime-efficient (n^4) table; its memory-efficient table (-s, or when n^4 cells exceed 0.9 x RAM) reads other\n"
-                             "      cells for those node pairs and is NOT reproduced. --root-as-edge scores the root as a point on one edge.\n";
-        }
         std::vector<double> lqic, qpic, eqpic;
         size_t m = countEvalTrees(a.eval);
         trace_mark(a.dev, "main: evaluation file read and split into trees");
@@ -247,6 +243,11 @@ int main(int argc, char *argv[]) {
         out << write_newick(referenceTree, comment) << "\n";
     } catch (const std::exception &e) {
         std::cerr << "ERROR: " << e.what() << std::endl;
+        if (a.savemem && std::string(e.what()).rfind("id = ", 0) == 0)
+            std::cerr << "       (-s with a rooted reference tree: the reference's memory-efficient table throws this std::runtime_error for the\n"
+                         "       node pairs of the root, quartet_lookup_table.hpp:79-85, and its run ends here as well. Without -s the root's\n"
+                         "       pairs are scored like the reference's runtime-efficient table scores them; --root-as-edge treats the root as\n"
+                         "       a point on one edge.)\n";
         return 1;
     }
 

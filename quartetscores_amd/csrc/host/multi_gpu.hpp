@@ -230,7 +230,8 @@ private:
         qs_ref_tree rt;
         rt.n_nodes = (uint32_t)refTree.node_count(); rt.n_taxa = (uint32_t)ref_.names.size();
         rt.parent = ref_.parent.data(); rt.leaf_node = ref_.leaf_node.data();
-        const uint32_t flags = (opt_.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt_.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u);
+        const uint32_t flags = (opt_.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt_.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u) |
+                                   (opt_.savemem_lookups ? QS_SCORE_SAVEMEM_LOOKUPS : 0u);
         std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
         int bif = 0;
         if (full_) {   // every GPU holds the whole table: GPU 0 scores alone

@@ -137,7 +137,8 @@ public:
             run_on_all([&](PerGpu &w) { round2(w, mins, cand); });
             for (PerGpu &w : gpu_) extra.insert(extra.end(), w.extra.begin(), w.extra.end());
             release();
-            const uint32_t flags = (opt_.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt_.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u);
+            const uint32_t flags = (opt_.qp_exact64 ? QS_SCORE_QP_EXACT64 : QS_SCORE_QP_WRAP32) | (opt_.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u) |
+                                   (opt_.savemem_lookups ? QS_SCORE_SAVEMEM_LOOKUPS : 0u);
             std::vector<double> lq(rt.n_nodes), qp(rt.n_nodes), eqp(rt.n_nodes);
             int bif = 0;
             if (qs_score_finish(nullptr, &rt, flags, sums.data(), cand.data(), (uint32_t)K, extra.empty() ? nullptr : extra.data(), extra.size() / 4,

@@ -587,7 +587,16 @@ extern "C" int qs_table_alloc(qs_ctx *c) {
 
 extern "C" int qs_table_attach(qs_ctx *c, void *device_ptr, uint64_t bytes) {
     if (c) c->log_valid = false;   // (the table / view / tuning may change: a logged pass 1 no longer describes it)
-    if (!c || !device_ptr) return fail(c, QS_ERR_ARG, "qs_table_attach: NULL");
+    if (!c) return QS_ERR_ARG;
+    if (!device_ptr) {
+        // detach: the caller takes its buffer back (e.g. to free a full table once its reduce-scattered shard is the scoring view)
+        if (bytes != 0) return fail(c, QS_ERR_ARG, "qs_table_attach: NULL pointer with a size (detach = NULL, 0)");
+        if (c->table && c->table_owned) return fail(c, QS_ERR_STATE, "qs_table_attach: detach of a table the context owns (qs_table_alloc)");
+        QS_HIP(c, hipSetDevice(c->device));
+        QS_HIP(c, hipStreamSynchronize(c->stream));   // nothing of this context may still be writing the buffer
+        c->table = nullptr; c->table_owned = false;
+        return QS_OK;
+    }
     // 16-bit cells are updated through their 32-bit word (packed half-word atomics of the scatter kernel, word-wise
     // collectives): the buffer must cover whole words
     const uint64_t need = (qs_table_bytes(c) + 3) & ~3ull;
@@ -1537,7 +1546,9 @@ extern "C" int qs_score_prepare(qs_ctx *c, const qs_ref_tree *ref, uint64_t n_tr
     if (!c || !ref) return fail(c, QS_ERR_ARG, "qs_score_prepare: NULL");
     QS_HIP(c, hipSetDevice(c->device));
     if (!c->copy_stream) QS_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    struct Restore { qs_ctx *c; ~Restore() { c->prep_stream = nullptr; } } restore{c};
+    // every exit path -- also the error returns below -- leaves the copy stream drained: what was uploaded through it is marked
+    // present in the context, and the kernels of a later qs_score run on `stream`, which has no ordering against `copy_stream`
+    struct Restore { qs_ctx *c; ~Restore() { c->prep_stream = nullptr; (void)hipStreamSynchronize(c->copy_stream); } } restore{c};
     c->prep_stream = c->copy_stream;
     const bool had_ref = c->ref_lca_dev != nullptr;
     const RefHost *Rp = nullptr;
@@ -1590,7 +1601,10 @@ extern "C" int qs_score_pass2(qs_ctx *c, const qs_ref_tree *ref, const int64_t *
         unsigned long long n_rec = 0;
         QS_HIP(c, hipMemcpyAsync(&n_rec, c->score_log + 4 * c->score_log_cap, 8, hipMemcpyDeviceToHost, c->stream));
         QS_HIP(c, hipStreamSynchronize(c->stream));
-        if (n_rec <= c->score_log_cap) {
+        // A counter that reached the capacity is an overflow: waves reserve chunks of 64 records, the capacity is a multiple
+        // of 64, so the counter can stop exactly AT the capacity while waves that found the log full at the start of a row
+        // have skipped their hits without moving it. Only a log with room left is known to be complete.
+        if (n_rec < c->score_log_cap) {
             sd.list = c->score_log; sd.list_cap = c->score_log_cap;
             QS_HIP(c, launch_score_log(c->stream, sd, c->tune_score_tol, n_rec));
             c->last_score_log = n_rec;
@@ -1664,6 +1678,53 @@ extern "C" int qs_score_overflow(qs_ctx *c, const qs_ref_tree *ref, const int64_
 
 extern "C" void qs_free_host(void *p) { free(p); }
 
+// QS_SCORE_SAVEMEM_LOOKUPS + a degree-2 reference root. For a node pair (root, v) the reference calls
+// countQuartetOccurrences(a, b, c, d) with a in S1 (the root's other side), b in S2 = ALL leaves on v's side, c in S3, d in S4
+// (v's child subtrees; QuartetScoreComputer.hpp:393-396,412-424): b repeats c or d. Its compact table sorts the ids
+// (quartet_lookup_table.hpp:170-212) and the const get_tuple throws std::runtime_error("id = ..., but quartet_lookup_.size() =
+// ...") when the index C(t1,4)+C(t2,3)+C(t3,2)+t4 of the sorted ids t1 >= t2 >= t3 >= t4 lies behind the table (:79-85), e.g.
+// whenever the two largest are both n-1: for every rooted reference tree with 4 or more taxa some call does (proved case by
+// case in DESIGN.md 1, checked on the unmodified header in tests/test_oracle_reftable.py). The exception is not caught
+// anywhere in the reference: its run ends there. This finds the FIRST throwing call in the reference's sequential order
+// (pairs by node index; a, b, c, d nested in that order, each ascending) without walking the O(n^4) calls: the index is
+// monotone in every id, so the calls of a prefix throw iff the one with the largest remaining ids does.
+static uint64_t dup_index(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {   // lookup_index_ on ids that may repeat
+    uint32_t t[4] = {a, b, c, d};
+    std::sort(t, t + 4);
+    return binom4(t[3]) + binom3(t[2]) + binom2(t[1]) + t[0];
+}
+static bool first_compact_throw(const RefHost &R, uint64_t nq, uint64_t *id_out) {
+    for (const RootPairHost &P : R.root_pairs) {
+        if (!P.s1_n || !P.s3_n || !P.s4_n) continue;
+        const uint32_t a_hi = P.s1_lo + P.s1_n - 1, c_hi = P.s3_lo + P.s3_n - 1, d_hi = P.s4_lo + P.s4_n - 1;
+        // the largest index any call of this pair reaches: b repeats the largest c or the largest d
+        if (std::max(dup_index(a_hi, c_hi, c_hi, d_hi), dup_index(a_hi, d_hi, c_hi, d_hi)) < nq) continue;
+        for (uint32_t a = P.s1_lo; a <= a_hi; ++a) {
+            if (std::max(dup_index(a, c_hi, c_hi, d_hi), dup_index(a, d_hi, c_hi, d_hi)) < nq) continue;
+            for (uint32_t b = P.s2_lo; b < P.s2_lo + P.s2_n; ++b) {
+                const bool in3 = b >= P.s3_lo && b <= c_hi, in4 = b >= P.s4_lo && b <= d_hi;
+                if (in3) {            // calls (a, b, c = b, d), d ascending: a throwing d exists iff the largest throws
+                    if (dup_index(a, b, b, d_hi) < nq) continue;
+                    for (uint32_t d = P.s4_lo; d <= d_hi; ++d)
+                        if (dup_index(a, b, b, d) >= nq) { *id_out = dup_index(a, b, b, d); return true; }
+                } else if (in4) {     // calls (a, b, c, d = b), c ascending
+                    if (dup_index(a, b, c_hi, b) < nq) continue;
+                    for (uint32_t c = P.s3_lo; c <= c_hi; ++c)
+                        if (dup_index(a, b, c, b) >= nq) { *id_out = dup_index(a, b, c, b); return true; }
+                }
+            }
+        }
+    }
+    return false;
+}
+static int check_savemem_lookups(qs_ctx *c, const RefHost &R, uint32_t flags) {
+    if (!(flags & QS_SCORE_SAVEMEM_LOOKUPS) || (flags & QS_SCORE_ROOT_AS_EDGE) || !R.bifurcating || !R.root_deg2) return QS_OK;
+    const uint64_t nq = binom4(R.n);
+    uint64_t id = 0;
+    if (!first_compact_throw(R, nq, &id)) return QS_OK;
+    return fail(c, QS_ERR_REFERENCE_THROWS, "id = " + std::to_string(id) + ", but quartet_lookup_.size() = " + std::to_string(nq));
+}
+
 // Pure host: log_score of the O(#node pairs) candidates and sums with the host libm
 // (QuartetScoreComputer.hpp:135-159), then the min-propagation along path(u,v) (:448-454, :472-489).
 extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, const int64_t *sums_host,
@@ -1677,6 +1738,7 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
     const RefHost &R = *Rp;
     const bool root_as_edge = (flags & QS_SCORE_ROOT_AS_EDGE) != 0;
     if (is_bifurcating) *is_bifurcating = R.bifurcating ? 1 : 0;
+    { int rc_s = check_savemem_lookups(c, R, flags); if (rc_s != QS_OK) return rc_s; }
     if (R.bifurcating && (!qpic || !eqpic)) return fail(c, QS_ERR_ARG, "qs_score: qpic/eqpic required for a bifurcating reference");
     const size_t np = (size_t)R.n_inner * R.n_inner;
     const unsigned long long *sums = (const unsigned long long *)sums_host;
@@ -1817,6 +1879,8 @@ extern "C" int qs_score(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags, doubl
         // the first call's set-up cost shows as its own phase and the events below bracket kernels only
         const RefHost *Rp = nullptr;
         int rc0 = get_ref(c, ref, true, &Rp);
+        if (rc0 != QS_OK) return rc0;
+        rc0 = check_savemem_lookups(c, *Rp, flags);      // (the reference throws during its scoring loop: before any kernel here)
         if (rc0 != QS_OK) return rc0;
         rc0 = ensure_score_tables(c);
         if (rc0 != QS_OK) return rc0;

@@ -1487,7 +1487,8 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g_in, cons
     if (g_in.total_tiles == 0 || n_groups == 0) return hipSuccess;
     const uint32_t npairs = (uint32_t)binom2(g_in.n);
     CountGeometry g = g_in;
-    if (mode == MODE_BINARY_FULL && g.perm_coop && g.n_coop) {
+    // (count_bitslice4_kernel carries at most 7 planes per element: deeper classes take the plain kernel over g.perm with all tiles)
+    if (mode == MODE_BINARY_FULL && g.perm_coop && g.n_coop && depth_bits <= 7) {
         // the tiles whose workgroups share their panel loads (count_bitslice4_kernel); the others follow below through
         // count_bitslice3_kernel with the rest list as its launch order (disjoint tiles: both write the same table)
         dim3 grid4(g.n_coop / kWavesPerBlock), block4(kCountThreads);

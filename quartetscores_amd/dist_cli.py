@@ -19,6 +19,12 @@ import sys
 import time
 
 
+def score_flags(args):
+    from . import _lib
+    return ((_lib.QS_SCORE_QP_EXACT64 if args.exact_qp else _lib.QS_SCORE_QP_WRAP32) |
+            (_lib.QS_SCORE_ROOT_AS_EDGE if args.root_as_edge else 0) | (_lib.QS_SCORE_SAVEMEM_LOOKUPS if args.savemem else 0))
+
+
 def _annotate(ref, lq, qp, eqp, bif):
     """Newick text with "qp-ic:X;lq-ic:Y;eqp-ic:Z" comments per edge, parts omitted when +inf; the qp-ic guard tests
     the LQ value like the reference (quartet_newick_writer.hpp:164-187, quirk Q6). %f = std::to_string(double)."""
@@ -77,7 +83,7 @@ def _table_sharded(args, ref, world, rank, dev, say, t_begin):
         if args.verbose:
             print(f"[rank {rank}] shard {k}: largest id in [{d_lo},{d_hi}), {ctx.table_bytes} bytes ({ctx.last_count_variant()})")
         return ctx
-    flags = _lib.QS_SCORE_QP_EXACT64 if args.exact_qp else _lib.QS_SCORE_QP_WRAP32
+    flags = score_flags(args)
     lq, qp, eqp, bif = distributed.score_table_shards(open_shard, mine, ref, flags, device=dev, close=lambda c: c.close())
     if world > 1:
         dist.barrier()
@@ -102,6 +108,10 @@ def main(argv=None):
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("-t", "--threads", type=int, default=0, help="host threads per rank for parsing the evaluation trees (0 = all)")
     ap.add_argument("--exact-qp", action="store_true", help="64-bit QP sums instead of the reference's 32-bit wrap")
+    ap.add_argument("-s", "--savemem", action="store_true",
+                    help="the reference's memory-efficient table behind the lookups of a ROOTED reference tree: it throws there "
+                         "(quartet_lookup_table.hpp:79-85) and so does this run (QS_SCORE_SAVEMEM_LOOKUPS)")
+    ap.add_argument("--root-as-edge", action="store_true", help="a degree-2 reference root as a point on one edge (QS_SCORE_ROOT_AS_EDGE)")
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto")
     ap.add_argument("--table-shards", type=int, default=-1,
                     help="table-sharded mode (1024 taxa x u16 = 273 GB: 8 ranks, 8 shards): the count table in K shards by largest taxon "
@@ -154,7 +164,7 @@ def main(argv=None):
         say("Finished counting quartets.")
         say(f"It took: {int((time.perf_counter() - t0) * 1e6)} microseconds.")
         t0 = time.perf_counter()
-        flags = _lib.QS_SCORE_QP_EXACT64 if args.exact_qp else _lib.QS_SCORE_QP_WRAP32
+        flags = score_flags(args)
         lq, qp, eqp, bif = distributed.score_sharded(ctx, ref, flags, device=dev)
         say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
         say("Finished computing scores.")

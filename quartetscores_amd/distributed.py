@@ -222,6 +222,12 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
     reduce_scatter_table(send, recv, group)
     rank_lo, n_owned = scatter_owned(ctx.table_tuples, world, rank, wire)
     shard = recv
+    if wire == "u32x2":
+        # the full 12 B / tuple table is not needed any more: detach and release it before the shard is allocated
+        ctx.table_attach(None)
+        table = None
+    # the reduced shard holds ALL ranks' trees: the scoring kernels size their k*log k table from it, not from this rank's share
+    ctx.set_tuning(_lib.QS_TUNE_TABLE_TREES, int(total_trees))
     if wire == "u16x2":                            # restore the third cell: n2 = total trees - n0 - n1
         shard = torch.zeros(table_words(max(n_owned, 1), 16), dtype=torch.int32, device=dev)
         ctx.unpack16x2(recv, n_owned, total_trees, shard)

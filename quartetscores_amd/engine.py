@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib, flatten, newick
 from ._lib import (QS_ALGO_AUTO, QS_ALGO_GATHER, QS_ALGO_SCATTER, QS_COUNT_OVERWRITE, QS_COUNT_TIMED, QS_COUNT_WIRE16X2, QS_SCORE_QP_EXACT64,  # noqa: F401
-                   QS_SCORE_QP_WRAP32, QS_SCORE_ROOT_AS_EDGE)
+                   QS_SCORE_QP_WRAP32, QS_SCORE_ROOT_AS_EDGE, QS_SCORE_SAVEMEM_LOOKUPS)
 
 
 class QSError(RuntimeError):
@@ -87,7 +87,12 @@ class Context:
         self._chk(self.L.qs_table_alloc(self.h))
 
     def table_attach(self, tensor):
-        """tensor: a torch CUDA tensor with >= table_bytes bytes (kept alive by this object)."""
+        """tensor: a torch CUDA tensor with >= table_bytes bytes (kept alive by this object); None detaches the
+        caller-owned table (waits for the context's stream first)."""
+        if tensor is None:
+            self._chk(self.L.qs_table_attach(self.h, None, 0))
+            self._attached = None
+            return
         nbytes = tensor.numel() * tensor.element_size()
         self._chk(self.L.qs_table_attach(self.h, C.c_void_p(tensor.data_ptr()), nbytes))
         self._attached = tensor
@@ -380,8 +385,11 @@ class QuartetScoreComputer:
         say("Finished counting quartets.")
         ctx = self.quartetCounterLookup.ctx
         # root_as_edge: a degree-2 root as a subdivision of one edge instead of the reference's handling (quirk Q5)
+        # enforceSmallMem (`-s`): the reference's compact table behind the lookups of a degree-2 root's node pairs -- it throws
+        # there (quartet_lookup_table.hpp:79-85), and so does this constructor (QSError, code QS_ERR_REFERENCE_THROWS)
         lq, qp, eqp, bif = ctx.score(self.ref, (QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32) |
-                                     (QS_SCORE_ROOT_AS_EDGE if root_as_edge else 0))
+                                     (QS_SCORE_ROOT_AS_EDGE if root_as_edge else 0) |
+                                     (QS_SCORE_SAVEMEM_LOOKUPS if enforceSmallMem else 0))
         self.bifurcating = bif
         say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
         self._lq, self._qp, self._eqp = lq[1:], (qp[1:] if bif else None), (eqp[1:] if bif else None)

@@ -94,6 +94,8 @@ def reflib():
         R.qsref_lookup_index.argtypes = [C.c_void_p, C.c_int] + [C.c_uint64] * 4
         R.qsref_table_increment.argtypes = [C.c_void_p, C.c_int] + [C.c_uint64] * 4
         R.qsref_table_occurrences.argtypes = [C.c_void_p, C.c_int] + [C.c_uint64] * 4 + [C.c_void_p]
+        R.qsref_table_occurrences_checked.restype = C.c_int
+        R.qsref_table_occurrences_checked.argtypes = [C.c_void_p, C.c_int] + [C.c_uint64] * 4 + [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64]
         _REF = R
     return _REF
 
@@ -157,7 +159,9 @@ class Oracle:
 
     def lookup(self, a, b, c, d):
         out = (C.c_uint64 * 3)()
-        lib().qso_lookup(self._h, a, b, c, d, out)
+        rc = lib().qso_lookup(self._h, a, b, c, d, out)
+        if rc != 0:      # savemem + a repeated id whose sorted index lies behind the table: the reference throws
+            raise OracleError(lib().qso_last_error(self._h).decode())
         return tuple(int(x) for x in out)
 
     def score(self, nthreads=1, qp_exact64=False):

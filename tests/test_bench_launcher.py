@@ -1,0 +1,79 @@
+"""bench.py's multi-GPU launch path: `python bench.py --gpus N` with N > 1 must run by itself -- the parent
+starts ONE fresh `python -m torch.distributed.run` child before anything touches a GPU, relays rank 0's JSON line and the
+child's exit code. CPU tests: the command it builds, the loud failure without GPUs, the relay. The GPU side
+(`--gpus 1 --via-launcher` against the plain N = 1 line) is tests/test_gpu_bench_launcher.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def clean_env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_dry_launch_builds_the_drivers_command():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "7", "--warmup", "3", "--config", "4", "--dry-launch"],
+                       capture_output=True, text=True, env=clean_env(), timeout=300)
+    assert p.returncode == 0, p.stderr
+    doc = json.loads(p.stdout.strip().splitlines()[-1])
+    cmd = doc["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(BENCH)
+    # the child gets this run's own arguments, minus the launcher-only flags
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "7", "--warmup", "3", "--config", "4"]
+    assert doc["n_ranks"] == 2
+
+
+def test_launch_fails_loudly_without_gpus():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this host has the GPUs")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=clean_env(), timeout=300)
+    assert p.returncode != 0
+    assert "needs 2 GPUs" in p.stderr and "nothing was launched" in p.stderr
+    assert '{"metric"' not in p.stdout          # no line, no fallback
+
+
+def test_parent_relays_the_childs_line_and_exit_code(monkeypatch, capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+    line = {"metric": "quartets counted/sec", "value": 1.0, "n_gpus": 2, "config": {}}
+    child = "import sys; print('RCCL banner'); print(%r); sys.exit(%%d)" % json.dumps(line)
+
+    class A:
+        gpus, dry_launch, via_launcher = 2, False, False
+
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 2)
+    monkeypatch.setattr(bench, "child_command", lambda n, argv, port=None: [sys.executable, "-c", child % 0])
+    assert bench.launch(A, ["--gpus", "2"]) == 0
+    out = capsys.readouterr()
+    got = json.loads(out.out.strip().splitlines()[-1])
+    assert got["value"] == 1.0 and got["config"]["launcher"]["ranks"] == 2
+    assert "RCCL banner" in out.err and "RCCL banner" not in out.out      # the JSON line is the only thing on stdout
+    # a failed child: its code comes back, no line is printed, nothing is retried
+    monkeypatch.setattr(bench, "child_command", lambda n, argv, port=None: [sys.executable, "-c", child % 3])
+    assert bench.launch(A, ["--gpus", "2"]) == 3
+    assert '{"metric"' not in capsys.readouterr().out
+    # a child that exits 0 without a line is a failure too
+    monkeypatch.setattr(bench, "child_command", lambda n, argv, port=None: [sys.executable, "-c", "print('nothing')"])
+    assert bench.launch(A, ["--gpus", "2"]) == 1
+
+
+def test_a_rank_refuses_a_world_size_that_contradicts_gpus():
+    env = clean_env()
+    env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr

@@ -407,6 +407,33 @@ def test_cpp_cli_gpus_path_matches_single_gpu(tmp_path, trees, rooted):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("driver", ["single", "gpus", "shards"])
+def test_cli_savemem_with_a_rooted_reference_ends_like_the_reference(tmp_path, driver):
+    """`-s` and a rooted reference tree: the reference's compact table throws std::runtime_error ("id = ..., but
+    quartet_lookup_.size() = ...", quartet_lookup_table.hpp:79-85) during the scoring of the root's node pairs and its run ends
+    without an output file. All three drivers of the CLI end the same way (the text = the committed fixture = the oracle's);
+    without -s the run succeeds, and -s with --root-as-edge too. No note about unreproduced behaviour is printed any more."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "rooted_compact.json")) as f:
+        fx = json.load(f)["rooted24"]
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(fx["ref"] + "\n")
+    e.write_text("\n".join(fx["eval"]) + "\n")
+    extra = {"single": [], "gpus": ["--gpus", "1"], "shards": ["--gpus", "1", "--table-shards", "3"]}[driver]
+    out = tmp_path / "o.nwk"
+    p = run("-r", str(r), "-e", str(e), "-o", str(out), "-s", *extra)
+    assert p.returncode == 1 and not out.exists()
+    assert "ERROR: " + fx["reference_throws"] in p.stderr
+    assert "Finished counting quartets." in p.stdout           # the reference counts first, then dies in the scoring loop
+    ok = tmp_path / "ok.nwk"
+    p = run("-r", str(r), "-e", str(e), "-o", str(ok), *extra)
+    assert p.returncode == 0 and ok.exists() and "NOT reproduced" not in p.stderr and "Note:" not in p.stderr
+    ok2 = tmp_path / "ok2.nwk"
+    p = run("-r", str(r), "-e", str(e), "-o", str(ok2), "-s", "--root-as-edge", *extra)
+    assert p.returncode == 0 and ok2.exists()
+
+
+@pytest.mark.gpu
 def test_insufficient_memory_is_reported_like_the_reference(tmp_path):
     """A count table that does not fit the device: the library reports QS_ERR_OOM with the reference's message
     ("Insufficient memory!", QuartetScoreComputer.hpp:724-745 throws it as a runtime_error) instead of crashing, the

@@ -1,0 +1,48 @@
+"""bench.py through its own spawn path on the GPU box: `--gpus 1 --via-launcher` starts the same fresh
+`python -m torch.distributed.run` child a `--gpus N` run starts (this pytest process stays the grandparent and the bench
+parent never touches the GPU); the rank initialises RCCL, proves its communicator and prints the line the parent relays."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+SMALL = ["--taxa", "192", "--trees", "3000", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-e2e", "--no-score"]
+
+
+def run_bench(extra):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert last.startswith('{"metric"'), p.stdout[-500:]
+    return json.loads(last)
+
+
+def test_via_launcher_reproduces_the_single_gpu_line():
+    plain = run_bench(["--gpus", "1"] + SMALL)
+    spawned = run_bench(["--gpus", "1", "--via-launcher"] + SMALL)
+    assert "collective" not in plain and "launcher" not in plain["config"]
+    col = spawned["collective"]
+    assert col["ranks"] == 1 and col["proof"] == 1 and col["proof_ok"] is True and col["backend"] == "nccl"
+    assert col["comm_init_ms"] > 0 and col["table_collective"] is None          # one rank: no peer to combine a table with
+    assert spawned["config"]["launcher"]["ranks"] == 1
+    for doc in (plain, spawned):
+        assert doc["n_gpus"] == 1 and doc["steps"] == 40 and doc["config"]["parity_tuple_sums_ok"] is True
+        assert doc["config"]["parity_lookup_equals_bruteforce"] is True
+        assert doc["config"]["kernel_ms_source"]       # (steps below 5 ms: the mean over extra bracketed steps; else the last timed step)
+    # same workload, same kernels: the two lines agree (short steps on a shared box: 5 %; configs[2] agrees within 1 %,
+    # profiles/r04_launcher/)
+    assert abs(spawned["ms_per_step"] / plain["ms_per_step"] - 1.0) < 0.05, (plain["ms_per_step"], spawned["ms_per_step"])
+
+
+def test_config4_through_the_launcher_takes_the_table_sharded_path():
+    doc = run_bench(["--gpus", "1", "--via-launcher", "--config", "4", "--taxa", "200", "--trees", "400", "--steps", "5", "--warmup", "1",
+                     "--no-cpu-baseline", "--no-e2e"])
+    assert doc["config"]["table_shard"] is not None and doc["config"]["collective"] is None
+    assert doc["collective"]["ranks"] == 1 and doc["dtype"] == "u16"

@@ -281,7 +281,9 @@ def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, ki
         assert (T.astype(np.uint64) == want).all(), (builder, v)
 
 
-@pytest.mark.parametrize("n,m,bits", [(40, 60, 4), (33, 70, 5), (58, 100, 6), (90, 40, 7)])
+# (132, 34, 8): a ladder of more than 128 LCA levels -- the cooperative kernel carries at most 7 planes, so classes of 8-10 depth
+# bits must take count_bitslice3_kernel over the full launch order even with QS_TUNE_COOP = 1
+@pytest.mark.parametrize("n,m,bits", [(40, 60, 4), (33, 70, 5), (58, 100, 6), (90, 40, 7), (132, 34, 8)])
 @pytest.mark.parametrize("count_bits", [32, 16])
 def test_cooperative_count_kernel_matches_oracle(eng, monkeypatch, n, m, bits, count_bits):
     """count_bitslice4_kernel (binary full batches; the four waves of a workgroup = four consecutive third ids of one
@@ -652,6 +654,39 @@ def test_rooted_reference_matches_the_reference_quirk_D4(eng, golden):
         assert list(got) == v, k
 
 
+@pytest.mark.parametrize("case", ["D4", "rooted9", "rooted24", "rooted41"])
+def test_rooted_reference_compact_mode_matches_oracle(eng, case):
+    """A rooted reference tree in the reference's memory-efficient table mode (`-s` / enforceSmallMem): the reference's
+    lookups for the root's node pairs repeat an id (QuartetScoreComputer.hpp:393-396), its compact table throws
+    std::runtime_error for an index behind the table (quartet_lookup_table.hpp:79-85) and the run ends. The engine reports
+    the same: QS_ERR_REFERENCE_THROWS carrying the what() of the first throwing call -- equal to the committed fixture and
+    to the oracle run live (whose repeated-id arithmetic is pinned on the unmodified header, tests/test_oracle_reftable.py).
+    Without enforceSmallMem the scores are the n^4 table's (test_rooted_reference_random_matches_oracle)."""
+    import json
+    import os
+    from oracle_api import OracleError
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rooted_compact.json")) as f:
+        fx = json.load(f)[case]
+    o = Oracle(fx["ref"])
+    o.count("\n".join(fx["eval"]), savemem=True, cint_bits=16)
+    with pytest.raises(OracleError) as eo:
+        o.score(nthreads=1)
+    assert str(eo.value) == fx["reference_throws"]
+    with pytest.raises(eng.QSError) as eg:
+        eng.QuartetScoreComputer(fx["ref"], fx["eval"], None, False, True)          # (..., verboseOutput, enforceSmallMem)
+    assert eg.value.code == _lib.QS_ERR_REFERENCE_THROWS and str(eg.value).endswith(fx["reference_throws"])
+    # the same inputs without -s: the runtime-efficient table's scores, equal to the oracle's
+    qsc = eng.QuartetScoreComputer(fx["ref"], fx["eval"])
+    o2 = oracle_counts(fx["ref"], fx["eval"])
+    o2.score()
+    want, got = o2.scores_by_bipartition(), qsc.scores_by_bipartition()
+    assert set(got) == set(want)
+    for k in got:
+        assert got[k] == want[k], (sorted(k), got[k], want[k])
+    # -s with --root-as-edge: no repeated ids are looked up, no exception
+    eng.QuartetScoreComputer(fx["ref"], fx["eval"], None, False, True, root_as_edge=True)
+
+
 @pytest.mark.parametrize("n,seed", [(9, 71), (24, 72), (41, 73)])
 def test_rooted_reference_random_matches_oracle(eng, n, seed):
     """Rooted random references (degree-2 root) against the oracle, which follows the reference's link arithmetic;
@@ -963,7 +998,13 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
                          ("single_s2", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 2}),
                          ("single_r4", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_SAMPLE: 4 | 65536}),
                          ("single_noties", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_DEDUPE: 0}),
-                         ("overflow", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 16})):
+                         ("overflow", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 16}),
+                         # capacities that are multiples of the 64-record chunk waves reserve: the log's counter can stop exactly
+                         # AT the capacity while waves that found it full dropped their hits -- a full log must count as an overflow
+                         ("cap64", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 64}),
+                         ("cap128", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 128}),
+                         ("cap256", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 256}),
+                         ("cap1024", {_lib.QS_TUNE_SCORE_PASSES: 2, _lib.QS_TUNE_SCORE_LOG_CAP: 1024})):
         for k_, v_ in tuning.items():
             monkeypatch.setitem(eng.DEFAULT_TUNING, k_, v_)
         ctx = eng.Context(ref.n_taxa, 32)
@@ -977,7 +1018,9 @@ def test_single_read_scoring_equals_two_passes(eng, monkeypatch, kind):
     for mode in ("single_nopre", "single_s2", "single_r4"):
         assert results[mode][4] > 0, mode
     assert results["auto"][4] == 0          # (a table below 1 GB: the automatic mode reads it twice)
-    for mode in ("two", "auto", "overflow", "single_nopre", "single_s2", "single_r4"):
+    for mode in ("cap64", "cap128", "cap256", "cap1024"):     # a log that is used must have had room left
+        assert results[mode][4] < int(mode[3:]), (mode, results[mode][4])
+    for mode in ("two", "auto", "overflow", "single_nopre", "single_s2", "single_r4", "single_noties", "cap64", "cap128", "cap256", "cap1024"):
         for i in range(3):
             assert np.array_equal(results["single"][i], results[mode][i], equal_nan=True), (mode, i)
     qsc_like = results["single"]

@@ -300,3 +300,64 @@ def test_score_plan_covers_every_rank_range_exactly_once():
     buf = np.zeros(8, dtype=np.uint64)
     assert L.qs_score_plan(3, 0, 0, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data) != 0
     assert L.qs_score_plan(8, 0, ranks.n_quartets(8) + 1, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data) != 0
+
+
+# ---- rooted reference tree + the reference's memory-efficient table ---------------------------------
+ROOTED_CASES = [("D4", None, 0)] + [(f"random{n}", n, seed) for n, seed in ((4, 5), (7, 81), (12, 82), (23, 83), (40, 84))]
+
+
+def rooted_case(golden, name, n, seed):
+    if name == "D4":
+        return golden["D4"]["ref"], golden["D1"]["eval"]
+    return synth.random_tree(n, np.random.default_rng(seed), rooted=True), synth.tree_set(n, 12, seed + 100, collapse=0.1)
+
+
+@pytest.mark.parametrize("name,n,seed", ROOTED_CASES)
+def test_rooted_reference_compact_mode_host_logic_matches_oracle(golden, name, n, seed):
+    """`-s` (QS_SCORE_SAVEMEM_LOOKUPS) with a degree-2 reference root. The reference's scoring loop then looks up ids that
+    repeat (QuartetScoreComputer.hpp:393-396), its compact table sorts them and throws std::runtime_error for an index behind
+    the table (quartet_lookup_table.hpp:79-85; pinned on the unmodified header in tests/test_oracle_reftable.py) -- for EVERY
+    rooted reference tree, so the reference's run ends there. The oracle restates that (sequential order, -t 1), and the
+    product's host logic (qs_score_finish, no device involved) must report the same exception text: the first throwing call
+    in the reference's order. Without the flag the same call scores the root's pairs like the n^4 table does."""
+    from oracle_api import OracleError
+    from quartetscores_amd import _lib, engine
+    ref_nw, trees = rooted_case(golden, name, n, seed)
+    eval_text = trees if isinstance(trees, str) else "\n".join(trees)
+    o = Oracle(ref_nw)
+    o.count(eval_text, savemem=True, cint_bits=16)
+    with pytest.raises(OracleError) as eo:
+        o.score(nthreads=1)
+    nq = o.nq
+    m = re.fullmatch(r"id = (\d+), but quartet_lookup_\.size\(\) = (\d+)", str(eo.value))
+    assert m and int(m.group(2)) == nq and int(m.group(1)) >= nq
+    ref = flatten.flatten_reference(ref_nw)
+    P = ((ref.n_nodes - ref.n_taxa) ** 2)
+    sums = np.zeros(3 * P, dtype=np.int64)
+    cand = np.full((1, _lib.QS_SCORE_CAND_SLOTS * P), -1, dtype=np.int64)
+    with pytest.raises(engine.QSError) as eg:
+        engine.score_finish_host(ref, sums, cand, _lib.QS_SCORE_SAVEMEM_LOOKUPS)
+    assert eg.value.code == _lib.QS_ERR_REFERENCE_THROWS
+    assert str(eg.value).endswith(str(eo.value)), (str(eg.value), str(eo.value))
+    # no flag, or the root treated as a point on an edge: no exception (the n^4 table's behaviour / no repeated ids at all)
+    engine.score_finish_host(ref, sums, cand, 0)
+    engine.score_finish_host(ref, sums, cand, _lib.QS_SCORE_SAVEMEM_LOOKUPS | _lib.QS_SCORE_ROOT_AS_EDGE)
+    o.close()
+
+
+def test_compact_mode_flag_changes_nothing_for_an_unrooted_reference(golden):
+    from quartetscores_amd import _lib, engine
+    ref = flatten.flatten_reference(golden["D1"]["ref"])
+    P = ((ref.n_nodes - ref.n_taxa) ** 2)
+    sums = np.arange(3 * P, dtype=np.int64) % 7
+    cand = np.full((1, _lib.QS_SCORE_CAND_SLOTS * P), -1, dtype=np.int64)
+    a = engine.score_finish_host(ref, sums, cand, 0)
+    b = engine.score_finish_host(ref, sums, cand, _lib.QS_SCORE_SAVEMEM_LOOKUPS)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y, equal_nan=True)
+    # and the oracle's savemem mode scores an unrooted reference without throwing
+    o = Oracle(golden["D1"]["ref"])
+    ev = golden["D1"]["eval"]
+    o.count(ev if isinstance(ev, str) else "\n".join(ev), savemem=True, cint_bits=16)
+    o.score()
+    o.close()
