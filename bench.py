@@ -78,6 +78,8 @@ def parse_args():
                     help="ladder: the reference tree is a caterpillar and the evaluation trees are that ladder + Poisson(n/8) NNIs (deep trees: 9 depth bits at 512 taxa)")
     ap.add_argument("--collapse", type=float, default=0.0, help="collapse each internal edge with this probability (multifurcating trees; numpy generator, small sizes)")
     ap.add_argument("--dropout", type=float, default=0.0, help="drop each taxon from a tree with this probability (partial trees; numpy generator, small sizes)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="a third of the trees binary and full, a third with --dropout (default 0.1), a third with --collapse (default 0.2), interleaved")
     ap.add_argument("--reduce", choices=["scatter", "all"], default="scatter",
                     help="N>1: reduce-scatter (each rank keeps and scores a shard of the reduced table) or all-reduce")
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto",
@@ -377,7 +379,7 @@ def main():
     # seeded inputs: seed = 1000 * config + tree-set id. Split configs: ONE set of m_total trees, rank
     # r takes trees [t_lo, t_hi); otherwise rank r counts its own set r (tree t of a set depends only on (seed, t)).
     seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or shards > 1) else rank)
-    binary_full_trees = not (args.collapse or args.dropout)
+    binary_full_trees = not (args.collapse or args.dropout or args.mixed)
     t_gen = time.perf_counter()
     if args.shape == "ladder":
         lad = "(t0,t1)"
@@ -394,7 +396,14 @@ def main():
         batch, _ = native_ingest.ingest_text(ref_nw, all_text, t_lo if split else 0, t_hi if split else m, want_ranges=(args.algo == "scatter"))
         sample_text = all_text
     else:                                   # multifurcating / partial trees: the numpy generator (small sizes only)
-        trees = synth.tree_set(n, m, seed_set, collapse=args.collapse, dropout=args.dropout)
+        if args.mixed:
+            k3 = m // 3
+            sets = [synth.tree_set(n, m - 2 * k3, seed_set), synth.tree_set(n, k3, seed_set + 1, dropout=args.dropout or 0.1),
+                    synth.tree_set(n, k3, seed_set + 2, collapse=args.collapse or 0.2)]
+            trees = [sets[i % 3][i // 3] if i // 3 < len(sets[i % 3]) else None for i in range(3 * len(sets[0]))]
+            trees = [t_ for t_ in trees if t_ is not None]
+        else:
+            trees = synth.tree_set(n, m, seed_set, collapse=args.collapse, dropout=args.dropout)
         batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
         sample_text = "\n".join(trees).encode()
     assert batch.n_trees == m
@@ -791,20 +800,29 @@ def main():
     units_per_launch = m * nq / launches
     launch_ms = count_ms / launches
     import re
-    mode = "binary_full" if "binary_full" in variant else "general_full" if "general_full" in variant else "partial" if "partial" in variant else None
+    # kernel variant: "gather/<mode>/bitslice_b4x2:2358+bitslice_b5x2:7642/count_u32", or classes of several modes:
+    # "gather/mixed/binary_full.bitslice_b4x2:120+binary_partial.bitslice_b5x2:80+..."
+    MODES = ("binary_full", "binary_partial", "general_full", "partial")
+    head = variant.split("/")[1] if variant.count("/") >= 2 else ""
+    mode = head if head in MODES else ("mixed" if head == "mixed" else None)
     # minimal VALU lane-operations per (tree, quartet) of the bit-sliced four-point test, DESIGN.md 3.1:
     #   binary_full: [L > R] and [L < R] over B+1 planes (2 v_bitop3 per plane) + 2 v_bcnt per 32 trees
-    #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 combine + 1 v_bcnt; partial: + 3 presence masks
-    # The batch is counted in depth classes (B = bits of a tree's deepest LCA): "bitslice_b4x2:2358+bitslice_b5x2:7642"
-    def ops_of(bits_):
-        return {"binary_full": 2 * (bits_ + 1) + 2, "general_full": 3 * (bits_ + 1) + 4, "partial": 3 * (bits_ + 1) + 8}[mode]
-    classes = [(int(b_), int(cnt_) if cnt_ else m) for b_, cnt_ in re.findall(r"bitslice_b(\d+)(?:x2)?(?::(\d+))?", variant)]
-    depth_bits = max((b_ for b_, _ in classes), default=None)
+    #   binary_partial: + 2 presence masks + 1 combine (the third topology = what is left of the trees holding all four) + 1 v_bcnt
+    #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 combine + 1 v_bcnt; partial: + 3 presence masks + presence AND
+    # The batch is counted in classes (mode of a tree x bits B of its deepest LCA)
+    def ops_of(bits_, mode_):
+        return {"binary_full": 2 * (bits_ + 1) + 2, "binary_partial": 2 * (bits_ + 1) + 6,
+                "general_full": 3 * (bits_ + 1) + 4, "partial": 3 * (bits_ + 1) + 8}[mode_]
+    POPS = {"binary_full": 2, "binary_partial": 3, "general_full": 3, "partial": 3}
+    classes = []                                     # (bits, trees, mode)
+    for mo_, b_, cnt_ in re.findall(r"(?:(binary_full|binary_partial|general_full|partial)\.)?bitslice_b(\d+)(?:x2)?(?::(\d+))?", variant):
+        classes.append((int(b_), int(cnt_) if cnt_ else m, mo_ or mode))
+    depth_bits = max((b_ for b_, _, _ in classes), default=None)
     ops32 = None
     if classes and "depth_u" not in variant and mode:
-        ops32 = sum(ops_of(b_) * cnt_ for b_, cnt_ in classes) / float(sum(cnt_ for _, cnt_ in classes))
+        ops32 = sum(ops_of(b_, mo_) * cnt_ for b_, cnt_, mo_ in classes) / float(sum(cnt_ for _, cnt_, _ in classes))
     wl_name = (f"configs[{cfg_no}]" if not custom else "custom")
-    workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'ladder' if args.shape == 'ladder' else 'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}")
+    workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'ladder' if args.shape == 'ladder' else 'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}" + ("_mixed" if args.mixed else ""))
     out = {
         "metric": "quartets counted/sec",
         "value": value,
@@ -821,7 +839,7 @@ def main():
         "config": {
             "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " per rank" if world > 1 else "")
                          + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
-                         + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else f", collapse {args.collapse} dropout {args.dropout}")
+                         + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else (", mixed thirds" if args.mixed else "") + f", collapse {args.collapse} dropout {args.dropout}")
                          + f", seeds {seed_ref}/{seed_set}")[:100],
             "quartets": nq_all,
             "quartets_this_rank": nq,
@@ -873,14 +891,13 @@ def main():
         achieved = units_per_launch * ops32 / 32.0 / (launch_ms * 1e-3) / 1e12
         # what the instruction mix itself allows (profiles/r03_valu_yardstick.txt): v_bcnt_u32_b32 issues at half rate, so
         # the minimal chain of a class with B depth bits takes 2 x (ops - pops) + 4 x pops cycles, not 2 x ops
-        pops = {"binary_full": 2, "general_full": 3, "partial": 3}[mode]
-        cyc_min = sum((2 * (ops_of(b_) - pops) + 4 * pops) * cnt_ for b_, cnt_ in classes) / float(sum(cnt_ for _, cnt_ in classes))
+        cyc_min = sum((2 * (ops_of(b_, mo_) - POPS[mo_]) + 4 * POPS[mo_]) * cnt_ for b_, cnt_, mo_ in classes) / float(sum(cnt_ for _, cnt_, _ in classes))
         mix_ceiling = 2.0 * ops32 / cyc_min
         roof = {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLOPS,
                 "issue_model": {"bcnt_half_rate": True, "min_cycles_per_unit32": cyc_min, "mix_ceiling_frac": mix_ceiling,
                                 "frac_of_mix_ceiling": achieved / VALU_PEAK_TLOPS / mix_ceiling, "source": "profiles/r03_valu_yardstick.txt"},
                 "algorithmic_ops_per_unit": ops32 / 32.0,
-                "algorithmic_ops_note": f"{ops32:.3f} wave-instr per (quartet, 32 trees): 2(B+1)+2, classes {classes}"[:100]}
+                "algorithmic_ops_note": f"{ops32:.3f} wave-instr per (quartet, 32 trees), classes (B, trees, mode): {classes}"[:100]}
     else:                                   # scatter / SWAR paths: priced against HBM with SURVEY 8(d)'s bytes
         achieved = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}

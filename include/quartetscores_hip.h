@@ -191,8 +191,10 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_SCORE_LOG_CAP 11u     /* records the candidate log of the single-read scoring may hold (0 = 8 M = 256 MB); tests force overflows */
 #define QS_TUNE_SCORE_SAMPLE 12u      /* single-read scoring: the pre-pass takes one round in S (value = S | 65536; default S = 64) or one 96-byte
                                        * chunk of every row in S (value = S); S a power of two; 0 = no pre-pass (and no automatic mode) */
-#define QS_TUNE_CLASS_PCT 15u         /* batches are counted class by class of depth bits; a class holding less than this share of the trees (and
-                                       * at least 1024 trees otherwise) is merged into the next deeper one: every class costs a table pass (default 10) */
+#define QS_TUNE_CLASS_PCT 15u         /* batches are counted class by class (kernel mode of a tree x its depth bits); a class holding less than this
+                                       * share of the trees, or fewer than QS_TUNE_CLASS_MIN_TREES, joins a more general mode / the next deeper
+                                       * class: every class costs a table pass (default 10) */
+#define QS_TUNE_CLASS_MIN_TREES 16u   /* ... and the absolute floor of a class (default 1024 trees; tests lower it to split small batches) */
 #define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel, shape of the table loads: 0 (default) = every lane loads its own row in 16-byte pieces;
                                        * 2 = ... and requests the next chunk before it processes the current one; 1 = eight lanes load the
                                        * 96-byte chunk of a row together and hand it over through LDS; 3 = 1 with the next chunk requested
@@ -227,6 +229,14 @@ void *qs_table_device_ptr(const qs_ctx *ctx);
 int qs_table_clear(qs_ctx *ctx);
 int qs_table_download(qs_ctx *ctx, void *host_dst, uint64_t bytes);
 int qs_table_upload(qs_ctx *ctx, const void *host_src, uint64_t bytes);
+
+/* dst[i] += src[0][i] + ... + src[n_src-1][i] for i < n_words (32-bit words; u16 cells and the two-cell wire words add as
+ * packed words while the totals stay in range). The sources may be memory of PEER devices that the caller has made
+ * accessible (hipDeviceEnablePeerAccess): the reduce(-scatter) of tree-sharded tables inside ONE process without a
+ * communicator -- GPU g sums chunk g of every peer's table with plain loads over xGMI (the C++ host's `--reduce p2p`;
+ * the reference has no cross-process reduction). 16-byte aligned pointers, at most 15 sources.
+ * Asynchronous on the context's stream; the caller orders it after the peers' counting (events / synchronisation). */
+int qs_sum_words(qs_ctx *ctx, void *dst_device, const void *const *src_device, uint32_t n_src, uint64_t n_words);
 
 /* Writes the u32 table as a u16 table (same [rank][3] layout, 2 bytes per cell, padded to a whole 32-bit word)
  * into caller-owned device memory: the wire format for the multi-GPU all-reduce while all totals stay below 2^16

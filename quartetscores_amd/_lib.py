@@ -18,7 +18,7 @@ QS_SCORE_QP_WRAP32, QS_SCORE_QP_EXACT64, QS_SCORE_ROOT_AS_EDGE, QS_SCORE_SAVEMEM
 QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
-QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD, QS_TUNE_CLASS_PCT = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD, QS_TUNE_CLASS_PCT, QS_TUNE_CLASS_MIN_TREES = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares
@@ -29,6 +29,7 @@ EXPORTS = [
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
     "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
+    "qs_sum_words",
 ]
 
 
@@ -94,6 +95,8 @@ def load():
     L.qs_table_pack32x2.argtypes = [vp, vp, u64]
     L.qs_unpack32x2.restype = i32
     L.qs_unpack32x2.argtypes = [vp, vp, u64, u64, vp]
+    L.qs_sum_words.restype = i32
+    L.qs_sum_words.argtypes = [vp, vp, vp, u32, u64]
     L.qs_table_device_ptr.restype = vp
     L.qs_table_device_ptr.argtypes = [vp]
     L.qs_table_clear.restype = i32

@@ -71,6 +71,9 @@ struct DeviceOptions {
     bool root_as_edge = false;   // QS_SCORE_ROOT_AS_EDGE: a degree-2 root as a subdivision of one edge (not the reference's quirk Q5)
     bool savemem_lookups = false; // QS_SCORE_SAVEMEM_LOOKUPS (the CLI's -s): a rooted reference tree ends the run with the
                                  // std::runtime_error the reference's compact table throws (quartet_lookup_table.hpp:79-85)
+    std::string reduce = "rccl"; // --gpus N: "rccl" (ncclReduceScatter / ncclAllReduce) or "p2p" (peer access, no communicator: multi_gpu.hpp)
+    bool gpus_on_one_device = false; // test hook of --reduce p2p: the N "GPUs" are N contexts on device `device`
+    bool comm_overlap = true;    // --gpus N, rccl: count while ncclCommInitAll runs (false: the first launch waits for the communicators)
     std::string load_table, save_table; // count-table persistence
     bool trace = false;          // --trace: time stamps of the counting pipeline on stderr
 };

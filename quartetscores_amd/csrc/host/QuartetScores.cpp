@@ -48,7 +48,10 @@ void usage(std::ostream &os) {
           "                  ends with the reference's own std::runtime_error, see --root-as-edge)\n"
           "   --device N     HIP device ordinal (default 0)\n"
           "   --gpus N       split the evaluation trees over N GPUs of this node (devices --device .. --device+N-1) and\n"
-          "                  combine the count tables with one RCCL collective over xGMI\n"
+          "                  combine the count tables with one reduction over xGMI\n"
+          "   --reduce R     with --gpus: rccl (default: one RCCL reduce-scatter / all-reduce) | p2p (this one process maps its\n"
+          "                  peers' memory and every GPU sums its chunk with plain loads: no communicator to create)\n"
+          "   --comm-overlap 0|1  with --gpus, rccl: count while the communicators are being created (default 1)\n"
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
           "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
@@ -116,6 +119,13 @@ int parse(int argc, char **argv, Args &a) {
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
         else if (f == "--root-as-edge") a.dev.root_as_edge = true;
+        else if (f == "--reduce") {
+            if (!(v = need(i, "--reduce"))) return 1;
+            a.dev.reduce = v;
+            if (a.dev.reduce != "rccl" && a.dev.reduce != "p2p") { std::cerr << "ERROR: --reduce takes rccl or p2p" << std::endl; return 1; }
+        }
+        else if (f == "--gpus-on-one-device") a.dev.gpus_on_one_device = true;
+        else if (f == "--comm-overlap") { if (!(v = need(i, "--comm-overlap")) || !number(v, "--comm-overlap", num)) return 1; a.dev.comm_overlap = num != 0; }
         else if (f == "--trace") a.dev.trace = true;
         else if (f == "--qic-rank-order") a.raw_rank_order = true;
         else if (f == "--save-table") { if (!(v = need(i, "--save-table"))) return 1; a.dev.save_table = v; }

@@ -5,10 +5,14 @@
 //   1. one host thread + one C-ABI context per GPU; thread g parses, flattens and counts the trees
 //      [g m / N, (g + 1) m / N) into its own full table (the table lives in memory this file allocates, qs_table_attach,
 //      padded to N equal chunks);
-//   2. ONE RCCL collective on the tables over xGMI (single process: ncclCommInitAll + a group call):
+//   2. ONE reduction of the tables over xGMI:
 //        reduce-scatter (default): GPU g ends with tuples [g T, (g + 1) T) of the summed table, half the bytes per link
 //        of an all-reduce, and scores that shard in place (qs_score_set_view);
-//        all-reduce (when the -q dump needs the whole table on one GPU): GPU 0 scores alone (qs_score);
+//        all-reduce / reduce to GPU 0 (when the -q dump needs the whole table on one GPU): GPU 0 scores alone (qs_score);
+//      carried out either by RCCL (`--reduce rccl`, the default: ncclCommInitAll + one group call) or, since this is ONE
+//      process that owns all N devices, by peer access (`--reduce p2p`): GPU g sums chunk g of every peer's table with plain
+//      16-byte loads over its xGMI links (qs_sum_words) -- no communicator, whose creation (1.7-5.6 s) costs more than the
+//      whole count of BASELINE configs[3] on this engine (0.03 s per GPU);
 //   3. sharded scoring: qs_score_pass1 on every GPU, the per-node-pair sums / minima (a few MB) are added / minimised on
 //      the host and the minima handed back, qs_score_pass2 + qs_score_overflow on every GPU, qs_score_finish on the host.
 // u16 tables travel as packed 32-bit words: every total stays below 2^16 (m < 65536 is what selects u16), so no carry
@@ -50,33 +54,40 @@ public:
         : ref_(flatten_reference(refTree)), opt_(opt), bits_(count_bits), full_(need_full_table) {
         int ndev = 0;
         QSM_HIP(hipGetDeviceCount(&ndev));
-        if (n_gpus < 1 || opt.device < 0 || opt.device + n_gpus > ndev)   // the devices used are opt.device .. opt.device + n_gpus - 1
+        if (opt.gpus_on_one_device && opt.reduce != "p2p") throw std::runtime_error("--gpus-on-one-device needs --reduce p2p (RCCL refuses two ranks on one device)");
+        if (n_gpus < 1 || opt.device < 0 || opt.device + (opt.gpus_on_one_device ? 1 : n_gpus) > ndev)   // the devices used are opt.device .. opt.device + n_gpus - 1
             throw std::runtime_error("--gpus " + std::to_string(n_gpus) + " from --device " + std::to_string(opt.device) + ": " + std::to_string(ndev) + " device(s) visible");
         G_ = n_gpus;
         std::cout << "There are " << m << " evaluation trees.\n";
         std::cout << "The reference tree has " << ref_.names.size() << " taxa.\n";
-        std::cout << "Counting on " << G_ << " GPU(s): trees split over the GPUs, one RCCL " << (full_ ? "all-reduce" : "reduce-scatter") << " of the count table.\n";
+        std::cout << "Counting on " << G_ << " GPU(s): trees split over the GPUs, one " << (opt_.reduce == "p2p" ? "peer-access " : "RCCL ") << (full_ ? "all-reduce" : "reduce-scatter") << " of the count table.\n";
         const auto t0 = std::chrono::steady_clock::now();
         ctx_.assign(G_, nullptr);
         table_.assign(G_, nullptr);
         send_.assign(G_, nullptr);
-        // RCCL's communicators take ~2 s to create (ncclCommInitAll). They are created on a helper thread while the GPUs'
-        // host threads create their contexts, allocate the tables and parse their first batch -- but NOT beside the count
-        // kernels: the creation issues many small device operations, each of which queues behind a 100 ms count kernel
-        // (measured: 5.6 s instead of 2.8 s for 512 taxa x 10000 trees with the two overlapped). The workers wait for the
-        // communicators before their first launch.
+        // RCCL's communicators take 1.7-5.6 s to create (ncclCommInitAll), on a helper thread that starts NOW. Nothing but the
+        // collective itself needs them: the GPUs' host threads create their contexts, allocate, parse and COUNT meanwhile
+        // (opt.comm_overlap, the default). Round 3 made the workers wait for the communicators before their first launch,
+        // because the creation's many small device operations queued behind 100 ms count kernels (5.6 s instead of 2.8 s
+        // at 512 taxa x 10000 trees); `--comm-overlap 0` restores that order. `--reduce p2p` creates no communicator at all.
         std::vector<int> devs(G_);
-        for (int g = 0; g < G_; ++g) devs[g] = opt_.device + g;
+        for (int g = 0; g < G_; ++g) devs[g] = dev_of(g);
         comms_.assign(G_, nullptr);
         ncclResult_t comm_rc = ncclSuccess;
         std::promise<void> comm_done;
-        comm_ready_ = comm_done.get_future().share();
-        std::thread comm_init([&] { trace_mark(opt_, "rccl thread: ncclCommInitAll starts"); comm_rc = ncclCommInitAll(comms_.data(), G_, devs.data()); trace_mark(opt_, "rccl thread: communicators ready"); comm_done.set_value(); });
+        const bool use_rccl = opt_.reduce != "p2p";
+        if (use_rccl && !opt_.comm_overlap) comm_ready_ = comm_done.get_future().share();
+        std::thread comm_init;
+        if (use_rccl)
+            comm_init = std::thread([&] { trace_mark(opt_, "rccl thread: ncclCommInitAll starts"); comm_rc = ncclCommInitAll(comms_.data(), G_, devs.data()); trace_mark(opt_, "rccl thread: communicators ready"); comm_done.set_value(); });
         try {
-            try { count(evalTreesPath, m); } catch (...) { comm_init.join(); throw; }
-            comm_init.join();
+            try { count(evalTreesPath, m); } catch (...) { if (comm_init.joinable()) comm_init.join(); throw; }
+            trace_mark(opt_, "main: all GPUs counted");
+            if (comm_init.joinable()) comm_init.join();
+            trace_mark(opt_, use_rccl ? "main: communicators joined" : "main: no communicator (peer access)");
             if (comm_rc != ncclSuccess) { comms_.assign(G_, nullptr); throw std::runtime_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(comm_rc)); }
-            reduce(m);
+            if (use_rccl) reduce(m); else reduce_p2p(m);
+            trace_mark(opt_, "main: tables reduced");
             const auto t1 = std::chrono::steady_clock::now();
             std::cout << "Finished counting quartets.\nIt took: " << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << " microseconds." << std::endl;
             score(refTree);
@@ -109,11 +120,15 @@ private:
     std::atomic<uint32_t> flags_and_{~0u};     // AND of qs_batch_flags over every batch of every GPU
     uint64_t tuples_ = 0, chunk_tuples_ = 0, chunk_words_ = 0;
 
+    // device of "GPU" g. --gpus-on-one-device (a test hook of --reduce p2p): all N contexts, tables and the peer sums live on
+    // ONE device, so that the N-way partition, the chunk arithmetic and qs_sum_words are exercised on a 1-GPU box.
+    int dev_of(int g) const { return opt_.gpus_on_one_device ? opt_.device : opt_.device + g; }
+
     void release() {
         for (auto &cm : comms_) if (cm) { (void)ncclCommDestroy(cm); cm = nullptr; }
         for (int g = 0; g < (int)ctx_.size(); ++g) {
             if (ctx_[g]) qs_destroy(ctx_[g]);
-            (void)hipSetDevice(opt_.device + g);
+            (void)hipSetDevice(dev_of(g));
             if (table_[g]) (void)hipFree(table_[g]);
             if (g < (int)send_.size() && send_[g]) (void)hipFree(send_[g]);
         }
@@ -130,18 +145,25 @@ private:
         // geometry of the padded table: N chunks of T tuples (T even: whole 32-bit words for u16 cells too)
         tuples_ = (uint64_t)n * (n - 1) * (n - 2) * (n - 3) / 24;
         chunk_tuples_ = (tuples_ + G_ - 1) / G_;
-        chunk_tuples_ += chunk_tuples_ & 1;
+        chunk_tuples_ = (chunk_tuples_ + 7) & ~(uint64_t)7;   // chunks start on 16-byte boundaries in every wire format (qs_sum_words)
         chunk_words_ = chunk_tuples_ * 3 * (bits_ / 8) / 4;
         const unsigned host_threads = std::max(1u, (opt_.ingest_threads ? opt_.ingest_threads : std::thread::hardware_concurrency()) / (unsigned)G_);
         auto worker = [&](int g) {
             try {
-                const int dev = opt_.device + g;
+                const int dev = dev_of(g);
                 if (qs_create(&ctx_[g], n, bits_, QS_FLAG_NONE, dev, nullptr, 0, 0) != QS_OK) throw std::runtime_error(qs_last_error(nullptr));
                 QSM_HIP(hipSetDevice(dev));
                 const size_t bytes = (size_t)chunk_words_ * 4 * G_;
                 if (hipMalloc(&table_[g], bytes) != hipSuccess) throw std::runtime_error("Insufficient memory!");
                 QSM_HIP(hipMemset(table_[g], 0, bytes));
                 if (qs_table_attach(ctx_[g], table_[g], bytes) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+                // the two-cell wire words (8 bytes per tuple) are allocated HERE, beside the parse of the first batch, not
+                // between the count and the collective; freed again if the trees turn out not to be binary and full
+                if (!full_ && bits_ == 32 && (opt_.algo & 0xFFu) != QS_ALGO_SCATTER && G_ > 1) {
+                    const size_t sb = (size_t)chunk_tuples_ * 2 * 4 * G_;
+                    if (hipMalloc(&send_[g], sb) == hipSuccess) QSM_HIP(hipMemsetAsync(send_[g], 0, sb, nullptr));   // padding tuples stay zero
+                    else { send_[g] = nullptr; (void)hipGetLastError(); }
+                }
                 const size_t lo = spans.size() * g / G_, hi = spans.size() * (g + 1) / G_;
                 const bool want_ranges = (opt_.algo & 0xFFu) == QS_ALGO_SCATTER;
                 std::vector<qs_device_batch *> in_flight;
@@ -154,7 +176,7 @@ private:
                         hb.node_off = want_ranges ? b.node_off.data() : nullptr; hb.rng_off = want_ranges ? b.rng_off.data() : nullptr;
                         hb.ranges = b.ranges.data();
                         if (in_flight.size() == 2) { qs_batch_free(ctx_[g], in_flight.front()); in_flight.erase(in_flight.begin()); }
-                        if (i0 == lo && comm_ready_.valid()) comm_ready_.wait();   // first launch: not beside RCCL's set-up
+                        if (i0 == lo && comm_ready_.valid()) comm_ready_.wait();   // --comm-overlap 0: first launch not beside RCCL's set-up
                         qs_device_batch *db = nullptr;
                         if (qs_batch_upload(ctx_[g], &hb, &db) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
                         flags_and_.fetch_and(qs_batch_flags(db));
@@ -187,19 +209,13 @@ private:
         const uint32_t both = QS_BATCH_ALL_TAXA | QS_BATCH_BINARY;
         const bool two_cell = !full_ && bits_ == 32 && (flags_and_.load() & both) == both && (opt_.algo & 0xFFu) != QS_ALGO_SCATTER;
         const uint64_t words2 = chunk_tuples_ * 2;                    // wire words per chunk in the two-cell format
-        if (two_cell)
-            for (int g = 0; g < G_; ++g) {
-                QSM_HIP(hipSetDevice(opt_.device + g));
-                if (hipMalloc(&send_[g], (size_t)words2 * 4 * G_) != hipSuccess) throw std::runtime_error("Insufficient memory!");
-                QSM_HIP(hipMemset(send_[g], 0, (size_t)words2 * 4 * G_));     // padding tuples behind the table stay zero
-                if (qs_table_pack32x2(ctx_[g], send_[g], (uint64_t)words2 * 4 * G_) != QS_OK || qs_sync(ctx_[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
-            }
+        pack_two_cell(two_cell, words2);
         bool group_open = false;
         try {
             QSM_NCCL(ncclGroupStart());
             group_open = true;
             for (int g = 0; g < G_; ++g) {
-                QSM_HIP(hipSetDevice(opt_.device + g));
+                QSM_HIP(hipSetDevice(dev_of(g)));
                 uint32_t *buf = (uint32_t *)table_[g];
                 if (full_) QSM_NCCL(ncclAllReduce(buf, buf, chunk_words_ * G_, ncclUint32, ncclSum, comms_[g], nullptr));
                 else if (two_cell) { uint32_t *sb = (uint32_t *)send_[g]; QSM_NCCL(ncclReduceScatter(sb, sb + (size_t)g * words2, words2, ncclUint32, ncclSum, comms_[g], nullptr)); }
@@ -207,23 +223,78 @@ private:
             }
             group_open = false;
             QSM_NCCL(ncclGroupEnd());
-            for (int g = 0; g < G_; ++g) { QSM_HIP(hipSetDevice(opt_.device + g)); QSM_HIP(hipDeviceSynchronize()); }
+            for (int g = 0; g < G_; ++g) { QSM_HIP(hipSetDevice(dev_of(g))); QSM_HIP(hipDeviceSynchronize()); }
         } catch (...) {
             if (group_open) (void)ncclGroupEnd();     // never destroy communicators inside an open group
             throw;
         }
-        if (two_cell) {
-            std::cout << "Wire format: two u32 cells per tuple (binary trees holding all taxa).\n";
-            for (int g = 0; g < G_; ++g) {   // the reduced pairs of GPU g's chunk -> [rank][3] tuples where score() expects its shard
-                QSM_HIP(hipSetDevice(opt_.device + g));
-                const uint64_t lo = std::min<uint64_t>((uint64_t)g * chunk_tuples_, tuples_), cnt = std::min<uint64_t>(lo + chunk_tuples_, tuples_) - lo;
-                char *shard = (char *)table_[g] + (size_t)g * chunk_words_ * 4;
-                if (cnt && (qs_unpack32x2(ctx_[g], (const uint32_t *)send_[g] + (size_t)g * words2, cnt, (uint64_t)m, shard) != QS_OK || qs_sync(ctx_[g]) != QS_OK))
-                    throw std::runtime_error(qs_last_error(ctx_[g]));
-                (void)hipFree(send_[g]); send_[g] = nullptr;
+        unpack_two_cell(two_cell, words2, m);
+        for (int g = 0; g < G_; ++g) (void)qs_set_tuning(ctx_[g], QS_TUNE_TABLE_TREES, (uint64_t)m);   // the reduced table holds all m trees
+    }
+
+    // (n0, n1) of every tuple into the pre-allocated wire words of every GPU: all packs are enqueued, then all are awaited
+    void pack_two_cell(bool two_cell, uint64_t words2) {
+        for (int g = 0; g < G_; ++g) {
+            QSM_HIP(hipSetDevice(dev_of(g)));
+            if (!two_cell) { if (send_[g]) { (void)hipFree(send_[g]); send_[g] = nullptr; } continue; }
+            if (!send_[g]) {
+                if (hipMalloc(&send_[g], (size_t)words2 * 4 * G_) != hipSuccess) throw std::runtime_error("Insufficient memory!");
+                QSM_HIP(hipMemset(send_[g], 0, (size_t)words2 * 4 * G_));
+            }
+            if (qs_table_pack32x2(ctx_[g], send_[g], (uint64_t)words2 * 4 * G_) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+        }
+        if (two_cell) for (int g = 0; g < G_; ++g) if (qs_sync(ctx_[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+    }
+    // the reduced pairs of GPU g's chunk -> [rank][3] tuples where score() expects its shard
+    void unpack_two_cell(bool two_cell, uint64_t words2, size_t m) {
+        if (!two_cell) return;
+        std::cout << "Wire format: two u32 cells per tuple (binary trees holding all taxa).\n";
+        for (int g = 0; g < G_; ++g) {
+            QSM_HIP(hipSetDevice(dev_of(g)));
+            const uint64_t lo = std::min<uint64_t>((uint64_t)g * chunk_tuples_, tuples_), cnt = std::min<uint64_t>(lo + chunk_tuples_, tuples_) - lo;
+            char *shard = (char *)table_[g] + (size_t)g * chunk_words_ * 4;
+            if (cnt && qs_unpack32x2(ctx_[g], (const uint32_t *)send_[g] + (size_t)g * words2, cnt, (uint64_t)m, shard) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+        }
+        for (int g = 0; g < G_; ++g) {
+            if (qs_sync(ctx_[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+            QSM_HIP(hipSetDevice(dev_of(g)));
+            (void)hipFree(send_[g]); send_[g] = nullptr;
+        }
+    }
+
+    // `--reduce p2p`: the same reduction without a communicator. This process owns all N devices, so every GPU maps its
+    // peers' memory (hipDeviceEnablePeerAccess) and sums ITS chunk of every peer's table with plain loads over xGMI
+    // (qs_sum_words: 16 bytes per lane, N - 1 sources): 7 links x their read rate per GPU, each byte crossing one link
+    // once -- the traffic of a reduce-scatter. With -q (full table on GPU 0) GPU 0 sums the whole tables of its peers.
+    void reduce_p2p(size_t m) {
+        const uint32_t both = QS_BATCH_ALL_TAXA | QS_BATCH_BINARY;
+        const bool two_cell = !full_ && bits_ == 32 && G_ > 1 && (flags_and_.load() & both) == both && (opt_.algo & 0xFFu) != QS_ALGO_SCATTER;
+        const uint64_t words2 = chunk_tuples_ * 2;
+        for (int g = 0; g < G_; ++g) {
+            QSM_HIP(hipSetDevice(dev_of(g)));
+            for (int p = 0; p < G_; ++p) {
+                if (p == g || dev_of(p) == dev_of(g)) continue;
+                int can = 0;
+                QSM_HIP(hipDeviceCanAccessPeer(&can, dev_of(g), dev_of(p)));
+                if (!can) throw std::runtime_error("--reduce p2p: device " + std::to_string(dev_of(g)) + " cannot access device " + std::to_string(dev_of(p)) + " (use --reduce rccl)");
+                const hipError_t e = hipDeviceEnablePeerAccess(dev_of(p), 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw std::runtime_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
             }
         }
-        for (int g = 0; g < G_; ++g) (void)qs_set_tuning(ctx_[g], QS_TUNE_TABLE_TREES, (uint64_t)m);   // the reduced table holds all m trees
+        pack_two_cell(two_cell, words2);          // (every GPU's counting has been awaited by its worker: qs_sync)
+        for (int g = 0; g < (full_ ? 1 : G_); ++g) {
+            std::vector<const void *> src;
+            char *dst;
+            uint64_t nw;
+            if (full_) { dst = (char *)table_[0]; nw = chunk_words_ * G_; for (int p = 1; p < G_; ++p) src.push_back(table_[p]); }
+            else if (two_cell) { dst = (char *)send_[g] + (size_t)g * words2 * 4; nw = words2; for (int p = 0; p < G_; ++p) if (p != g) src.push_back((const char *)send_[p] + (size_t)g * words2 * 4); }
+            else { dst = (char *)table_[g] + (size_t)g * chunk_words_ * 4; nw = chunk_words_; for (int p = 0; p < G_; ++p) if (p != g) src.push_back((const char *)table_[p] + (size_t)g * chunk_words_ * 4); }
+            if (qs_sum_words(ctx_[g], dst, src.data(), (uint32_t)src.size(), nw) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+        }
+        for (int g = 0; g < (full_ ? 1 : G_); ++g) if (qs_sync(ctx_[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
+        unpack_two_cell(two_cell, words2, m);
+        for (int g = 0; g < G_; ++g) (void)qs_set_tuning(ctx_[g], QS_TUNE_TABLE_TREES, (uint64_t)m);
     }
 
     void score(Tree const &refTree) {
@@ -242,12 +313,12 @@ private:
             std::vector<int64_t *> d_sums(G_, nullptr), d_min(G_, nullptr), d_cand(G_, nullptr);
             std::vector<int64_t> sums(P * 3, 0), mins(P, INT64_MAX), cand((size_t)G_ * P * QS_SCORE_CAND_SLOTS), extra;
             auto free_all = [&]() {
-                for (int g = 0; g < G_; ++g) { (void)hipSetDevice(opt_.device + g); (void)hipFree(d_sums[g]); (void)hipFree(d_min[g]); (void)hipFree(d_cand[g]); }
+                for (int g = 0; g < G_; ++g) { (void)hipSetDevice(dev_of(g)); (void)hipFree(d_sums[g]); (void)hipFree(d_min[g]); (void)hipFree(d_cand[g]); }
             };
             try {
                 std::vector<int64_t> part_s(P * 3), part_m(P);
                 for (int g = 0; g < G_; ++g) {   // pass 1 on every GPU (asynchronous), on its shard of the reduced table
-                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipSetDevice(dev_of(g)));
                     QSM_HIP(hipMalloc((void **)&d_sums[g], P * 3 * 8)); QSM_HIP(hipMalloc((void **)&d_min[g], P * 8)); QSM_HIP(hipMalloc((void **)&d_cand[g], P * QS_SCORE_CAND_SLOTS * 8));
                     const uint64_t lo = std::min<uint64_t>((uint64_t)g * chunk_tuples_, tuples_), cnt = std::min<uint64_t>(lo + chunk_tuples_, tuples_) - lo;
                     const char *shard = (const char *)table_[g] + (size_t)g * chunk_words_ * 4;
@@ -255,19 +326,19 @@ private:
                     if (qs_score_pass1(ctx_[g], &rt, d_sums[g], d_min[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
                 }
                 for (int g = 0; g < G_; ++g) {   // SUM / MIN over the shards on the host (a few MB)
-                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipSetDevice(dev_of(g)));
                     QSM_HIP(hipMemcpy(part_s.data(), d_sums[g], P * 3 * 8, hipMemcpyDeviceToHost));
                     QSM_HIP(hipMemcpy(part_m.data(), d_min[g], P * 8, hipMemcpyDeviceToHost));
                     for (size_t i = 0; i < P * 3; ++i) sums[i] = (int64_t)((uint64_t)sums[i] + (uint64_t)part_s[i]);
                     for (size_t i = 0; i < P; ++i) mins[i] = std::min(mins[i], part_m[i]);
                 }
                 for (int g = 0; g < G_; ++g) {
-                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipSetDevice(dev_of(g)));
                     QSM_HIP(hipMemcpy(d_min[g], mins.data(), P * 8, hipMemcpyHostToDevice));
                     if (qs_score_pass2(ctx_[g], &rt, d_min[g], d_cand[g]) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));
                 }
                 for (int g = 0; g < G_; ++g) {
-                    QSM_HIP(hipSetDevice(opt_.device + g));
+                    QSM_HIP(hipSetDevice(dev_of(g)));
                     int64_t *list = nullptr;
                     uint64_t k = 0;
                     if (qs_score_overflow(ctx_[g], &rt, d_min[g], d_cand[g], &list, &k) != QS_OK) throw std::runtime_error(qs_last_error(ctx_[g]));

@@ -37,6 +37,7 @@ struct RefHost {
     bool bifurcating = false;
     bool root_deg2 = false;             // rooted Newick: the root has exactly two children
     std::vector<RootPairHost> root_pairs; // the node pairs (root, v) of such a tree, as the reference enumerates them
+    uint32_t root_split = 0;            // ... and the number of taxa under the root's first child: lookup ids [0, root_split)
     uint64_t root_items = 0;
 };
 
@@ -129,6 +130,7 @@ struct qs_ctx {
     size_t score_acc_cap = 0, score_acc_host_cap = 0;
     uint64_t last_score_estimate = 0;            // automatic single-read mode: predicted log records of the last qs_score (sample x S)
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
+    uint32_t tune_class_min = 1024;              // QS_TUNE_CLASS_MIN_TREES
     uint32_t tune_class_pct = 10;                // QS_TUNE_CLASS_PCT: a depth class below this share of the batch's trees is merged into the next one
     uint32_t tune_score_load = 0;                // QS_TUNE_SCORE_LOAD: 0 = a lane loads its row in 16-byte pieces, 1 = eight lanes load a row's chunk (LDS hand-over)
     uint32_t tune_score_dedupe = 1;              // QS_TUNE_SCORE_DEDUPE: the logging pass skips a quartet that repeats its node pair's last logged triple
@@ -362,6 +364,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             if (value >> 17 || (value && (S < 2 || (S & (S - 1))))) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_SAMPLE takes 0 or a power of two in [2, 32768], optionally | 65536 (whole rounds)");
             c->tune_score_sample = (uint32_t)value; return QS_OK;
         }
+        case QS_TUNE_CLASS_MIN_TREES: c->tune_class_min = (uint32_t)std::min<uint64_t>(value, 0xFFFFFFFFull); return QS_OK;
         case QS_TUNE_CLASS_PCT: if (value > 100) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_CLASS_PCT takes 0 .. 100"); c->tune_class_pct = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_LOAD: if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3"); c->tune_score_load = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
@@ -696,6 +699,19 @@ extern "C" int qs_unpack32x2(qs_ctx *c, const void *src_device, uint64_t n_tuple
     return QS_OK;
 }
 
+extern "C" int qs_sum_words(qs_ctx *c, void *dst_device, const void *const *src_device, uint32_t n_src, uint64_t n_words) {
+    if (c) c->log_valid = false;   // (a table may change under a logged pass 1)
+    if (!c || (n_words && n_src && (!dst_device || !src_device))) return fail(c, QS_ERR_ARG, "qs_sum_words: NULL argument");
+    if (n_src > 15) return fail(c, QS_ERR_ARG, "qs_sum_words: at most 15 sources");
+    if ((uintptr_t)dst_device & 15) return fail(c, QS_ERR_ARG, "qs_sum_words: the destination must be 16-byte aligned");
+    for (uint32_t k = 0; k < n_src; ++k)
+        if (!src_device[k] || ((uintptr_t)src_device[k] & 15)) return fail(c, QS_ERR_ARG, "qs_sum_words: sources must be non-NULL and 16-byte aligned");
+    QS_HIP(c, hipSetDevice(c->device));
+    if (c->n_cu == 0) { int v = 0; QS_HIP(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cu = std::max(1, v); }
+    QS_HIP(c, launch_sum_words(c->stream, dst_device, src_device, n_src, n_words, c->n_cu));
+    return QS_OK;   // asynchronous on the context's stream
+}
+
 // ---- batches -----------------------------------------------------------------------------
 
 extern "C" void qs_batch_free(qs_ctx *c, qs_device_batch *b) {
@@ -779,6 +795,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     // Trees are independent: large batches are checked by a few host threads, the first error in tree order wins.
     struct Part { uint32_t max_depth = 0; bool all_full = true, all_binary = true; uint32_t err_tree = 0xFFFFFFFFu; std::string err; };
     std::vector<uint16_t> tree_depth(nt, 0); // deepest LCA of every tree
+    std::vector<uint8_t> tree_mode(nt, 0);   // CountMode of every tree: the cheapest kernel instance that is exact for it
     auto check = [&](uint32_t t0, uint32_t t1, Part &P) {
         std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
         std::vector<uint32_t> stack;
@@ -807,6 +824,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
             }
             const bool binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
             if (!binary) P.all_binary = false;
+            tree_mode[t] = (uint8_t)(L == n ? (binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL) : (binary ? MODE_BINARY_PARTIAL : MODE_PARTIAL));
         }
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -831,40 +849,75 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     d.n_trees = nt;
     d.total_leaves = nt ? hb->leaf_off[nt] : 0;
     d.max_depth = max_depth; d.all_full = all_full && nt > 0; d.all_binary = all_binary && nt > 0;
-    // Depth classes. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B of the deepest LCA of the
-    // trees it is given (2(B+1)+2 instructions, B >= 4), and one deep tree would put the whole batch on its B. Trees are
-    // therefore counted class by class: B = 4 .. 10 (LCA depths below 1024: ladder-like trees of up to ~2000 taxa) and
-    // "deeper" (byte-SWAR kernel, 16-bit depths). A class below the batch's top class that holds fewer than
-    // max(1024, 10 %) of the trees is merged upwards: every class costs at least one more panel slice = one more pass
-    // over the table. (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
+    // Classes = (kernel mode, depth bits) per TREE. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B
+    // of the deepest LCA of the trees it is given (2(B+1)+2 instructions for full binary trees, B >= 4) and with what the
+    // trees may contain: binary trees with missing taxa 2(B+1)+6, multifurcating trees 3(B+1)+4, both 3(B+1)+8 on a tile of
+    // half the size. One deep, one multifurcating or one incomplete tree must not put the whole batch on the dearest
+    // instance (the reference's loop is shape-independent, QuartetCounterLookup.hpp:65-106), so trees are counted class by
+    // class: B = 4 .. 10 (LCA depths below 1024: ladder-like trees of up to ~2000 taxa) and "deeper" (byte-SWAR kernel,
+    // 16-bit depths) within each of the four modes. Every class costs at least one more panel slice = one more pass over
+    // the table, so a class that holds fewer than max(1024, QS_TUNE_CLASS_PCT %) of the trees joins one that is exact for
+    // it: first a whole mode joins a more general mode that is present (binary_full -> binary_partial, general_full or
+    // partial; binary_partial, general_full -> partial), then a depth class joins the next deeper one of its mode.
+    // (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
     std::vector<uint32_t> order_host;
     {
-        constexpr uint32_t top_bits = 10, deep = 11;   // class id = depth bits; `deep` = beyond the bit-sliced instances
+        constexpr uint32_t top_bits = 10, deep = 11;   // depth class id = depth bits; `deep` = beyond the bit-sliced instances
+        constexpr uint32_t kModes = 4, kBits = 12;
         auto cls_of = [&](uint32_t depth) { uint32_t bb = 1; while ((1u << bb) <= depth) ++bb; return bb <= 4 ? 4u : (bb <= top_bits ? bb : deep); };
-        uint32_t cnt[12] = {0}, mx[12] = {0};
+        uint32_t cnt[kModes][kBits] = {{0}}, mx[kModes][kBits] = {{0}};
         std::vector<uint8_t> cls(nt);
-        for (uint32_t t = 0; t < nt; ++t) { cls[t] = (uint8_t)cls_of(tree_depth[t]); cnt[cls[t]]++; mx[cls[t]] = std::max<uint32_t>(mx[cls[t]], tree_depth[t]); }
-        uint32_t remap[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-        const uint32_t small = std::max<uint32_t>(1024, (uint32_t)((uint64_t)nt * c->tune_class_pct / 100));
-        for (uint32_t bb = 4; bb < top_bits; ++bb) {
-            if (cnt[bb] == 0 || cnt[bb] >= small) continue;
-            uint32_t up = bb + 1;
-            while (up <= top_bits && cnt[up] == 0) ++up;
-            if (up > top_bits) continue;               // nothing above it among the bit-sliced classes
-            cnt[up] += cnt[bb]; mx[up] = std::max(mx[up], mx[bb]); cnt[bb] = 0; remap[bb] = up;
+        for (uint32_t t = 0; t < nt; ++t) {
+            cls[t] = (uint8_t)cls_of(tree_depth[t]);
+            cnt[tree_mode[t]][cls[t]]++;
+            mx[tree_mode[t]][cls[t]] = std::max<uint32_t>(mx[tree_mode[t]][cls[t]], tree_depth[t]);
         }
-        auto final_cls = [&](uint32_t k) { while (remap[k] != k) k = remap[k]; return k; };
+        const uint32_t small = std::max<uint32_t>(c->tune_class_min, (uint32_t)((uint64_t)nt * c->tune_class_pct / 100));
+        uint32_t mode_map[kModes] = {0, 1, 2, 3};
+        auto total = [&](uint32_t mo) { uint32_t s_ = 0; for (uint32_t bb = 0; bb < kBits; ++bb) s_ += cnt[mo][bb]; return s_; };
+        auto join_mode = [&](uint32_t from, std::initializer_list<uint32_t> into) {
+            const uint32_t tf = total(from);
+            if (tf == 0 || tf >= small) return;
+            for (uint32_t to : into) {
+                if (total(to) == 0) continue;
+                for (uint32_t bb = 0; bb < kBits; ++bb) { cnt[to][bb] += cnt[from][bb]; mx[to][bb] = std::max(mx[to][bb], mx[from][bb]); cnt[from][bb] = 0; }
+                mode_map[from] = to;
+                return;
+            }
+        };
+        join_mode(MODE_BINARY_FULL, {MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL});
+        join_mode(MODE_BINARY_PARTIAL, {MODE_PARTIAL});
+        join_mode(MODE_GENERAL_FULL, {MODE_PARTIAL});
+        uint32_t remap[kModes][kBits];
+        for (uint32_t mo = 0; mo < kModes; ++mo) {
+            for (uint32_t bb = 0; bb < kBits; ++bb) remap[mo][bb] = bb;
+            for (uint32_t bb = 4; bb < top_bits; ++bb) {
+                if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                uint32_t up = bb + 1;
+                while (up <= top_bits && cnt[mo][up] == 0) ++up;
+                if (up > top_bits) continue;               // nothing above it among the bit-sliced classes of this mode
+                cnt[mo][up] += cnt[mo][bb]; mx[mo][up] = std::max(mx[mo][up], mx[mo][bb]); cnt[mo][bb] = 0; remap[mo][bb] = up;
+            }
+        }
+        auto final_mode = [&](uint32_t mo) { while (mode_map[mo] != mo) mo = mode_map[mo]; return mo; };
+        auto final_cls = [&](uint32_t mo, uint32_t k) { while (remap[mo][k] != k) k = remap[mo][k]; return k; };
         d.n_classes = 0;
-        uint32_t run = 0, start[12] = {0};
-        for (uint32_t k = 4; k <= deep; ++k) {
-            if (cnt[k] == 0) continue;
-            start[k] = run; run += cnt[k];
-            d.class_bits[d.n_classes] = k; d.class_end[d.n_classes] = run; d.class_max_depth[d.n_classes] = mx[k];
-            d.n_classes++;
+        uint32_t run = 0, start[kModes][kBits] = {{0}};
+        // launch order: the dearest instances first? No: by mode, then depth -- binary_full first (its first slice stores
+        // instead of accumulating when the caller asks for QS_COUNT_OVERWRITE; any class may be the first)
+        static const uint32_t mode_seq[kModes] = {MODE_BINARY_FULL, MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL};
+        for (uint32_t mi = 0; mi < kModes; ++mi) {
+            const uint32_t mo = mode_seq[mi];
+            for (uint32_t k = 4; k <= deep; ++k) {
+                if (cnt[mo][k] == 0) continue;
+                start[mo][k] = run; run += cnt[mo][k];
+                d.class_mode[d.n_classes] = mo; d.class_bits[d.n_classes] = k; d.class_end[d.n_classes] = run; d.class_max_depth[d.n_classes] = mx[mo][k];
+                d.n_classes++;
+            }
         }
         if (d.n_classes > 1) {
             order_host.resize(nt);
-            for (uint32_t t = 0; t < nt; ++t) order_host[start[final_cls(cls[t])]++] = t;
+            for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(tree_mode[t]); order_host[start[mo][final_cls(mo, cls[t])]++] = t; }
         }
     }
     // scatter batches: the tree of every inner node, and a bounds check of the leaf ranges (host side, before any copy)
@@ -1009,34 +1062,43 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     c->ev_used = 0;
     if (timed) QS_HIP(c, mark(c, 0));
     if (algo == QS_ALGO_GATHER) {
-        int mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
-        static const char *mode_names[3] = {"binary_full", "general_full", "partial"};
+        static const char *mode_names[4] = {"binary_full", "general_full", "partial", "binary_partial"};
         CountGeometry g;
         g.n = c->n; g.d_lo = std::max(c->d_lo, 3u); g.d_hi = c->d_hi; g.rank_lo = c->rank_lo;
         g.n_dblk = c->n_dblk; g.total_tiles = c->total_tiles; g.dprefix = c->dprefix; g.cprefix = c->cprefix;
-        // One (panel build + count kernel) per slice of every depth class of the batch (classes: qs_batch_upload; slices:
-        // slice_groups). With QS_IMPL_SWAR the whole batch is one class of the byte-SWAR kernel.
+        // One (panel build + count kernel) per slice of every class of the batch (classes = kernel mode x depth bits per TREE:
+        // qs_batch_upload; slices: slice_groups). With QS_IMPL_SWAR the whole batch is one class of the byte-SWAR kernel,
+        // in the mode the batch as a whole needs.
         const uint32_t top_bits = 10u;
-        if (c->tune_gather_impl == QS_IMPL_BITSLICE && d.class_bits[d.n_classes - 1] > top_bits)
-            return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 10 bits");
         const bool all_swar = c->tune_gather_impl == QS_IMPL_SWAR;
+        if (c->tune_gather_impl == QS_IMPL_BITSLICE)
+            for (uint32_t k = 0; k < d.n_classes; ++k)
+                if (d.class_bits[k] > top_bits) return fail(c, QS_ERR_UNSUPPORTED, "QS_IMPL_BITSLICE: tree depth needs more than 10 bits");
         const uint32_t n_cls = all_swar ? 1u : d.n_classes;
-        bool first = true;
+        bool first = true, mixed = false;
+        for (uint32_t k = 1; k < n_cls; ++k) mixed = mixed || d.class_mode[k] != d.class_mode[0];
+        const int batch_mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
         std::string names;
+        bool any_coop = false;
         for (uint32_t k = 0; k < n_cls; ++k) {
             const uint32_t s_lo = (all_swar || k == 0) ? 0u : d.class_end[k - 1], s_hi = all_swar ? d.n_trees : d.class_end[k];
             const uint32_t depth_bits = all_swar ? 11u : d.class_bits[k];   // 11 = beyond the bit-sliced instances
             const uint32_t cls_max_depth = all_swar ? d.max_depth : d.class_max_depth[k];
             const bool use_bitslice = depth_bits <= top_bits;
-            // bit-sliced classes run count_bitslice3_kernel on the compact panel (binary_full: two a-columns per lane)
+            // the byte-SWAR kernel has no binary_partial instance: such trees are exact under its partial mode
+            int mode = all_swar ? batch_mode : (int)d.class_mode[k];
+            if (!use_bitslice && mode == MODE_BINARY_PARTIAL) mode = MODE_PARTIAL;
+            const bool part = mode == MODE_PARTIAL || mode == MODE_BINARY_PARTIAL;           // panel elements carry a presence word
+            const bool bin_tiles = mode == MODE_BINARY_FULL || mode == MODE_BINARY_PARTIAL;  // two a-columns per lane
+            // bit-sliced classes run count_bitslice3_kernel on the compact panel
             int bits = 8;
             uint32_t tpc;            // trees per panel element
             size_t elem_bytes;       // bytes per (pair, element)
-            const uint32_t compact_nw = std::max(depth_bits, 4u) + (mode == MODE_PARTIAL ? 1u : 0u); // words per compact panel element
+            const uint32_t compact_nw = std::max(depth_bits, 4u) + (part ? 1u : 0u); // words per compact panel element
             if (use_bitslice) { tpc = 32; elem_bytes = compact_nw * 4; }
             else {
-                const uint32_t lim8 = mode == MODE_PARTIAL ? kMaxDepthU8Partial : kMaxDepthU8Full;
-                const uint32_t lim16 = mode == MODE_PARTIAL ? kMaxDepthU16Partial : kMaxDepthU16Full;
+                const uint32_t lim8 = part ? kMaxDepthU8Partial : kMaxDepthU8Full;
+                const uint32_t lim16 = part ? kMaxDepthU16Partial : kMaxDepthU16Full;
                 if (cls_max_depth <= lim8) bits = 8;
                 else if (cls_max_depth <= lim16) bits = 16;
                 else return fail(c, QS_ERR_UNSUPPORTED, "qs_count_batch: tree depth " + std::to_string(cls_max_depth) + " exceeds the panel range; re-root the tree at its centre");
@@ -1044,8 +1106,8 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             }
             const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
             const uint32_t n_chunks_total = (s_hi - s_lo + tpc - 1) / tpc;
-            const uint32_t *order = nullptr;   // launch order of the bit-sliced kernel's tiles for this batch's tiling
-            if (use_bitslice) { int rc_o = tile_order(c, mode == MODE_BINARY_FULL ? 0 : 1, &order); if (rc_o != QS_OK) return rc_o; }
+            const uint32_t *order = nullptr;   // launch order of the bit-sliced kernel's tiles for this class's tiling
+            if (use_bitslice) { int rc_o = tile_order(c, bin_tiles ? 0 : 1, &order); if (rc_o != QS_OK) return rc_o; }
             const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, order != nullptr);
             const size_t need = (size_t)chunks_per_slice * chunk_bytes;
             if (need > c->panel_bytes) {
@@ -1060,14 +1122,14 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 DeviceBatch sub = d;
                 sub.slot0 = s_lo + t0;        // slots [slot0, slot0 + nt) of the class-ordered batch
                 sub.n_trees = nt;
-                if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, mode == MODE_PARTIAL, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
-                else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, mode == MODE_PARTIAL, c->panel, nch));
+                if (use_bitslice) QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, part, c->panel, nch, compact_nw, c->tune_panel_kernel == 1));
+                else QS_HIP(c, launch_build_panel(c->stream, sub, c->n, bits, part, c->panel, nch));
                 if (timed) QS_HIP(c, mark(c, 0));
                 if (use_bitslice) {
                     CountGeometry g3 = g;
-                    if (mode == MODE_BINARY_FULL) {
+                    if (bin_tiles) {
                         g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3;
-                        g3.perm_coop = c->perm_coop; g3.n_coop = c->n_coop; g3.perm_rest = c->perm_rest; g3.n_rest = c->n_rest;
+                        if (mode == MODE_BINARY_FULL) { g3.perm_coop = c->perm_coop; g3.n_coop = c->n_coop; g3.perm_rest = c->perm_rest; g3.n_rest = c->n_rest; any_coop = any_coop || c->n_coop; }
                     }
                     else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
                     g3.perm = order;
@@ -1077,14 +1139,16 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 first = false;
                 if (timed) QS_HIP(c, mark(c, 1));
             }
-            // kernel variant of the class; several classes: "a:trees+b:trees"
-            std::string nm = use_bitslice ? "bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (mode == MODE_BINARY_FULL ? "x2" : "")
+            // kernel variant of the class; several classes: "a:trees+b:trees", classes of several modes: "mode.a:trees+..."
+            std::string nm = use_bitslice ? "bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (bin_tiles ? "x2" : "")
                                           : "depth_u" + std::to_string(bits);
+            if (mixed) nm = std::string(mode_names[mode]) + "." + nm;
             if (n_cls > 1) nm += ":" + std::to_string(s_hi - s_lo);
             names += (k ? "+" : "") + nm;
         }
-        c->variant = std::string("gather/") + mode_names[mode] + "/" + names + "/count_u" + std::to_string(c->count_bits);
-        if (mode == MODE_BINARY_FULL && !all_swar && c->n_coop) c->variant += "/coop4";   // tiles with two a-blocks: count_bitslice4_kernel
+        const int one_mode = all_swar ? batch_mode : (int)d.class_mode[0];
+        c->variant = std::string("gather/") + (mixed ? "mixed" : mode_names[(!all_swar && d.class_bits[0] > top_bits && one_mode == MODE_BINARY_PARTIAL) ? (int)MODE_PARTIAL : one_mode]) + "/" + names + "/count_u" + std::to_string(c->count_bits);
+        if (any_coop) c->variant += "/coop4";   // tiles with two a-blocks of binary_full classes: count_bitslice4_kernel
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");
@@ -1274,6 +1338,7 @@ static int build_ref(qs_ctx *c, const qs_ref_tree *ref, RefHost &R) {
         for (uint32_t v = 0; v < N; ++v) if (R.parent[v] >= 0) kids[(uint32_t)R.parent[v]].push_back(v);
         for (auto &k : kids) std::sort(k.begin(), k.end(), [&](uint32_t p_, uint32_t q_) { return lo[p_] < lo[q_]; });
         const uint32_t rx = kids[R.root][0], ry = kids[R.root][1];
+        R.root_split = cnt[rx];
         for (uint32_t v = 0; v < N; ++v) {
             if (v == R.root || R.nchild[v] != 2) continue;
             const bool in_x = lo[v] >= lo[rx] && lo[v] < lo[rx] + cnt[rx];
@@ -1369,6 +1434,7 @@ static void fill_score_device(const qs_ctx *c, const RefHost &R, const uint32_t 
     sd.pair_sums = nullptr; sd.pair_min = nullptr; sd.pair_cand = nullptr; sd.flags = c->dev_flags + 1;
     sd.cand_limit = c->tune_cand_slots; sd.list = nullptr; sd.list_count = nullptr; sd.list_cap = 0; sd.last_trip = nullptr;
     sd.frame = R.bifurcating ? 0 : 1;
+    sd.root_split = (R.bifurcating && R.root_deg2) ? R.root_split : 0u;
     sd.bundle_plo = sd.bundle_pcnt = sd.bundle_rounds = nullptr; sd.n_rounds = 0; sd.sample = 0;
 }
 
@@ -1745,9 +1811,17 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
     const unsigned long long *cand = (const unsigned long long *)cand_host;
     // extra candidates (qs_score_overflow lists, any order): key -> range in a sorted copy
     std::vector<std::array<unsigned long long, 4>> extra;
+    // A record flagged kListSwap / a slot flagged kCandSwap is a quartet the reference evaluates twice for a degree-2 root, the
+    // second time with q2 and q3 exchanged (qs_score.hip root_swapped; QuartetScoreComputer.hpp:393-396,417-454): both orders
+    // enter the minimum. QS_SCORE_ROOT_AS_EDGE does not reproduce the reference's root pairs, hence not this either.
+    const bool both_orders = !root_as_edge;
     if (extra_host && n_extra) {
-        extra.resize(n_extra);
-        memcpy(extra.data(), extra_host, n_extra * 32);
+        extra.reserve(n_extra);
+        for (uint64_t i = 0; i < n_extra; ++i) {
+            const unsigned long long *e = (const unsigned long long *)extra_host + 4 * i;
+            extra.push_back({e[0] & 0xFFFFFFFFull, e[1], e[2], e[3]});
+            if ((e[0] & kListSwap) && both_orders) extra.push_back({e[0] & 0xFFFFFFFFull, e[1], e[3], e[2]});
+        }
         std::sort(extra.begin(), extra.end());
     }
     const double inf = std::numeric_limits<double>::infinity();
@@ -1772,9 +1846,10 @@ extern "C" int qs_score_finish(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags
                     const unsigned long long *cs = cand + ((size_t)part * np + key) * kCand;
                     for (int s = 0; s < kCand && cs[s] != kCandEmpty; ++s) {
                         if (cs[s] == kCandOverflow) continue;   // marker: this pair's full list is in `extra`
-                        const uint64_t q1 = cs[s] >> 42, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
+                        const uint64_t q1 = (cs[s] >> 42) & 0x1FFFFFu, q2 = (cs[s] >> 21) & 0x1FFFFFu, q3 = cs[s] & 0x1FFFFFu;
                         const double v = host_log_score(q1, q2, q3);
                         lqmin = std::min(lqmin, v);
+                        if ((cs[s] & kCandSwap) && both_orders) lqmin = std::min(lqmin, host_log_score(q1, q3, q2));
                         any = true;
                     }
                 }

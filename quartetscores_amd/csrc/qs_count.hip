@@ -39,10 +39,6 @@
 #include <type_traits>
 #include <vector>
 
-#ifndef QS_EXP
-#define QS_EXP 0   // kernel experiments (tools/Makefile: make exp EXP=<bits>); 0 = the product
-#endif
-
 namespace qs {
 
 // ======================================================================================
@@ -847,11 +843,7 @@ uint32_t bitslice3_tiles_for_c(uint32_t c) {
 
 constexpr int kS3RSlots = kDB * 16;            // R elements: slot = d-row * 16 + b-column (0..15)
 constexpr int kS3Row0 = kS3RSlots;             // 16 elements M[x,c] of the a-columns
-#if QS_EXP & 64
-constexpr int kS3Slots = kS3RSlots + 32;       // experiment: 16 dummy slots behind the row for the lanes that load nothing
-#else
 constexpr int kS3Slots = kS3RSlots + 16;       // 144
-#endif
 constexpr uint32_t kS3Inv = 0x80000000u;       // offset beyond any tree group (also after >> 2): the buffer load returns zeros
 
 typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
@@ -888,18 +880,6 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
-#if QS_EXP & 32
-// diagnostic build only (tools/: make exp EXP=33): s_memtime stamps around the step's barrier and around a full drain of
-// the step's panel loads, summed over all waves: [0] waves, [1] cycles in the group loop, [2] at the barrier, [3] in the drain
-__device__ unsigned long long qs_dbg_stamps[8];
-__device__ __forceinline__ unsigned long long qs_stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#endif
 
 // one table tuple = three cells: moved with ONE 12-byte access for u32 cells (global_load/store_dwordx3; a tuple
 // is 4-byte aligned) instead of three 4-byte ones -- the epilogue of a wave is 16 tuples per lane
@@ -921,7 +901,7 @@ template <typename CT> __device__ __forceinline__ void store_tuple(CT *p, uint32
 // (7 depth bits, binary: 8-plane operands in two a-columns; 4 bits, general) take 3 -- a spill means scratch memory
 // Deep trees (8..10 depth bits: ladders of up to ~2000 taxa) carry 9..12-word operands: 2 waves per SIMD.
 // (8 and 9 bits in the binary / general modes: 3 waves -- <= 168 VGPRs and 42-46 KB of LDS per workgroup.)
-template <int B, int MODE> constexpr int bs3_waves() { return (B >= 10 || (B >= 7 && MODE == MODE_PARTIAL)) ? 2 : B >= 8 ? 3 : ((B == 7 && MODE == MODE_BINARY_FULL) || (B == 4 && MODE == MODE_GENERAL_FULL)) ? 3 : QS_BS3_WAVES; }
+template <int B, int MODE> constexpr int bs3_waves() { return (B >= 10 || (B >= 7 && (MODE == MODE_PARTIAL || MODE == MODE_BINARY_PARTIAL))) ? 2 : MODE == MODE_BINARY_PARTIAL ? (B <= 5 ? 4 : 3) : B >= 8 ? 3 : ((B == 7 && MODE == MODE_BINARY_FULL) || (B == 4 && MODE == MODE_GENERAL_FULL)) ? 3 : QS_BS3_WAVES; }
 template <int B, int MODE, typename CT>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(bs3_waves<B, MODE>(), bs3_waves<B, MODE>()))) void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees,
@@ -933,7 +913,12 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                                                                         uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
                                                                         uint32_t xcd_remap, uint32_t *__restrict__ wire,
                                                                         const uint32_t *__restrict__ perm) {
-    constexpr bool BIN = MODE == MODE_BINARY_FULL, PART = MODE == MODE_PARTIAL;
+    // BIN: the two-a-column tiling of batches of BINARY trees (two comparisons decide a quartet); PART: elements carry a
+    // presence word (taxa may be missing). binary_partial = both: the third topology is what is left of the trees that
+    // hold all four taxa, v & ~(gt | lt) -- no third comparison (gene trees: binary, with missing taxa).
+    constexpr bool BIN = MODE == MODE_BINARY_FULL || MODE == MODE_BINARY_PARTIAL;
+    constexpr bool PART = MODE == MODE_PARTIAL || MODE == MODE_BINARY_PARTIAL;
+    constexpr bool BP = MODE == MODE_BINARY_PARTIAL;
     constexpr int NB = B + 1;
     constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
     constexpr int NW = NWP < 4 ? 4 : NWP;
@@ -943,10 +928,6 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     static_assert(B <= kMaxDepthBits && RW <= kBitWords, "at most 10 depth bits (11 planes + presence in 12 words)");
     constexpr int kImg = (HW == 5 || HW == 6) ? 2 * kS3Slots + (kS3Slots * (HW - 4) + 3) / 4 : kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
     __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
-#ifdef QS_LDS_PAD   // occupancy experiments: bytes of LDS nobody uses, so that fewer workgroups fit on a CU
-    __shared__ uint4 lds_pad[QS_LDS_PAD / 16];
-    if (n_groups == 0xFFFFFFFFu) lds_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);
-#endif
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -1024,11 +1005,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     const bool ok0 = dok && bE0 < c, ok1 = dok && two_r && bE1 < c;
     const uint32_t rowd = (uint32_t)binom2(dE);
     const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv;
-#if QS_EXP & 128   // timing-only knock-out (wrong counts): M[c,d] requested by one lane of eight
-    const uint32_t yoff = (dok && r_col == 0) ? (rowd + c) * 16u : kS3Inv;
-#else
     const uint32_t yoff = dok ? (rowd + c) * 16u : kS3Inv;      // M[c,d]: shared by both R elements of the lane
-#endif
     const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
     // the 16 M[x,c] elements are staged by ALL lanes, four copies of each (lane & 15 picks the element; the copies
     // load the same address and store the same value to the same slot). With the store under `if (lane < 16)` the
@@ -1038,26 +1015,20 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     uint32_t xa = 0xFFFFFFFFu;
     if (l16 < 8) xa = blk0 * kTA + l16;
     else if (blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (l16 - 8);
-#if QS_EXP & 64
-    // experiment: only lanes 0..15 request the 16 M[x,c] elements (the others: out-of-range offset, dummy LDS slots)
-    const uint32_t rowoff = (xa < c && lane < 16) ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
-    const uint32_t rowslot = kS3Row0 + l16 + (lane < 16 ? 0u : 16u);
-#else
     const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
     const uint32_t rowslot = kS3Row0 + l16;
-#endif
     const uint32_t ab1off = v1 ? pi1 * 16u : kS3Inv, ab2off = v2 ? pi2 * 16u : kS3Inv;
     const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
     // counters per d slot. Binary: x0/x1 = ab|cd, ac|bd of (a1,b); y0/y1 the same of (a2,b).
     // General / partial: x0/x1/y0 = ab|cd, ac|bd, ad|bc of (a1,b).
-    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB];
+    // binary_partial: z0 / z1 = ad|bc of (a1,b) / (a2,b).
+    uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB], z0[kDB], z1[kDB];
 #pragma unroll
-    for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
+    for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = z0[j] = z1[j] = 0;
 
     auto rsrc_of = [&](uint32_t g) {
-        // QS_EXP & 16 (timing-only knock-out): zero records -> every panel load returns zeros without touching memory
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (QS_EXP & 16) ? 0 : (int)group_bytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (int)group_bytes, 0x00020000);
     };
     // compact panel element -> planes in w[0..B-1], presence (partial) in w[kPres]
     auto gload = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff) {
@@ -1087,9 +1058,6 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         return lload(buf, kS3Row0 + col);
     };
     struct Staged { Planes x0, x1, y, row; };
-#if QS_EXP & 32
-    unsigned long long dbg_bar = 0, dbg_vm = 0;
-#endif
 
     // one 32-tree step: request group g_next into (st, abn1, abn2), count group g from (cur, abc1, abc2), then
     // turn the requested elements into the LDS image `nxt`
@@ -1103,13 +1071,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         // instead of becoming separate requests to the L2, whose number bounds the kernel together with VALU issue
         // (profiles/r02_experiments.md): -5 % at 512 taxa, -9 % with NNI trees, -5 % on a 1024-taxon shard, -1 % at 256;
         // at 128 taxa and below (the panel sits in the L2 anyway) it costs 4-6 %, so the launcher sets bit 1 from 200 on.
-#if QS_EXP & 32
-        const unsigned long long tb0 = qs_stamp();
-#endif
-        if ((xcd_remap & 2u) && !(QS_EXP & 2)) __builtin_amdgcn_s_barrier();
-#if QS_EXP & 32
-        dbg_bar += qs_stamp() - tb0;
-#endif
+        if (xcd_remap & 2u) __builtin_amdgcn_s_barrier();
         Staged st;
         st.x0 = gload(r, x0off);
         st.y = gload(r, yoff);
@@ -1129,11 +1091,21 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
                 if (BIN) {
+                    if (BP) {
+                        const uint32_t v = L1.w[kPres] & Rb.w[kPres];   // a1, b, c, d all present
+                        gt &= v; lt &= v;
+                        popc_acc(lut3<kTT_NOR_AND>(v, gt, lt), z0[j]);   // a binary tree that holds all four resolves the quartet
+                    }
                     popc_acc(gt, x0[j]);
                     popc_acc(lt, x1[j]);
                     if (A2) {
                         uint32_t gt2, lt2;
                         cmp_planes<NB>(L2, Rb, gt2, lt2);
+                        if (BP) {
+                            const uint32_t v2 = L2.w[kPres] & Rb.w[kPres];
+                            gt2 &= v2; lt2 &= v2;
+                            popc_acc(lut3<kTT_NOR_AND>(v2, gt2, lt2), z1[j]);
+                        }
                         popc_acc(gt2, y0[j]);
                         popc_acc(lt2, y1[j]);
                     }
@@ -1150,13 +1122,6 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                 }
             }
         }
-#if QS_EXP & 32
-        {
-            const unsigned long long tv0 = qs_stamp();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dbg_vm += qs_stamp() - tv0;
-        }
-#endif
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
         if (TWO) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
         if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
@@ -1192,9 +1157,6 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     };
     using T_ = std::true_type; using F_ = std::false_type;
     const bool full = jlo == 0 && jhi == (uint32_t)kDB;
-#if QS_EXP & 32
-    const unsigned long long tl0 = qs_stamp();
-#endif
     if (BIN) {
         if (has_a2) { if (full) run(T_{}, T_{}, F_{}); else run(T_{}, F_{}, F_{}); }
         else if (offdiag) run(F_{}, F_{}, F_{});
@@ -1202,20 +1164,12 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     } else {
         if (full) run(F_{}, T_{}, T_{}); else run(F_{}, F_{}, T_{});
     }
-#if QS_EXP & 32
-    if (lane == 0) {
-        atomicAdd(&qs_dbg_stamps[0], 1ull);
-        atomicAdd(&qs_dbg_stamps[1], qs_stamp() - tl0);
-        atomicAdd(&qs_dbg_stamps[2], dbg_bar);
-        atomicAdd(&qs_dbg_stamps[3], dbg_vm);
-    }
-#endif
 
     // rank of {a,b,c,d} = C(d,4) + C(c,3) + C(b,2) + a; along the d slots C(d+1,4) = C(d,4) + C(d,3) etc., so the
     // 64-bit products and divisions are done once per wave instead of once per slot
     uint64_t bd4 = binom4(d0), bd3 = binom3(d0), bd2 = binom2(d0);
     const uint64_t rcb = binom3(c) - rank_lo;
-    if (BIN && wire) {
+    if (MODE == MODE_BINARY_FULL && wire) {
         // Wire output (qs_count_batch with QS_COUNT_WIRE16X2; binary_full batches only): instead of the [rank][3]
         // table the kernel writes ONE word n0 | n1 << 16 per tuple -- the two-cell format the multi-GPU collective
         // moves (n2 = trees - n0 - n1 is restored by qs_unpack16x2). No table write, no pack kernel.
@@ -1247,14 +1201,14 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         if (d < d1 && d > c) {
             if (v1) {
                 const uint64_t idx = (base + pi1) * 3;
-                uint32_t w0 = x0[j], w1 = x1[j], w2 = BIN ? m_trees - x0[j] - x1[j] : y0[j];
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = BP ? z0[j] : BIN ? m_trees - x0[j] - x1[j] : y0[j];
                 if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 store_tuple(table + idx, w0, w1, w2);
             }
             if (BIN && v2) {
                 const uint64_t idx = (base + pi2) * 3;
-                uint32_t w0 = y0[j], w1 = y1[j], w2 = m_trees - y0[j] - y1[j];
+                uint32_t w0 = y0[j], w1 = y1[j], w2 = BP ? z1[j] : m_trees - y0[j] - y1[j];
                 if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 store_tuple(table + idx, w0, w1, w2);
@@ -1376,7 +1330,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = 0;
 
     auto rsrc_of = [&](uint32_t g) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (QS_EXP & 16) ? 0 : (int)group_bytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(P) + (size_t)g * group_bytes), 0, (int)group_bytes, 0x00020000);
     };
     auto put_raw = [&](int bufi, const Planes &sh, const Planes &pv) {
         if (wave < 3) c4_put<NWRAW>(raw_lo[bufi], raw_hi[bufi], wave * kWave + lane, sh);
@@ -1473,13 +1427,6 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     }
 }
 
-#if QS_EXP & 32
-extern "C" int qs_debug_stamps(unsigned long long out[8]) {   // read and reset (diagnostic builds only)
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qs_dbg_stamps), 64) != hipSuccess) return -1;
-    unsigned long long z[8] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(qs_dbg_stamps), z, 64) == hipSuccess ? 0 : -1;
-}
-#endif
 
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g_in, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
@@ -1533,10 +1480,12 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g_in, cons
     if (count_bits == 32) {
         if (mode == MODE_BINARY_FULL) QS_BS3_B(MODE_BINARY_FULL, uint32_t);
         else if (mode == MODE_GENERAL_FULL) QS_BS3_B(MODE_GENERAL_FULL, uint32_t);
+        else if (mode == MODE_BINARY_PARTIAL) QS_BS3_B(MODE_BINARY_PARTIAL, uint32_t);
         else QS_BS3_BP(uint32_t);
     } else {
         if (mode == MODE_BINARY_FULL) QS_BS3_B(MODE_BINARY_FULL, uint16_t);
         else if (mode == MODE_GENERAL_FULL) QS_BS3_B(MODE_GENERAL_FULL, uint16_t);
+        else if (mode == MODE_BINARY_PARTIAL) QS_BS3_B(MODE_BINARY_PARTIAL, uint16_t);
         else QS_BS3_BP(uint16_t);
     }
 #undef QS_BS3_BP
@@ -1708,6 +1657,36 @@ hipError_t launch_unpack16x2(hipStream_t s, const void *src, void *dst_u16, uint
     if (n_tuples == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n_tuples + 255) / 256));
     hipLaunchKernelGGL(unpack16x2_kernel, grid, block, 0, s, (const uint32_t *)src, (uint16_t *)dst_u16, n_tuples, trees, shape_flag);
+    return hipGetLastError();
+}
+
+// dst[i] += src[0][i] + ... + src[n_src-1][i] over 32-bit words: the single-process reduce(-scatter) of the multi-GPU host
+// (`--reduce p2p`): GPU g sums its chunk of every peer's table with plain 16-byte loads over xGMI (the sources are peer
+// device memory, mapped by hipDeviceEnablePeerAccess), no communicator. Grid-stride; every load is read once: non-temporal.
+constexpr int kSumMaxSrc = 15;
+struct SumSources { const uint32_t *p[kSumMaxSrc]; };
+__global__ __launch_bounds__(256) void sum_words_kernel(uint32_t *__restrict__ dst, SumSources src, uint32_t n_src, uint64_t n_words) {
+    const uint64_t n4 = n_words / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        qs_u32x4 acc = reinterpret_cast<const qs_u32x4 *>(dst)[i];
+        for (uint32_t k = 0; k < n_src; ++k) acc += __builtin_nontemporal_load(reinterpret_cast<const qs_u32x4 *>(src.p[k]) + i);
+        reinterpret_cast<qs_u32x4 *>(dst)[i] = acc;
+    }
+    const uint64_t t = 4 * n4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // the last n_words % 4 words
+    if (t < n_words) {
+        uint32_t acc = dst[t];
+        for (uint32_t k = 0; k < n_src; ++k) acc += src.p[k][t];
+        dst[t] = acc;
+    }
+}
+hipError_t launch_sum_words(hipStream_t s, void *dst, const void *const *src, uint32_t n_src, uint64_t n_words, int n_cu) {
+    if (n_words == 0 || n_src == 0) return hipSuccess;
+    if (n_src > (uint32_t)kSumMaxSrc) return hipErrorInvalidValue;
+    SumSources ss;
+    for (uint32_t k = 0; k < (uint32_t)kSumMaxSrc; ++k) ss.p[k] = k < n_src ? (const uint32_t *)src[k] : nullptr;
+    const uint64_t want = (n_words / 4 + 255) / 256;
+    dim3 block(256), grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)std::max(n_cu, 1) * 16)));
+    hipLaunchKernelGGL(sum_words_kernel, grid, block, 0, s, (uint32_t *)dst, ss, n_src, n_words);
     return hipGetLastError();
 }
 

@@ -12,7 +12,9 @@ enum PanelBits { PANEL_U8 = 8, PANEL_U16 = 16 };
 enum CountMode {
     MODE_BINARY_FULL = 0,  // every tree fully resolved and holding all n taxa: n2 = m - n0 - n1
     MODE_GENERAL_FULL = 1, // multifurcations possible, all taxa present
-    MODE_PARTIAL = 2       // taxa may be missing (flag bit in the panel)
+    MODE_PARTIAL = 2,      // taxa may be missing (flag bit in the panel), multifurcations possible
+    MODE_BINARY_PARTIAL = 3 // every tree fully resolved, taxa may be missing (gene trees): n2 = (trees holding all four) - n0 - n1;
+                            // bit-sliced kernel only (the byte-SWAR kernel takes such trees as MODE_PARTIAL)
 };
 
 // depth limits of the SWAR comparison (see qs_count.hip)
@@ -31,14 +33,17 @@ struct DeviceBatch {
     uint32_t max_depth = 0;
     bool all_full = false;
     bool all_binary = false;
-    // Trees are counted class by class (classes = bits of the deepest LCA of a tree, so that shallow trees run the
-    // cheaper kernel instances): slot s of the class-ordered batch is tree tree_order[s]; class k holds the slots
-    // [class_end[k-1], class_end[k]) and needs class_bits[k] depth bits (> 10: byte-SWAR kernel). A sub-batch for the
-    // panel builders = slots [slot0, slot0 + n_trees).
+    // Trees are counted class by class. A class = (kernel mode of the tree -- binary / multifurcating x all taxa / missing
+    // taxa --, bits of its deepest LCA), so that every tree runs the cheapest kernel instance that is exact for it: the
+    // full binary trees of a batch keep the binary_full instance whatever else the batch holds. Slot s of the class-ordered
+    // batch is tree tree_order[s]; class k holds the slots [class_end[k-1], class_end[k]), runs mode class_mode[k] and
+    // needs class_bits[k] depth bits (> 10: byte-SWAR kernel). A sub-batch for the panel builders = slots
+    // [slot0, slot0 + n_trees).
     uint32_t *tree_order = nullptr; // device, n_trees entries, or NULL = identity
     uint32_t slot0 = 0;
     uint32_t n_classes = 0;
-    uint32_t class_bits[8] = {0}, class_end[8] = {0}, class_max_depth[8] = {0};
+    static constexpr uint32_t kMaxClasses = 32;   // 4 modes x 8 depth classes
+    uint32_t class_bits[kMaxClasses] = {0}, class_end[kMaxClasses] = {0}, class_max_depth[kMaxClasses] = {0}, class_mode[kMaxClasses] = {0};
     uint32_t *leaf_off = nullptr;  // device
     uint16_t *leaf_ids = nullptr;  // device
     uint16_t *adj_depth = nullptr; // device
@@ -87,6 +92,7 @@ hipError_t launch_pack16x2(hipStream_t s, const void *table_u32, void *dst, uint
 hipError_t launch_unpack16x2(hipStream_t s, const void *src, void *dst_u16, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
 hipError_t launch_pack32x2(hipStream_t s, const void *table_u32, void *dst, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
 hipError_t launch_unpack32x2(hipStream_t s, const void *src, void *dst_u32, uint64_t n_tuples, uint32_t trees, uint32_t *shape_flag);
+hipError_t launch_sum_words(hipStream_t s, void *dst, const void *const *src, uint32_t n_src, uint64_t n_words, int n_cu); // dst += sum of (peer) sources
 hipError_t launch_lookup(hipStream_t s, uint32_t n, uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, const void *table,
                          int count_bits, uint64_t nq, const uint16_t *abcd_dev, uint64_t *out_dev);
 size_t gather_lds_bytes(uint32_t d_hi);
@@ -121,12 +127,16 @@ struct ScoreDevice {
     uint32_t coop_load;            // bundle kernel: 1 = a row's 96-byte chunk is loaded by eight lanes and handed over through LDS (QS_TUNE_SCORE_LOAD)
     uint32_t sample;               // pass 1, bundle kernel: 0 = every chunk; else the minima-only pre-pass of the single-read scoring:
                                    //    bits 0..15 = S (a power of two): one chunk (bit 16 clear) or one round (bit 16 set) in S
+    uint32_t root_split;           // bifurcating reference with a degree-2 root: ids [0, root_split) lie under the root's first child (else 0);
+                                   //    marks the quartets the reference evaluates in both (q2, q3) orders (qs_score.hip root_swapped)
     int frame;                     // 0: node-pair frame of processNodePair (QSC:417-431); 1: the (u,z|v,w) argument
                                    //    order of the multifurcating / raw-QIC loops (QSC:551-558, 661-668)
 };
 constexpr int kCand = 8;
 constexpr unsigned long long kCandEmpty = ~0ull;
 constexpr unsigned long long kCandOverflow = ~0ull - 1; // in the LAST slot of a node pair: its slots did not suffice (qs_score_overflow)
+constexpr unsigned long long kCandSwap = 1ull << 63;    // candidate slot flag: the reference also evaluates log_score(q1, q3, q2) for it (degree-2 root)
+constexpr unsigned long long kListSwap = 1ull << 32;    // the same flag in the key word of a (key, q1, q2, q3) record (candidate log, overflow lists)
 uint32_t score_scan_max_lds_log(bool coop_load = false);
 // kernel: 0 = bundle kernel (a wave walks 64 rows with the same b in lockstep; needs sd.bundle_* = plan_bundles of the
 // rank range, and the partial rows at its ends, which go through the scan kernel), 1 = scan kernel (lane = 8 consecutive ranks)

@@ -213,8 +213,24 @@ __device__ __forceinline__ uint32_t gcd_u32(uint32_t x, uint32_t y) {
     }
     return x << sh;
 }
+// Reference tree with a degree-2 root (sd.root_split = k > 0: the lookup ids [0, k) lie under the root's first child): for
+// the node pairs (root, v) the reference's processNodePair also walks quartets it does not own (S2 = v's whole side,
+// QuartetScoreComputer.hpp:393-396) and takes std::min of THEIR log_score into the same path edges (:448-454). For a leaf
+// x alone on one side of the root and three leaves on the other, two of them (c', d') under the two children of v and the
+// third (b') outside v's subtree, that second evaluation is countQuartetOccurrences(x, b', c', d'); the owning pair
+// (lca(b', v), v) evaluates (b', x, c', d') when b' follows v's subtree in the leaf order -- the same counts with q2 and q3
+// exchanged, a log_score that can differ in the last bits (the sum p1 log p1 + p2 log p2 + p3 log p3 is taken in that
+// order, :141-156), and the reference keeps the smaller. In sorted ids a < b < c < d that is exactly:
+//   a alone on the first side  (a < k <= b) with the three others shaped (b,c)|d  <=>  reference topology ad|bc, or
+//   d alone on the second side (c < k <= d) with the three others shaped (a,b)|c  <=>  reference topology ab|cd.
+// Such a quartet's candidate carries kCandSwap and qs_score_finish evaluates both orders.
+__device__ __forceinline__ bool root_swapped(const ScoreDevice &sd, uint32_t code, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t k = sd.root_split;
+    return k != 0 && ((code == 1 && a < k && b >= k) || (code == 0 && c < k && d >= k));
+}
 // pass 2: record the gcd-reduced triple of a near-minimal quartet (log_score(k q) is bit-identical to log_score(q))
-__device__ __noinline__ void scan_candidate(const ScoreDevice &sd, uint32_t key, uint32_t q1, uint32_t q2, uint32_t q3) {
+// swp (bit 63 of the slot, kCandSwap): the reference evaluates this quartet a second time with q2 and q3 exchanged (root_swapped below)
+__device__ __noinline__ void scan_candidate(const ScoreDevice &sd, uint32_t key, uint32_t q1, uint32_t q2, uint32_t q3, bool swp = false) {
     uint32_t g = gcd_u32(gcd_u32(q1, q2), q3);
     if (g == 0) g = 1;
     const uint32_t a = q1 / g, b = q2 / g, c = q3 / g;
@@ -224,7 +240,12 @@ __device__ __noinline__ void scan_candidate(const ScoreDevice &sd, uint32_t key,
         __hip_atomic_store(&slots[kCand - 1], kCandOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c;
+    const unsigned long long packed = ((unsigned long long)a << 42) | ((unsigned long long)b << 21) | c | (swp ? kCandSwap : 0ull);
+    if (packed >= kCandOverflow) {   // (a flagged triple of counts 2^21 - 1 would read as a marker: finished by qs_score_overflow)
+        atomicOr(&sd.flags[0], 2u);
+        __hip_atomic_store(&slots[kCand - 1], kCandOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     // cheap pre-check avoids hammering CAS when thousands of quartets share one triple
     for (uint32_t s = 0; s < sd.cand_limit; ++s) {
         unsigned long long cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -277,6 +298,7 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
             uint32_t a = st.a, b = st.b, c = st.c, d = st.d;
             uint32_t e12 = sd.ref_lca[(size_t)c * sd.n + b], e23 = sd.ref_lca[(size_t)d * sd.n + c];
             ScanSeg seg = scan_classify(sd, a, b, e12, e23);
+            bool swp = PASS >= 2 && root_swapped(sd, seg.code, a, b, c, d);
             unsigned long long s1 = 0, s2 = 0, s3 = 0;
             long long mn = kSortableMax;
             double thr = 0.0;
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
                         e12 = sd.ref_lca[(size_t)c * sd.n + b]; e23 = sd.ref_lca[(size_t)d * sd.n + c];
                     }
                     seg = scan_classify(sd, a, b, e12, e23);
+                    swp = PASS >= 2 && root_swapped(sd, seg.code, a, b, c, d);
                     s1 = s2 = s3 = 0; mn = kSortableMax;
                     if (PASS >= 2 && seg.code != 3) thr = sortable_to_f64(sd.pair_min[seg.key]) + tol;
                     if (PASS == 3) marked = seg.code != 3 && sd.pair_cand[(size_t)seg.key * kCand + kCand - 1] == kCandOverflow;
@@ -311,12 +334,12 @@ __global__ __launch_bounds__(kSThreads) void score_scan_kernel(ScoreDevice sd, u
                         s1 += q1; s2 += q2; s3 += q3;
                         const long long sq = f64_to_sortable(qic);
                         mn = sq < mn ? sq : mn;
-                    } else if (PASS == 2) { if (qic <= thr) scan_candidate(sd, seg.key, q1, q2, q3); }
+                    } else if (PASS == 2) { if (qic <= thr) scan_candidate(sd, seg.key, q1, q2, q3, swp); }
                     else if (marked && qic <= thr) {   // pass 3: (key, q1, q2, q3) of every near-minimal quartet of a marked pair
                         const unsigned long long at = atomicAdd(sd.list_count, 1ull);
                         if (at < sd.list_cap) {
                             unsigned long long *e = sd.list + at * 4;
-                            e[0] = seg.key; e[1] = q1; e[2] = q2; e[3] = q3;
+                            e[0] = seg.key | (swp ? kListSwap : 0ull); e[1] = q1; e[2] = q2; e[3] = q3;
                         }
                     }
                 }
@@ -515,7 +538,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             constexpr int CH = sizeof(CT) == 2 ? QS_BUNDLE_CH16 : QS_BUNDLE_CH;   // tuples a lane requests at once: 96 bytes of its row, back to back, so that
             uint32_t q[CH][3];                      // the requests for one cache line meet in the L1 while it is still pending
             uint32_t key = kKeyEmpty, code = 3;
-            bool first_is_n0 = true;
+            bool first_is_n0 = true, swp = false;
             unsigned long long S0 = 0, S1 = 0, S2 = 0;
             double mn = kHuge, thr = -kHuge;
             uint32_t h0 = 0, h1 = 0, h2 = 0;        // pass 2 / logging pass 1: the lane's previous near-minimal tuple in this run
@@ -642,6 +665,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                 hprev = false;
                             }
                             key = nkey; code = ncode; first_is_n0 = ncode == 0;
+                            swp = (PASS == 2 || logging) && root_swapped(sd, ncode, a, b, c, d);   // (constant along a run: a crossing of the root split is a change of lca(a,b))
                         }
                         const uint32_t n0 = q[u][0], n1 = q[u][1], n2 = q[u][2];
                         const double qic = bundle_qic(t1, sd, qc, n0, n1, n2, first_is_n0);
@@ -667,7 +691,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                             uint32_t q1, q2, q3;
                                             permute_counts(code, n0, n1, n2, q1, q2, q3);
                                             // (three counts below 2^21 pack without loss; anything larger is simply never filtered: all ones)
-                                            packed = ((q1 | q2 | q3) >> 21) ? ~0ull : ((unsigned long long)q1 << 42) | ((unsigned long long)q2 << 21) | q3;
+                                            packed = ((q1 | q2 | q3) >> 21) ? ~0ull : ((unsigned long long)q1 << 42) | ((unsigned long long)q2 << 21) | q3 | (swp ? kCandSwap : 0ull);
                                             if (packed != ~0ull && sd.last_trip[key] == packed) hit = false;
                                         }
                                     }
@@ -696,7 +720,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                             uint32_t q1, q2, q3;
                                             permute_counts(code, n0, n1, n2, q1, q2, q3);
                                             unsigned long long *rec = sd.list + 4 * (wbase + (unsigned long long)__builtin_popcountll(hits & ((1ull << lane) - 1ull)));
-                                            rec[0] = key; rec[1] = q1; rec[2] = q2; rec[3] = q3;
+                                            rec[0] = key | (swp ? kListSwap : 0ull); rec[1] = q1; rec[2] = q2; rec[3] = q3;
                                             if (sd.last_trip != nullptr) sd.last_trip[key] = packed;
                                         }
                                         wbase += cnt; wleft -= cnt;
@@ -714,7 +738,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                                 if (hit) {
                                     uint32_t q1, q2, q3;
                                     permute_counts(code, n0, n1, n2, q1, q2, q3);
-                                    scan_candidate(sd, key, q1, q2, q3);
+                                    scan_candidate(sd, key, q1, q2, q3, swp);
                                 }
                             }
                             if (near) { h0 = n0; h1 = n1; h2 = n2; }
@@ -870,9 +894,10 @@ __global__ __launch_bounds__(256) void score_log_kernel(ScoreDevice sd, double t
     const unsigned long long *rec = sd.list + 4 * i;
     const uint32_t key = (uint32_t)rec[0], q1 = (uint32_t)rec[1], q2 = (uint32_t)rec[2], q3 = (uint32_t)rec[3];
     if (key >= sd.n_inner * sd.n_inner) return;         // (never logged; a guard in front of the indexed reads)
+    const bool swp = (rec[0] & kListSwap) != 0;         // root_swapped: the reference evaluates it in both orders
     const double mag = bundle_qic_slow(sd.logk, sd.tbl_n, q1, q2, q3);
     const double qic = q1 != max(max(q1, q2), q3) ? -mag : mag;
-    if (qic <= sortable_to_f64(sd.pair_min[key]) + tol) scan_candidate(sd, key, q1, q2, q3);
+    if (qic <= sortable_to_f64(sd.pair_min[key]) + tol) scan_candidate(sd, key, q1, q2, q3, swp);
 }
 hipError_t launch_score_log(hipStream_t s, const ScoreDevice &sd, double tol, unsigned long long n_rec) {
     if (n_rec == 0) return hipSuccess;

@@ -97,6 +97,13 @@ class Context:
         self._chk(self.L.qs_table_attach(self.h, C.c_void_p(tensor.data_ptr()), nbytes))
         self._attached = tensor
 
+    def sum_words(self, dst, sources):
+        """qs_sum_words: dst += sum of the source tensors, as 32-bit words (torch CUDA tensors of equal size; the sources may
+        live on peer devices this process has enabled access to); asynchronous."""
+        n = dst.numel() * dst.element_size() // 4
+        arr = (C.c_void_p * len(sources))(*[s_.data_ptr() for s_ in sources])
+        self._chk(self.L.qs_sum_words(self.h, C.c_void_p(dst.data_ptr()), arr, len(sources), n))
+
     def table_pack16(self, tensor):
         """u32 table -> u16 table in `tensor` (torch CUDA tensor, >= ceil(cells/2)*4 bytes); asynchronous."""
         self._chk(self.L.qs_table_pack16(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()))

@@ -434,6 +434,44 @@ def test_cli_savemem_with_a_rooted_reference_ends_like_the_reference(tmp_path, d
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("trees,kind", [(300, "binary"), (70000, "binary"), (200, "mixed")])
+def test_cpp_cli_peer_access_reduce_matches_single_gpu(tmp_path, trees, kind):
+    """`QuartetScores --gpus N --reduce p2p`: the tree-sharded tables are reduced without a communicator -- every GPU sums
+    its chunk of every peer's table with plain loads (qs_sum_words over peer-mapped memory). On a 1-GPU box the N-way
+    partition runs as N contexts on one device (--gpus-on-one-device): 3 "GPUs", reduce-scatter of the three-cell u16 table
+    (300 trees), the two-cell u32 wire words (70000 binary full trees) and a table of mixed trees; with -q the reduce to GPU 0
+    (the whole table on one device). Output byte-identical to the single-GPU CLI."""
+    import numpy as np
+    from quartetscores_amd import native_ingest, synth
+    n = 15
+    ref_nw = synth.random_tree(n, np.random.default_rng(911))
+    if kind == "binary":
+        text = native_ingest.synth_trees(n, trees, 912)
+    else:
+        text = ("\n".join(synth.tree_set(n, trees // 2, 913, collapse=0.2, dropout=0.1) + synth.tree_set(n, trees - trees // 2, 914)) + "\n").encode()
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_bytes(text)
+    o1, q1 = tmp_path / "o1.nwk", tmp_path / "q1.txt"
+    p = run("-r", str(r), "-e", str(e), "-o", str(o1), "-q", str(q1))
+    assert p.returncode == 0, p.stderr
+    for gpus in ("1", "3"):
+        o2 = tmp_path / f"o2_{gpus}.nwk"
+        p = run("-r", str(r), "-e", str(e), "-o", str(o2), "--gpus", gpus, "--reduce", "p2p", "--gpus-on-one-device")
+        assert p.returncode == 0, p.stderr
+        assert "peer-access reduce-scatter" in p.stdout and o2.read_text() == o1.read_text(), gpus
+        if kind == "binary" and trees >= 65536 and gpus == "3":
+            assert "two u32 cells per tuple" in p.stdout
+        o3, q3 = tmp_path / f"o3_{gpus}.nwk", tmp_path / f"q3_{gpus}.txt"
+        p = run("-r", str(r), "-e", str(e), "-o", str(o3), "--gpus", gpus, "--reduce", "p2p", "--gpus-on-one-device", "-q", str(q3))
+        assert p.returncode == 0, p.stderr
+        assert "peer-access all-reduce" in p.stdout and o3.read_text() == o1.read_text() and q3.read_text() == q1.read_text(), gpus
+    # RCCL refuses two ranks on one device: the test hook says so instead of hanging
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "o4.nwk"), "--gpus", "2", "--gpus-on-one-device")
+    assert p.returncode == 1 and "needs --reduce p2p" in p.stderr
+
+
+@pytest.mark.gpu
 def test_insufficient_memory_is_reported_like_the_reference(tmp_path):
     """A count table that does not fit the device: the library reports QS_ERR_OOM with the reference's message
     ("Insufficient memory!", QuartetScoreComputer.hpp:724-745 throws it as a runtime_error) instead of crashing, the

@@ -60,6 +60,8 @@ CASES = [
     (20, 60, 0.3, 0.3, False, 5, "partial"),          # taxon dropout + collapsed edges (fixture F2)
     (12, 17, 0.5, 0.0, True, 6, "partial"),
     (64, 40, 0.0, 0.0, False, 7, "binary_full"),
+    (26, 45, 0.2, 0.0, False, 8, "binary_partial"),   # gene trees: binary, taxa missing (two comparisons + presence, two a-columns)
+    (41, 70, 0.05, 0.0, True, 9, "binary_partial"),   # few taxa missing: the handful of full trees join the class
 ]
 
 
@@ -77,7 +79,8 @@ def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, root
     ref = flatten.flatten_reference(ref_nw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
     ctx, T = gpu_table(eng, ref, batch, count_bits)
-    assert variant in ctx.last_count_variant(), ctx.last_count_variant()
+    # (the byte-SWAR kernel has no binary_partial instance: it counts such batches in its partial mode)
+    assert (variant if impl == "bitslice" else variant.replace("binary_partial", "/partial/")) in ctx.last_count_variant(), ctx.last_count_variant()
     assert ("bitslice" in ctx.last_count_variant()) == (impl == "bitslice")
     o = oracle_counts(ref_nw, trees)
     assert o.names == ref.names
@@ -85,7 +88,7 @@ def test_gather_counts_bit_exact(eng, monkeypatch, n, m, dropout, collapse, root
     assert ctx.trees_counted == m
 
 
-@pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES[:6])
+@pytest.mark.parametrize("n,m,dropout,collapse,rooted,seed,variant", CASES[:6] + CASES[7:8])
 def test_scatter_counts_bit_exact(eng, n, m, dropout, collapse, rooted, seed, variant):
     ref_nw, trees = make_case(n, m, seed, dropout=dropout, collapse=collapse, rooted=rooted)
     ref = flatten.flatten_reference(ref_nw)
@@ -236,6 +239,74 @@ def test_depth_classes_are_counted_separately(eng, kind):
         assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all(), (kind, algo_split)
 
 
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_mixed_batches_are_counted_mode_by_mode(eng, monkeypatch, count_bits):
+    """The kernel mode is a property of the TREE, not of the batch: a batch of one third full binary trees,
+    one third binary trees with missing taxa and one third trees with collapsed edges (some of those with missing taxa too),
+    interleaved, with two deep ladders among them, is counted class by class -- binary_full, binary_partial, general_full,
+    partial, each with its own depth classes -- and the table equals the oracle's; with the default class floor (1024
+    trees) the small classes join the most general mode present and the table is the same. The reference's loop is
+    shape-independent (QuartetCounterLookup.hpp:65-106, partial trees :214-221)."""
+    n = 30
+    ref_nw = synth.reference_tree(n, 430)
+    ref = flatten.flatten_reference(ref_nw)
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    full, drop = synth.tree_set(n, 40, 431), synth.tree_set(n, 40, 432, dropout=0.12)
+    coll, both = synth.tree_set(n, 30, 433, collapse=0.2), synth.tree_set(n, 12, 434, collapse=0.2, dropout=0.1)
+    trees, parts = [], []
+    for k in range(10):
+        chunk = full[4 * k:4 * k + 4] + drop[4 * k:4 * k + 4] + coll[3 * k:3 * k + 3] + both[k:k + 1]
+        trees += chunk
+        parts.append(flatten.flatten_eval_trees(chunk, ref.name_to_id))
+    trees += [cat + ";"] * 2
+    parts.append(flatten.flatten_eval_trees([cat + ";"] * 2, ref.name_to_id, recentre=False))   # depth 28: the 5-bit class of binary_full
+    batch = parts[0]
+    for p_ in parts[1:]:
+        batch = _concat_batches(batch, p_)
+    want = oracle_counts(ref_nw, trees).counts()
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
+    ctx, T = gpu_table(eng, ref, batch, count_bits)
+    v = ctx.last_count_variant()
+    assert "gather/mixed/" in v, v
+    for piece in ("binary_full.bitslice_b4x2:", "binary_full.bitslice_b5x2:2", "binary_partial.bitslice_b4x2:", "general_full.bitslice_b4:", "partial.bitslice_b4:"):
+        assert piece in v, (piece, v)
+    assert (T.astype(np.uint64) == want).all(), v
+    # accumulation over two uploads of the same mixed batch, split at an odd place
+    ctx2, T2 = gpu_table(eng, ref, batch, count_bits, split=37)
+    assert (T2.astype(np.uint64) == want).all()
+    # default floors: the small classes join a more general mode that is present -- same table
+    monkeypatch.delitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES)
+    monkeypatch.delitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT)
+    ctx3, T3 = gpu_table(eng, ref, batch, count_bits)
+    assert "gather/partial/" in ctx3.last_count_variant(), ctx3.last_count_variant()
+    assert (T3 == T).all()
+    # the byte-SWAR implementation takes the batch as a whole in the mode it needs
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+    ctx4, T4 = gpu_table(eng, ref, batch, count_bits)
+    assert "gather/partial/depth_u" in ctx4.last_count_variant()
+    assert (T4 == T).all()
+
+
+def test_a_few_incomplete_trees_do_not_slow_the_full_ones(eng, monkeypatch):
+    """1200 full binary trees and 1100 binary trees with missing taxa in one batch (interleaved): two classes, the full
+    trees keep the binary_full instance; tuples still equal the oracle's."""
+    n = 20
+    ref_nw = synth.reference_tree(n, 440)
+    ref = flatten.flatten_reference(ref_nw)
+    full, drop = synth.tree_set(n, 1200, 441), synth.tree_set(n, 1100, 442, dropout=0.2)
+    trees = []
+    for k in range(100):
+        trees += full[12 * k:12 * k + 12] + drop[11 * k:11 * k + 11]
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx, T = gpu_table(eng, ref, batch, 32)
+    v = ctx.last_count_variant()
+    assert "gather/mixed/" in v and "binary_full.bitslice_b4x2:12" in v and "binary_partial.bitslice_b4x2:10" in v, v
+    assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all()
+
+
 def test_only_the_deep_trees_take_the_deep_instance(eng, monkeypatch):
     n = 140
     ref_nw = synth.reference_tree(n, 420)
@@ -257,7 +328,7 @@ def test_only_the_deep_trees_take_the_deep_instance(eng, monkeypatch):
 
 
 @pytest.mark.parametrize("n,bits", [(20, 5), (40, 6), (80, 7), (150, 8)])
-@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial"])
+@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial", "binary_partial"])
 @pytest.mark.parametrize("count_bits", [32, 16])
 def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, kind, count_bits):
     """All (depth bits B, mode) instances of count_bitslice3_kernel up to 8 bits against the oracle: a caterpillar that is
@@ -268,7 +339,7 @@ def test_every_depth_width_of_the_bitsliced_kernel(eng, monkeypatch, n, bits, ki
     cat = "(t0,t1)"
     for i in range(2, n):
         cat = "(" + cat + f",t{i})"
-    kw = {"binary_full": {}, "general_full": {"collapse": 0.25}, "partial": {"dropout": 0.15, "collapse": 0.1}}[kind]
+    kw = {"binary_full": {}, "general_full": {"collapse": 0.25}, "partial": {"dropout": 0.15, "collapse": 0.1}, "binary_partial": {"dropout": 0.15}}[kind]
     trees = [cat + ";"] * 2 + synth.tree_set(n, 38, 300 + n, **kw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
     assert (1 << (bits - 1)) <= int(batch.adj_depth.max()) < (1 << bits)
@@ -344,7 +415,7 @@ def test_very_deep_trees_stay_bit_sliced(eng):
 
 
 @pytest.mark.parametrize("n,bits", [(300, 9), (600, 10), (1100, 11)])
-@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial"])
+@pytest.mark.parametrize("kind", ["binary_full", "general_full", "partial", "binary_partial"])
 def test_deep_ladders_9_and_10_bits(eng, monkeypatch, n, bits, kind):
     """Ladder-like trees (LCA depths up to n - 2, not re-rooted) on the 9- and 10-bit instances of the bit-sliced kernel,
     11 bits = beyond them (byte-SWAR kernel with 16-bit depths). Tables of these sizes are too large for the oracle, so a
@@ -360,7 +431,7 @@ def test_deep_ladders_9_and_10_bits(eng, monkeypatch, n, bits, kind):
     cat = "(t0,t1)"
     for i in range(2, n):
         cat = "(" + cat + f",t{i})"
-    kw = {"binary_full": {}, "general_full": {"collapse": 0.25}, "partial": {"dropout": 0.1, "collapse": 0.1}}[kind]
+    kw = {"binary_full": {}, "general_full": {"collapse": 0.25}, "partial": {"dropout": 0.1, "collapse": 0.1}, "binary_partial": {"dropout": 0.1}}[kind]
     trees = [cat + ";"] * 2 + synth.tree_set(n, 34, 950 + n, **kw)
     batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
     assert (1 << (bits - 1)) <= int(batch.adj_depth.max()) < (1 << bits)
@@ -374,6 +445,7 @@ def test_deep_ladders_9_and_10_bits(eng, monkeypatch, n, bits, kind):
         return ctx, ctx.table_download()
     ctx, T = shard_table()
     v = ctx.last_count_variant()
+    # (beyond 10 bits the two ladders take the byte-SWAR kernel -- in its partial mode when they share a mode with incomplete trees)
     assert kind in v and ((f"bitslice_b{bits}" in v) if bits <= 10 else ("depth_u16" in v)), v
     rng = np.random.default_rng(n)
     qs_ = np.sort(np.stack([np.append(rng.choice(d_lo + 1, size=3, replace=False), rng.integers(d_lo, n)) for _ in range(1500)]), axis=1)
@@ -685,6 +757,36 @@ def test_rooted_reference_compact_mode_matches_oracle(eng, case):
         assert got[k] == want[k], (sorted(k), got[k], want[k])
     # -s with --root-as-edge: no repeated ids are looked up, no exception
     eng.QuartetScoreComputer(fx["ref"], fx["eval"], None, False, True, root_as_edge=True)
+
+
+@pytest.mark.parametrize("route", ["two_pass_bundle", "single_read_log", "scan_kernel", "overflow_lists"])
+@pytest.mark.parametrize("case", ["rooted24", "rooted41"])
+def test_rooted_reference_second_evaluation_order(eng, monkeypatch, case, route):
+    """For a degree-2 root the reference's processNodePair(root, v) also walks quartets that another node pair owns and takes
+    std::min of their log_score into the same edges (QuartetScoreComputer.hpp:393-396,417-454) -- for a leaf alone on one side
+    of the root and an outsider that FOLLOWS v's subtree, with q2 and q3 exchanged, which changes the last bits of the sum
+    (:141-156). The engine flags those quartets (root_swapped in qs_score.hip) through every route a candidate can take --
+    the bundle kernel's pass 2, the candidate log of the single-read pass, the scan kernel, the overflow lists -- and the host
+    evaluates both orders: LQ-IC identical to the oracle's, where an unflagged run is off by up to 2 ulp (this fixture)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rooted_compact.json")) as f:
+        fx = json.load(f)[case]
+    tuning = {"two_pass_bundle": {_lib.QS_TUNE_SCORE_PASSES: 1}, "single_read_log": {_lib.QS_TUNE_SCORE_PASSES: 2},
+              "scan_kernel": {_lib.QS_TUNE_SCORE_KERNEL: 1}, "overflow_lists": {_lib.QS_TUNE_SCORE_CAND_SLOTS: 1}}[route]
+    for k_, v_ in tuning.items():
+        monkeypatch.setitem(eng.DEFAULT_TUNING, k_, v_)
+    o = oracle_counts(fx["ref"], fx["eval"])
+    for exact in (False, True):
+        o.score(qp_exact64=exact)
+        want = o.scores_by_bipartition()
+        qsc = eng.QuartetScoreComputer(fx["ref"], fx["eval"], qp_exact64=exact)
+        got = qsc.scores_by_bipartition()
+        assert set(got) == set(want)
+        for k in got:
+            assert got[k] == want[k], (route, exact, sorted(k), got[k], want[k])
+    if route == "single_read_log":
+        assert qsc.quartetCounterLookup.ctx.last_score_log() > 0
 
 
 @pytest.mark.parametrize("n,seed", [(9, 71), (24, 72), (41, 73)])
@@ -1427,3 +1529,25 @@ def test_lockstep_launches_match_the_swar_kernel(eng, dropout, collapse, variant
         assert (got == want).all()
         ctx.batch_free(hb)
         ctx.close()
+
+
+@pytest.mark.parametrize("n_words", [1, 3, 4, 1023, 1 << 20, (1 << 20) + 7])
+def test_sum_words_adds_every_source(eng, n_words):
+    """qs_sum_words (the peer-access reduce of the multi-GPU host): dst += sum of up to 15 sources over 32-bit words, for sizes
+    with and without a tail below 16 bytes; u16 cells add as packed words."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(n_words)
+    ctx = eng.Context(8, 32)
+    for k in (0, 1, 2, 7, 15):
+        dst = torch.randint(0, 1 << 20, (n_words,), generator=g, dtype=torch.int32).to(dev)
+        srcs = [torch.randint(0, 1 << 20, (n_words,), generator=g, dtype=torch.int32).to(dev) for _ in range(k)]
+        want = dst.clone()
+        for s_ in srcs:
+            want += s_
+        ctx.sum_words(dst, srcs)
+        ctx.sync()
+        assert torch.equal(dst, want), (n_words, k)
+    with pytest.raises(eng.QSError):
+        ctx.sum_words(torch.zeros(4, dtype=torch.int32, device=dev), [torch.zeros(4, dtype=torch.int32, device=dev)] * 16)
+    ctx.close()

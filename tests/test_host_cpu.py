@@ -361,3 +361,43 @@ def test_compact_mode_flag_changes_nothing_for_an_unrooted_reference(golden):
     o.count(ev if isinstance(ev, str) else "\n".join(ev), savemem=True, cint_bits=16)
     o.score()
     o.close()
+
+
+def test_finish_evaluates_a_flagged_candidate_in_both_orders(golden):
+    """A candidate slot flagged kCandSwap (bit 63) marks a quartet the reference evaluates twice for a degree-2 root, the second
+    time with q2 and q3 exchanged (QuartetScoreComputer.hpp:393-396,417-454): log_score sums p1 log p1 + p2 log p2 + p3 log p3
+    in that order (:141-156), so the two values can differ in the last bits and std::min keeps the smaller. qs_score_finish
+    (pure host) takes both; with QS_SCORE_ROOT_AS_EDGE, or without the flag, only the stored order."""
+    from quartetscores_amd import _lib, engine
+    ref = flatten.flatten_reference(golden["D4"]["ref"])
+    ni = ref.n_nodes - ref.n_taxa
+    P = ni * ni
+    # a triple whose two orders give different doubles
+    trip = None
+    for q1 in range(1, 60):
+        for q2 in range(1, 60):
+            for q3 in range(q2 + 1, 60):
+                if engine.log_score(q1, q2, q3) != engine.log_score(q1, q3, q2):
+                    trip = (q1, q2, q3)
+                    break
+            if trip:
+                break
+        if trip:
+            break
+    assert trip, "no order-sensitive triple below 60?"
+    a, b = engine.log_score(*trip), engine.log_score(trip[0], trip[2], trip[1])
+    packed = (trip[0] << 42) | (trip[1] << 21) | trip[2]
+    sums = np.zeros(3 * P, dtype=np.int64)
+    key = 0 * ni + 1                                    # some pair of inner nodes (iu < iv)
+    for flagged, flags, want in ((False, 0, a), (True, 0, min(a, b)), (True, _lib.QS_SCORE_ROOT_AS_EDGE, a)):
+        cand = np.full((1, _lib.QS_SCORE_CAND_SLOTS * P), -1, dtype=np.int64)
+        word = packed | ((1 << 63) if flagged else 0)
+        cand[0, _lib.QS_SCORE_CAND_SLOTS * key] = np.array([word], dtype=np.uint64).view(np.int64)[0]
+        lq, _, _, _ = engine.score_finish_host(ref, sums, cand, flags)
+        got = lq[np.isfinite(lq)]
+        assert len(got) and (got == want).all(), (flagged, flags, got, want)
+    # the same through an overflow-list record (key word bit 32)
+    cand = np.full((1, _lib.QS_SCORE_CAND_SLOTS * P), -1, dtype=np.int64)
+    extra = np.array([[key | (1 << 32), trip[0], trip[1], trip[2]]], dtype=np.int64)
+    lq, _, _, _ = engine.score_finish_host(ref, sums, cand, 0, extra=extra)
+    assert (lq[np.isfinite(lq)] == min(a, b)).all()

@@ -27,11 +27,19 @@ def timed(label, cmd, out):
     dt = time.perf_counter() - t0
     lines = [l for l in p.stdout.split("\n") if "took" in l or "Elapsed" in l]
     print(f"{label}: {dt:.3f} s wall, rc {p.returncode} | " + " ".join(lines))
+    if "--trace" in cmd:
+        print("".join("      " + l + "\n" for l in p.stderr.split("\n") if "rccl" in l or "main:" in l), end="")
 
 for t in ("1", "8", "64", "0"):
     timed(f"QuartetScores -t {t}", ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out.nwk", "-t", t], d + "/out.nwk")
-timed("QuartetScores --gpus 1 (RCCL driver, one device)", ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out3.nwk", "--gpus", "1"], d + "/out3.nwk")
-print("--gpus 1 output identical:", open(d + "/out.nwk").read() == open(d + "/out3.nwk").read())
+base_cmd = ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out3.nwk", "-t", "8", "--gpus", "1"]
+for label, extra in (("--gpus 1, RCCL, counting beside ncclCommInitAll (default)", []),
+                     ("--gpus 1, RCCL, first launch waits for the communicators (--comm-overlap 0: round 3)", ["--comm-overlap", "0"]),
+                     ("--gpus 1 --reduce p2p (peer access, no communicator)", ["--reduce", "p2p"]),
+                     ("--gpus 3 --reduce p2p --gpus-on-one-device (3 contexts, reduce-scatter by qs_sum_words)", ["--gpus", "3", "--reduce", "p2p", "--gpus-on-one-device"])):
+    for rep in range(2):
+        timed("QuartetScores " + label, base_cmd + extra + (["--trace"] if rep == 1 else []), d + "/out3.nwk")
+    print("   output identical to the single-GPU CLI:", open(d + "/out.nwk").read() == open(d + "/out3.nwk").read())
 timed("dist_cli, 1 process", [sys.executable, "-m", "quartetscores_amd.dist_cli", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out2.nwk"], d + "/out2.nwk")
 print("outputs identical:", open(d + "/out.nwk").read() == open(d + "/out2.nwk").read())
 PY
