@@ -2,7 +2,11 @@
 """bench.py -- quartets counted per second on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 (or `--via-launcher`) and no WORLD_SIZE in the environment: this process is only the PARENT. Before any
+GPU call it starts one fresh child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py <same arguments>`, relays rank 0's JSON line as its own last line and exits with the child's code (no
+retry; `--dry-launch` prints the command). Started by torch.distributed.run itself (WORLD_SIZE set) it is a rank.
 
 Workloads (BASELINE.json `configs`; seeded synthetic trees from csrc/host/synth.hpp):
     --config 1   configs[1]: 128 taxa x 1 000 trees, u32 table (128 MB)
@@ -11,18 +15,22 @@ Workloads (BASELINE.json `configs`; seeded synthetic trees fr
                  collective on the table per step                                   <- default at N > 1 (strong scaling)
     --config 4   configs[4]: 1024 taxa x 5 000 trees, u16 table sharded by the largest taxon id over max(N, 8) shards;
                  every rank counts all trees into its shard(s), no table collective
-    --taxa/--trees/--count-bits override the sizes (the workload label then says "custom").
+    --taxa/--trees/--count-bits override the sizes (the workload label then says "custom"); --dropout / --collapse / --mixed
+    make binary trees with missing taxa / multifurcating trees / a third of each (numpy generator, small tree counts).
 
-A step = one pass of the hot path over the rank's batch of trees, which is already resident in HBM: build the
-pair-depth panel and run the count kernel slice by slice (first slice stores, the others accumulate), then for N > 1
-the collective on the table. Exactly K steps are timed between barrier + torch.cuda.synchronize() on both sides;
-value = quartet-tree units counted by all ranks / max-over-ranks time.
+A step = one pass of the hot path over the rank's batch of trees, which is already resident in HBM (the task's measurement
+contract; the upload-inclusive step is reported as e2e.upload_in_step_ms, +1 %): build the pair-depth panel and run the count
+kernel class by class and slice by slice (first slice stores, the others accumulate), then for N > 1 the collective on the
+table. Exactly K steps are timed between barrier + torch.cuda.synchronize() on both sides; value = quartet-tree units counted
+by all ranks / max-over-ranks time. N > 1: `collective` = {ranks, proof (all-reduce of ones), comm_init_ms,
+collective_alone_ms}; rank 0 runs the cpu_baseline leg at every N.
 
 roofline: the dominant kernel is the count kernel. The gather formulation keeps every counter in a
 register and writes each table cell once per panel slice, so it is bound by VALU issue, not by HBM:
     achieved = ALGORITHMIC vector lane-operations per launch (the minimal compare chain of the bit-sliced four-point
-               test, (2(B+1)+2)/32 per tree x quartet for binary trees with B depth bits) / the kernel's average
-               launch duration, measured live with HIP events on the launch stream (qs_last_count_ms);
+               test per class: (2(B+1)+2)/32 per tree x quartet for full binary trees with B depth bits, 2(B+1)+6 with
+               missing taxa, 3(B+1)+4 / +8 for multifurcating trees) / the kernel's average launch duration, measured live
+               with HIP events on the launch stream around every launch of the LAST timed step (qs_last_count_ms);
     peak     = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles
                per SIMD = the 157.3 TFLOP/s fp32 vector peak / 2 flops).
 `issued` (instructions really issued, from rocprofv3 SQ_INSTS_VALU) and `traffic` (HBM bytes from FETCH_SIZE /
@@ -193,7 +201,10 @@ def host_info():
                 mem = min(mem, int(v)) if mem else int(v)
     except (OSError, ValueError):
         pass
-    return {"host_cpus": os.cpu_count() or 1, "cpu_model": model, "mem_available_bytes": mem}
+    import glob
+    nodes = len(glob.glob("/sys/devices/system/node/node[0-9]*")) or 1
+    return {"host_cpus": os.cpu_count() or 1, "cpu_model": model, "mem_available_bytes": mem, "numa_nodes": nodes,
+            "threads_note": "OpenMP threads are not pinned; beyond one NUMA node's cores the n^4 table's remote accesses cost more than the threads add"[:100]}
 
 
 def cpu_child(spec_path):

@@ -73,7 +73,7 @@ struct DeviceOptions {
                                  // std::runtime_error the reference's compact table throws (quartet_lookup_table.hpp:79-85)
     std::string reduce = "rccl"; // --gpus N: "rccl" (ncclReduceScatter / ncclAllReduce) or "p2p" (peer access, no communicator: multi_gpu.hpp)
     bool gpus_on_one_device = false; // test hook of --reduce p2p: the N "GPUs" are N contexts on device `device`
-    bool comm_overlap = true;    // --gpus N, rccl: count while ncclCommInitAll runs (false: the first launch waits for the communicators)
+    bool comm_overlap = false;   // --gpus N, rccl: count while ncclCommInitAll runs (false: the first launch waits for the communicators)
     std::string load_table, save_table; // count-table persistence
     bool trace = false;          // --trace: time stamps of the counting pipeline on stderr
 };

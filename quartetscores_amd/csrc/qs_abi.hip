@@ -1089,7 +1089,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             int mode = all_swar ? batch_mode : (int)d.class_mode[k];
             if (!use_bitslice && mode == MODE_BINARY_PARTIAL) mode = MODE_PARTIAL;
             const bool part = mode == MODE_PARTIAL || mode == MODE_BINARY_PARTIAL;           // panel elements carry a presence word
-            const bool bin_tiles = mode == MODE_BINARY_FULL || mode == MODE_BINARY_PARTIAL;  // two a-columns per lane
+            const bool bin_tiles = true;   // every instance of the bit-sliced kernel owns two a-columns per lane (16 a x 8 b tiles) since round 4
             // bit-sliced classes run count_bitslice3_kernel on the compact panel
             int bits = 8;
             uint32_t tpc;            // trees per panel element
@@ -1107,7 +1107,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             const size_t chunk_bytes = (size_t)binom2(c->n) * elem_bytes;
             const uint32_t n_chunks_total = (s_hi - s_lo + tpc - 1) / tpc;
             const uint32_t *order = nullptr;   // launch order of the bit-sliced kernel's tiles for this class's tiling
-            if (use_bitslice) { int rc_o = tile_order(c, bin_tiles ? 0 : 1, &order); if (rc_o != QS_OK) return rc_o; }
+            if (use_bitslice) { int rc_o = tile_order(c, 0, &order); if (rc_o != QS_OK) return rc_o; }
             const uint32_t chunks_per_slice = slice_groups(c, chunk_bytes, n_chunks_total, order != nullptr);
             const size_t need = (size_t)chunks_per_slice * chunk_bytes;
             if (need > c->panel_bytes) {

@@ -841,9 +841,11 @@ uint32_t bitslice3_tiles_for_c(uint32_t c) {
     return (T * T) / 4 + (T + 1) / 2; // pairs of a-blocks below every b-block + pairs of diagonal blocks
 }
 
-constexpr int kS3RSlots = kDB * 16;            // R elements: slot = d-row * 16 + b-column (0..15)
-constexpr int kS3Row0 = kS3RSlots;             // 16 elements M[x,c] of the a-columns
-constexpr int kS3Slots = kS3RSlots + 16;       // 144
+// LDS image per wave: RC columns (16; 24 in the general / partial modes, which also stage R of the two a-blocks and M[b,c])
+// x 8 d-rows of R elements, then RC elements M[x,c]
+constexpr int s3_cols(bool gen) { return gen ? 24 : 16; }
+constexpr int s3_row0(bool gen) { return kDB * s3_cols(gen); }              // R elements: slot = d-row * RC + column
+constexpr int s3_slots(bool gen) { return s3_row0(gen) + s3_cols(gen); }    // 144 / 216
 constexpr uint32_t kS3Inv = 0x80000000u;       // offset beyond any tree group (also after >> 2): the buffer load returns zeros
 
 typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
@@ -877,6 +879,9 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 #ifndef QS_BS3_WAVES
 #define QS_BS3_WAVES 4
 #endif
+#ifndef QS_GEN3_MAXB
+#define QS_GEN3_MAXB 6   /* general / partial instances up to this many depth bits are held to 3 waves per SIMD (168 VGPRs, a few spills) */
+#endif
 
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
@@ -901,7 +906,15 @@ template <typename CT> __device__ __forceinline__ void store_tuple(CT *p, uint32
 // (7 depth bits, binary: 8-plane operands in two a-columns; 4 bits, general) take 3 -- a spill means scratch memory
 // Deep trees (8..10 depth bits: ladders of up to ~2000 taxa) carry 9..12-word operands: 2 waves per SIMD.
 // (8 and 9 bits in the binary / general modes: 3 waves -- <= 168 VGPRs and 42-46 KB of LDS per workgroup.)
-template <int B, int MODE> constexpr int bs3_waves() { return (B >= 10 || (B >= 7 && (MODE == MODE_PARTIAL || MODE == MODE_BINARY_PARTIAL))) ? 2 : MODE == MODE_BINARY_PARTIAL ? (B <= 5 ? 4 : 3) : B >= 8 ? 3 : ((B == 7 && MODE == MODE_BINARY_FULL) || (B == 4 && MODE == MODE_GENERAL_FULL)) ? 3 : QS_BS3_WAVES; }
+template <int B, int MODE> constexpr int bs3_waves() {
+    constexpr bool gen = MODE == MODE_GENERAL_FULL || MODE == MODE_PARTIAL;
+    if (gen) return B <= (MODE == MODE_PARTIAL ? QS_GEN3_MAXB - 1 : QS_GEN3_MAXB) ? 3 : 2;   // two a-columns + three counters per quartet: 172-192 VGPRs unconstrained (B <= 6)
+    if (B >= 10 || (B >= 7 && MODE == MODE_BINARY_PARTIAL)) return 2;
+    if (MODE == MODE_BINARY_PARTIAL) return 3;
+    if (B >= 8) return 3;
+    if (B == 7 && MODE == MODE_BINARY_FULL) return 3;
+    return QS_BS3_WAVES;
+}
 template <int B, int MODE, typename CT>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(bs3_waves<B, MODE>(), bs3_waves<B, MODE>()))) void count_bitslice3_kernel(const uint4 *__restrict__ P, uint32_t npairs,
                                                                         uint32_t n_groups, uint32_t m_trees,
@@ -913,12 +926,19 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                                                                         uint32_t *__restrict__ overflow_flag, uint32_t overwrite,
                                                                         uint32_t xcd_remap, uint32_t *__restrict__ wire,
                                                                         const uint32_t *__restrict__ perm) {
-    // BIN: the two-a-column tiling of batches of BINARY trees (two comparisons decide a quartet); PART: elements carry a
-    // presence word (taxa may be missing). binary_partial = both: the third topology is what is left of the trees that
-    // hold all four taxa, v & ~(gt | lt) -- no third comparison (gene trees: binary, with missing taxa).
+    // BIN: batches of BINARY trees (two comparisons decide a quartet); GEN = !BIN: multifurcations possible, a third comparison
+    // tells ad|bc from "unresolved". PART: elements carry a presence word (taxa may be missing). binary_partial = BIN and
+    // PART: the third topology is what is left of the trees that hold all four taxa, v & ~(gt | lt) -- no third comparison
+    // (gene trees: binary, with missing taxa). Every mode uses the same tiling: a lane owns TWO a-columns (round 4; the
+    // general modes used to own one: half the quartets per panel byte loaded).
     constexpr bool BIN = MODE == MODE_BINARY_FULL || MODE == MODE_BINARY_PARTIAL;
+    constexpr bool GEN = !BIN;
     constexpr bool PART = MODE == MODE_PARTIAL || MODE == MODE_BINARY_PARTIAL;
     constexpr bool BP = MODE == MODE_BINARY_PARTIAL;
+    constexpr int RC = s3_cols(GEN), kS3Row0 = s3_row0(GEN), kS3Slots = s3_slots(GEN);
+    // LDS operations of one wave execute in order and no wave reads another's image, so ONE buffer per wave would do; the
+    // binary modes keep two (the stores of the next image then carry no dependence on the current image's reads)
+    constexpr int NBUF = GEN ? 1 : 2;
     constexpr int NB = B + 1;
     constexpr int NWP = B + (PART ? 1 : 0);                 // words of a compact panel element (planes [+ presence])
     constexpr int NW = NWP < 4 ? 4 : NWP;
@@ -927,11 +947,11 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     constexpr int PW = B + 1;                               // where the presence word travels in an LDS element
     static_assert(B <= kMaxDepthBits && RW <= kBitWords, "at most 10 depth bits (11 planes + presence in 12 words)");
     constexpr int kImg = (HW == 5 || HW == 6) ? 2 * kS3Slots + (kS3Slots * (HW - 4) + 3) / 4 : kS3Slots + (kS3Slots * HW + 3) / 4; // uint4 per wave and buffer
-    __shared__ uint4 stage_all[kWavesPerBlock][2][kImg];
+    __shared__ uint4 stage_all[kWavesPerBlock][NBUF][kImg];
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    uint4 *buf0 = stage_all[wave][0], *buf1 = stage_all[wave][1];
+    uint4 *buf0 = stage_all[wave][0], *buf1 = stage_all[wave][NBUF - 1];
 
     // ---- tile decode (wave-uniform): d-block k counts down from the top of the shard ----
     // Workgroups with the same blockIdx % 8 share an XCD (observed dispatch rule, used for speed only). With
@@ -953,33 +973,28 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     const uint32_t d0 = d1 > d_start + kDB ? d1 - kDB : d_start;
     const uint32_t c = wave_search_le(cprefix, 2, d1 - 1, local, lane, cp_c);
     const uint32_t T = (c + kTB - 1) / kTB;
-    const uint32_t n_off = BIN ? (T * T) / 4 : T * (T - 1) / 2;
+    const uint32_t n_off = (T * T) / 4;
     const uint32_t tl = local - cp_c;
     const bool offdiag = tl < n_off;
 
-    // id blocks behind the 16 staged columns: columns 0..7 = blk0, 8..15 = blk1 (0xFFFFFFFF = absent). Binary
-    // tiles: blk0/blk1 = the two a-blocks, blkB = the b-block (its R elements use columns 0..7). General / partial
-    // tiles (one a-column per lane; they also need R of (a,d) and M[bc]): blk0 = a-block, blk1 = b-block.
+    // id blocks: blk0 / blk1 = the two a-blocks (blk1 = 0xFFFFFFFF: absent), blkB = the b-block. Off-diagonal tiles: lane
+    // (ia, ib) owns a1 = 8 blk0 + ia, a2 = 8 blk1 + ia, b = 8 blkB + ib. Staged columns: M[x,c] of blk0 in columns 0..7 and of
+    // blk1 in 8..15; the binary modes stage the R elements of the b-block in columns 0..7, the general modes R of blk0 / blk1 /
+    // blkB in columns 0..7 / 8..15 / 16..23 (they also compare R of (a,d)) and M[b,c] in row columns 16..23.
+    // Diagonal tiles (a and b from the same block) pack two diagonal blocks per wave, one a per lane, 16 columns.
     uint32_t blk0, blk1, blkB;
     uint32_t a1, a2, b, colA1, colA2, colB;
-    if (offdiag && BIN) {
+    if (offdiag) {
         uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f)); // largest Bk with floor(Bk^2 / 4) <= tl
         while ((Bk * Bk) / 4 > tl) --Bk;
         while (((Bk + 1) * (Bk + 1)) / 4 <= tl) ++Bk;
         const uint32_t j = tl - (Bk * Bk) / 4;
         blk0 = 2 * j; blk1 = (2 * j + 1 < Bk) ? 2 * j + 1 : 0xFFFFFFFFu; blkB = Bk;
         const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
-        colA1 = ia; colA2 = kTA + ia; colB = ib;
+        colA1 = ia; colA2 = kTA + ia; colB = GEN ? 2 * kTA + ib : ib;
         a1 = blk0 * kTA + ia;
         a2 = blk1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : blk1 * kTA + ia;
         b = Bk * kTB + ib;
-    } else if (offdiag) {
-        unrank2(tl, blk0, blk1);
-        blkB = blk1;
-        const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
-        colA1 = ia; colA2 = ia; colB = kTA + ib;
-        a1 = blk0 * kTA + ia; a2 = 0xFFFFFFFFu;
-        b = blk1 * kTB + ib;
     } else {
         const uint32_t kd = tl - n_off;
         blk0 = 2 * kd; blk1 = 2 * kd + 1; blkB = blk0;
@@ -990,8 +1005,8 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         a1 = (h ? blk1 : blk0) * kTA + ia; a2 = 0xFFFFFFFFu;
         b = q < 28 ? (h ? blk1 : blk0) * kTA + ib : 0xFFFFFFFFu;
     }
-    const bool has_a2 = BIN && offdiag && blk1 != 0xFFFFFFFFu; // wave-uniform
-    const bool two_r = !BIN || !offdiag;                        // R elements for all 16 columns (else 8: the b-block)
+    const bool has_a2 = offdiag && blk1 != 0xFFFFFFFFu;         // wave-uniform
+    const uint32_t n_r = offdiag ? (GEN ? 3u : 1u) : 2u;        // blocks of R elements staged per d-row (wave-uniform)
     const bool v1 = (a1 < b) && (b < c);
     const bool v2 = has_a2 && (a2 < b) && (b < c);
     const uint32_t pi1 = v1 ? (uint32_t)binom2(b) + a1 : 0u;
@@ -1001,28 +1016,30 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     // ---- loop-invariant offsets inside one tree group (16 bytes per pair in the lo array), and LDS slots ----
     const uint32_t r_j = lane >> 3, r_col = lane & 7, dE = d0 + r_j;
     const bool dok = dE < d1 && dE > c;
-    const uint32_t bE0 = (two_r ? blk0 : blkB) * kTB + r_col, bE1 = blk1 * kTB + r_col;
-    const bool ok0 = dok && bE0 < c, ok1 = dok && two_r && bE1 < c;
+    // lane (r_j, r_col) stages the R elements of d-row r_j and column r_col of up to three blocks: slots r_j * RC + r_col + {0, 8, 16}
+    const uint32_t bE0 = (n_r == 1 ? blkB : blk0) * kTB + r_col, bE1 = blk1 * kTB + r_col, bE2 = blkB * kTB + r_col;
+    const bool ok0 = dok && bE0 < c, ok1 = dok && n_r >= 2 && blk1 != 0xFFFFFFFFu && bE1 < c, ok2 = dok && n_r == 3 && bE2 < c;
     const uint32_t rowd = (uint32_t)binom2(dE);
     const uint32_t x0off = ok0 ? (rowd + bE0) * 16u : kS3Inv, x1off = ok1 ? (rowd + bE1) * 16u : kS3Inv;
-    const uint32_t yoff = dok ? (rowd + c) * 16u : kS3Inv;      // M[c,d]: shared by both R elements of the lane
-    const uint32_t slot0 = r_j * 16 + r_col, slot1 = slot0 + 8;
-    // the 16 M[x,c] elements are staged by ALL lanes, four copies of each (lane & 15 picks the element; the copies
-    // load the same address and store the same value to the same slot). With the store under `if (lane < 16)` the
-    // compiler sank the load into that branch, i.e. behind the whole compute of the step, and waited for it with
-    // vmcnt(0) right there: one exposed memory latency per 32-tree step (knock-out: profiles/r02_experiments.md).
-    const uint32_t l16 = lane & 15;
+    const uint32_t x2off = ok2 ? (rowd + bE2) * 16u : kS3Inv;
+    const uint32_t yoff = dok ? (rowd + c) * 16u : kS3Inv;      // M[c,d]: shared by all R elements of the lane
+    const uint32_t slot0 = r_j * RC + r_col, slot1 = slot0 + 8, slot2 = slot0 + 16;
+    // the RC elements M[x,c] (x in blk0, blk1 and -- general modes -- the b-block) are staged by ALL lanes, in copies (lane & 15
+    // resp. lane & 31 picks the element; the copies load the same address and store the same value to the same slot). With the
+    // store under `if (lane < 16)` the compiler sank the load into that branch, i.e. behind the whole compute of the step, and
+    // waited for it with vmcnt(0) right there: one exposed memory latency per 32-tree step (knock-out: profiles/r02_experiments.md).
+    const uint32_t lrow = GEN ? ((lane & 31) < 24 ? (lane & 31) : (lane & 31) - 8) : (lane & 15);   // (0..23: lanes 24..31 repeat 16..23)
     uint32_t xa = 0xFFFFFFFFu;
-    if (l16 < 8) xa = blk0 * kTA + l16;
-    else if (blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (l16 - 8);
+    if (lrow < 8) xa = blk0 * kTA + lrow;
+    else if (lrow < 16) { if (blk1 != 0xFFFFFFFFu) xa = blk1 * kTA + (lrow - 8); }
+    else if (lrow < (uint32_t)RC && offdiag) xa = blkB * kTB + (lrow - 16);
     const uint32_t rowoff = xa < c ? ((uint32_t)binom2(c) + xa) * 16u : kS3Inv;
-    const uint32_t rowslot = kS3Row0 + l16;
+    const uint32_t rowslot = kS3Row0 + lrow;
     const uint32_t ab1off = v1 ? pi1 * 16u : kS3Inv, ab2off = v2 ? pi2 * 16u : kS3Inv;
     const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
-    // counters per d slot. Binary: x0/x1 = ab|cd, ac|bd of (a1,b); y0/y1 the same of (a2,b).
-    // General / partial: x0/x1/y0 = ab|cd, ac|bd, ad|bc of (a1,b).
-    // binary_partial: z0 / z1 = ad|bc of (a1,b) / (a2,b).
+    // counters per d slot: x0 / x1 = ab|cd, ac|bd of (a1,b); y0 / y1 the same of (a2,b); z0 / z1 = ad|bc of (a1,b) / (a2,b)
+    // (binary_full: the third count is m minus the other two, z0 / z1 stay unused).
     uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB], z0[kDB], z1[kDB];
 #pragma unroll
     for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = z0[j] = z1[j] = 0;
@@ -1057,13 +1074,14 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         }
         return lload(buf, kS3Row0 + col);
     };
-    struct Staged { Planes x0, x1, y, row; };
+    struct Staged { Planes x0, x1, x2, y, row; };
 
     // one 32-tree step: request group g_next into (st, abn1, abn2), count group g from (cur, abc1, abc2), then
     // turn the requested elements into the LDS image `nxt`
     auto step = [&](uint32_t g_next, const uint4 *cur, uint4 *nxt, const Planes &abc1, const Planes &abc2, Planes &abn1,
-                    Planes &abn2, auto a2_tag, auto full_tag, auto two_tag) {
-        constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value, TWO = decltype(two_tag)::value;
+                    Planes &abn2, auto a2_tag, auto full_tag, auto nr_tag) {
+        constexpr bool A2 = decltype(a2_tag)::value, FULL = decltype(full_tag)::value;
+        constexpr int NR = decltype(nr_tag)::value;                   // blocks of R elements this tile stages (n_r)
         const __amdgpu_buffer_rsrc_t r = rsrc_of(g_next);
         // The four waves of a workgroup are independent tiles, but consecutive ones: same b-block, c and d-block. Keeping
         // them in step (one s_barrier per 32-tree group; every wave runs the same number of steps, a wave without a tile
@@ -1075,19 +1093,24 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         Staged st;
         st.x0 = gload(r, x0off);
         st.y = gload(r, yoff);
-        if (TWO) st.x1 = gload(r, x1off);
+        if (NR >= 2) st.x1 = gload(r, x1off);
+        if (NR == 3) st.x2 = gload(r, x2off);
         st.row = gload(r, rowoff);
         abn1 = gload(r, ab1off);
         if (A2) abn2 = gload(r, ab2off);
 
-        const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1)); // M[ab] - M[ac] + 2^B
-        Planes L2 = L1;
-        if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));
-        if (!BIN) L2 = sub_biased<B>(abc1, row0_load(cur, colB));     // M[ab] - M[bc] + 2^B
+        const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1)); // M[a1 b] - M[a1 c] + 2^B
+        Planes L2 = L1, G1 = L1, G2 = L1;
+        if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));      // M[a2 b] - M[a2 c] + 2^B
+        if (GEN) {                                                    // M[ab] - M[bc] + 2^B: the other side of the third comparison
+            const Planes rb = row0_load(cur, colB);
+            G1 = sub_biased<B>(abc1, rb);
+            if (A2) G2 = sub_biased<B>(abc2, rb);
+        }
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
             if (FULL || ((uint32_t)j >= jlo && (uint32_t)j < jhi)) { // wave-uniform
-                const Planes Rb = lload(cur, j * 16 + colB);         // M[bd] - M[cd] + 2^B
+                const Planes Rb = lload(cur, j * RC + colB);         // M[bd] - M[cd] + 2^B
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
                 if (BIN) {
@@ -1110,26 +1133,41 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                         popc_acc(lt2, y1[j]);
                     }
                 } else {
-                    const Planes Ra = lload(cur, j * 16 + colA1);    // M[ad] - M[cd] + 2^B
-                    uint32_t g3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, L2), gt, lt); // S1 == S2 and S3 > S1
+                    const Planes Ra = lload(cur, j * RC + colA1);    // M[a1 d] - M[cd] + 2^B
+                    uint32_t g3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, G1), gt, lt); // S1 == S2 and S3 > S1
                     if (PART) {
-                        const uint32_t v = L1.w[kPres] & Rb.w[kPres]; // a, b, c, d all present
+                        const uint32_t v = L1.w[kPres] & Rb.w[kPres]; // a1, b, c, d all present
                         gt &= v; lt &= v; g3 &= v;
                     }
                     popc_acc(gt, x0[j]);
                     popc_acc(lt, x1[j]);
-                    popc_acc(g3, y0[j]);
+                    popc_acc(g3, z0[j]);
+                    if (A2) {                                        // the second a-column against the same R of (b,d)
+                        const Planes Ra2 = lload(cur, j * RC + colA2);
+                        uint32_t gt2, lt2;
+                        cmp_planes<NB>(L2, Rb, gt2, lt2);
+                        uint32_t h3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra2, G2), gt2, lt2);
+                        if (PART) {
+                            const uint32_t v2 = L2.w[kPres] & Rb.w[kPres];
+                            gt2 &= v2; lt2 &= v2; h3 &= v2;
+                        }
+                        popc_acc(gt2, y0[j]);
+                        popc_acc(lt2, y1[j]);
+                        popc_acc(h3, z1[j]);
+                    }
                 }
             }
         }
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
-        if (TWO) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
+        if (NR >= 2) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
+        if (NR == 3) lstore(nxt, slot2, sub_biased<B>(st.x2, st.y));
         if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
         else lstore(nxt, rowslot, st.row);
     };
 
-    auto run = [&](auto a2_tag, auto full_tag, auto two_tag) {
-        constexpr bool A2 = decltype(a2_tag)::value, TWO = decltype(two_tag)::value;
+    auto run = [&](auto a2_tag, auto full_tag, auto nr_tag) {
+        constexpr bool A2 = decltype(a2_tag)::value;
+        constexpr int NR = decltype(nr_tag)::value;
         Planes abA1, abA2, abB1, abB2;
 #pragma unroll
         for (int w = 0; w < kBitWords; ++w) abA2.w[w] = abB2.w[w] = 0;
@@ -1137,7 +1175,8 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
             const __amdgpu_buffer_rsrc_t r = rsrc_of(0);
             const Planes y = gload(r, yoff);
             lstore(buf0, slot0, sub_biased<B>(gload(r, x0off), y));
-            if (TWO) lstore(buf0, slot1, sub_biased<B>(gload(r, x1off), y));
+            if (NR >= 2) lstore(buf0, slot1, sub_biased<B>(gload(r, x1off), y));
+            if (NR == 3) lstore(buf0, slot2, sub_biased<B>(gload(r, x2off), y));
             const Planes row = gload(r, rowoff);
             lstore(buf0, rowslot, row);
             abA1 = gload(r, ab1off);
@@ -1150,19 +1189,22 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         // round trip per two steps, taken by all waves of a SIMD at about the same time.
         uint32_t g = 0;
         for (; g + 2 <= n_groups; g += 2) {
-            step(g + 1, buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, two_tag);
-            step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, two_tag); // past the end: re-reads the last group (unused)
+            step(g + 1, buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, nr_tag);
+            step(min(g + 2, g_last), buf1, buf0, abB1, abB2, abA1, abA2, a2_tag, full_tag, nr_tag); // past the end: re-reads the last group (unused)
         }
-        if (g < n_groups) step(g_last, buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, two_tag);
+        if (g < n_groups) step(g_last, buf0, buf1, abA1, abA2, abB1, abB2, a2_tag, full_tag, nr_tag);
     };
     using T_ = std::true_type; using F_ = std::false_type;
+    using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N3 = std::integral_constant<int, 3>;
     const bool full = jlo == 0 && jhi == (uint32_t)kDB;
     if (BIN) {
-        if (has_a2) { if (full) run(T_{}, T_{}, F_{}); else run(T_{}, F_{}, F_{}); }
-        else if (offdiag) run(F_{}, F_{}, F_{});
-        else run(F_{}, F_{}, T_{});
+        if (has_a2) { if (full) run(T_{}, T_{}, N1{}); else run(T_{}, F_{}, N1{}); }
+        else if (offdiag) run(F_{}, F_{}, N1{});
+        else run(F_{}, F_{}, N2{});
     } else {
-        if (full) run(F_{}, T_{}, T_{}); else run(F_{}, F_{}, T_{});
+        if (has_a2) { if (full) run(T_{}, T_{}, N3{}); else run(T_{}, F_{}, N3{}); }
+        else if (offdiag) run(F_{}, F_{}, N3{});
+        else run(F_{}, F_{}, N2{});
     }
 
     // rank of {a,b,c,d} = C(d,4) + C(c,3) + C(b,2) + a; along the d slots C(d+1,4) = C(d,4) + C(d,3) etc., so the
@@ -1201,14 +1243,14 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         if (d < d1 && d > c) {
             if (v1) {
                 const uint64_t idx = (base + pi1) * 3;
-                uint32_t w0 = x0[j], w1 = x1[j], w2 = BP ? z0[j] : BIN ? m_trees - x0[j] - x1[j] : y0[j];
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = MODE == MODE_BINARY_FULL ? m_trees - x0[j] - x1[j] : z0[j];
                 if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 store_tuple(table + idx, w0, w1, w2);
             }
-            if (BIN && v2) {
+            if (v2) {
                 const uint64_t idx = (base + pi2) * 3;
-                uint32_t w0 = y0[j], w1 = y1[j], w2 = BP ? z1[j] : m_trees - y0[j] - y1[j];
+                uint32_t w0 = y0[j], w1 = y1[j], w2 = MODE == MODE_BINARY_FULL ? m_trees - y0[j] - y1[j] : z1[j];
                 if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 store_tuple(table + idx, w0, w1, w2);

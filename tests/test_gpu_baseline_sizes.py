@@ -16,7 +16,7 @@ import pytest
 
 import bruteforce
 from oracle_api import Oracle
-from quartetscores_amd import _lib, distributed, flatten, native_ingest, ranks
+from quartetscores_amd import _lib, distributed, flatten, native_ingest, ranks, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +120,7 @@ def score_steps(ctx, ref, kernel):
 
 
 def test_configs2_512_taxa_10000_trees_u32(eng):
-    """BASELINE configs[2]: 34 GB table, depth classes B=4 / B=5, three panel slices (the later ones read-modify-write
+    """BASELINE configs[2]: 34 GB table, depth classes B=4 / B=5, two panel slices = two launches (the second read-modify-writes
     the table). Scoring at full size: the bundle kernel (43 000 planned rounds) and the scan kernel give the same
     per-node-pair sums bit for bit and the same LQ-/QP-/EQP-IC."""
     ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 2, 512, 10000, 32)
@@ -183,4 +183,60 @@ def test_configs4_shard_1024_taxa_5000_trees_u16(eng):
     # the shard's part of the scoring (u16 cells, a plan restricted to d in [d_lo, d_hi)): both kernels, same sums
     a, b = score_steps(ctx, ref, 0), score_steps(ctx, ref, 1)
     assert (a[0] == b[0]).all() and a[0].any()
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["dropout", "collapse", "mixed"])
+def test_512_taxa_gene_tree_like_batches(eng, kind):
+    """The round-3 verdict's workloads at BASELINE configs[2]'s taxon count (34 GB table): 900 trees with 10 % of the taxa
+    missing (binary_partial), with 20 % of the internal edges collapsed (general_full on the two-column tile), or a third each
+    of full / incomplete / collapsed trees (classes of several modes in one batch). The table is too large for the oracle:
+    the bit-sliced table must equal the byte-SWAR kernel's bit for bit (which takes the whole batch in ONE mode), every
+    tuple sums to at most the number of trees, and 20 000 random quartets equal the split-based brute force."""
+    import torch
+    n, m = 512, 900
+    ref_nw = native_ingest.synth_trees(n, 1, 2000).decode().strip()
+    ref = flatten.flatten_reference(ref_nw)
+    if kind == "mixed":
+        parts = [synth.tree_set(n, 300, 2101), synth.tree_set(n, 300, 2102, dropout=0.1), synth.tree_set(n, 300, 2103, collapse=0.2)]
+        trees = [parts[i % 3][i // 3] for i in range(m)]
+    else:
+        trees = synth.tree_set(n, m, 2100, **({"dropout": 0.1} if kind == "dropout" else {"collapse": 0.2}))
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = eng.Context(n, 32)
+    table = torch.zeros((ctx.table_bytes + 3) // 4, dtype=torch.int32, device="cuda")
+    ctx.table_attach(table)
+    if kind == "mixed":       # 300 trees per mode: let them form their own classes
+        ctx.set_tuning(_lib.QS_TUNE_CLASS_MIN_TREES, 64)
+        ctx.set_tuning(_lib.QS_TUNE_CLASS_PCT, 0)
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    v = ctx.last_count_variant()
+    assert {"dropout": "gather/binary_partial/", "collapse": "gather/general_full/", "mixed": "gather/mixed/"}[kind] in v and "depth_u" not in v, v
+    nq = ctx.table_tuples
+    for lo in range(0, nq, 1 << 26):
+        hi = min(nq, lo + (1 << 26))
+        sums = table[lo * 3: hi * 3].view(hi - lo, 3).sum(dim=1)
+        assert int(sums.max().item()) <= m
+    mine = table.clone()
+    ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    assert "depth_u" in ctx.last_count_variant()
+    assert torch.equal(mine, table)
+    del mine
+    ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_AUTO)
+    # random quartets of a 48-tree prefix against the brute force
+    k = 48
+    hb2 = ctx.batch_upload(batch.slice(0, k), with_nodes=False)
+    ctx.count_batch(hb2, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    rng = np.random.default_rng(2107)
+    q = np.sort(np.stack([rng.choice(n, size=4, replace=False) for _ in range(20000)]), axis=1)
+    got = ctx.lookup(q.astype(np.uint16))
+    want = bruteforce.quartet_counts_for(trees[:k], ref.names, q)
+    assert (got == want).all()
+    ctx.batch_free(hb2)
+    ctx.batch_free(hb)
     ctx.close()

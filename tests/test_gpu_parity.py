@@ -271,7 +271,7 @@ def test_mixed_batches_are_counted_mode_by_mode(eng, monkeypatch, count_bits):
     ctx, T = gpu_table(eng, ref, batch, count_bits)
     v = ctx.last_count_variant()
     assert "gather/mixed/" in v, v
-    for piece in ("binary_full.bitslice_b4x2:", "binary_full.bitslice_b5x2:2", "binary_partial.bitslice_b4x2:", "general_full.bitslice_b4:", "partial.bitslice_b4:"):
+    for piece in ("binary_full.bitslice_b4x2:", "binary_full.bitslice_b5x2:2", "binary_partial.bitslice_b4x2:", "general_full.bitslice_b4x2:", "partial.bitslice_b4x2:"):
         assert piece in v, (piece, v)
     assert (T.astype(np.uint64) == want).all(), v
     # accumulation over two uploads of the same mixed batch, split at an odd place
