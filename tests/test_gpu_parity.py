@@ -1551,3 +1551,28 @@ def test_sum_words_adds_every_source(eng, n_words):
     with pytest.raises(eng.QSError):
         ctx.sum_words(torch.zeros(4, dtype=torch.int32, device=dev), [torch.zeros(4, dtype=torch.int32, device=dev)] * 16)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_rooted_reference_soak_against_the_oracle(eng, monkeypatch, seed):
+    """Random rooted (degree-2 root) reference trees of 6-45 taxa with random small sets of binary / incomplete / multifurcating
+    evaluation trees: LQ-, QP- and EQP-IC of every edge identical to the oracle's (wrap32 and 64-bit QP sums), through a random
+    candidate route (two passes, forced single read, scan kernel, one candidate slot). Small tree sets make near-minimal ties --
+    and with them both evaluation orders of the root pairs' quartets -- common."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(6, 46))
+    m = int(rng.choice([3, 8, 15, 40]))
+    kw = [dict(), dict(dropout=0.15), dict(collapse=0.2), dict(collapse=0.15, dropout=0.1)][int(rng.integers(0, 4))]
+    ref_nw = synth.random_tree(n, rng, rooted=True)
+    trees = synth.tree_set(n, m, 7100 + seed, **kw)
+    route = [{_lib.QS_TUNE_SCORE_PASSES: 1}, {_lib.QS_TUNE_SCORE_PASSES: 2}, {_lib.QS_TUNE_SCORE_KERNEL: 1}, {_lib.QS_TUNE_SCORE_CAND_SLOTS: 1}][int(rng.integers(0, 4))]
+    for k_, v_ in route.items():
+        monkeypatch.setitem(eng.DEFAULT_TUNING, k_, v_)
+    o = oracle_counts(ref_nw, trees)
+    for exact in (False, True):
+        o.score(qp_exact64=exact)
+        want = o.scores_by_bipartition()
+        got = eng.QuartetScoreComputer(ref_nw, trees, qp_exact64=exact).scores_by_bipartition()
+        assert set(got) == set(want)
+        for k in got:
+            assert got[k] == want[k], (n, m, kw, route, exact, sorted(k), got[k], want[k])

@@ -17,7 +17,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(cases):
     n = int(rng.choice([4, 5, 7, 9, 16, 17, 24, 33, 40, 64, 65, 97, 130, 200, 257]))
-    kind = str(rng.choice(["binary", "binary", "collapsed", "partial", "mixed", "ladder"]))
+    kind = str(rng.choice(["binary", "binary", "collapsed", "partial", "mixed", "ladder", "modes", "modes"]))
     m = int(rng.choice([1, 31, 33, 200, 1500])) if n <= 130 else int(rng.choice([40, 300]))
     bits = int(rng.choice([16, 32]))
     seed = int(rng.integers(1, 1 << 30))
@@ -27,6 +27,10 @@ for case in range(cases):
         for i in range(n - 3, -1, -1):
             lad = f"(t{i},{lad})"
         trees = [lad + ";"] + list(synth.nni_tree_set(lad + ";", m - 1, seed + 1)) if m > 1 else [lad + ";"]
+    elif kind == "modes":      # trees of all four kernel modes interleaved in one batch (round 4: the mode is a property of the tree)
+        kws = [dict(), dict(dropout=0.2), dict(collapse=0.25), dict(collapse=0.2, dropout=0.15)]
+        sets = [synth.tree_set(n, (m + 3) // 4, seed + 10 + i, **kw) for i, kw in enumerate(kws)]
+        trees = [sets[i % 4][i // 4] for i in range(m)]
     else:
         kw = {"collapsed": dict(collapse=0.25), "partial": dict(dropout=0.2), "mixed": dict(collapse=0.2, dropout=0.15)}.get(kind, {})
         trees = synth.tree_set(n, m, seed + 2, **kw)
@@ -40,7 +44,8 @@ for case in range(cases):
     for name, tuning in (("swar", {_lib.QS_TUNE_GATHER_IMPL: _lib.QS_IMPL_SWAR}), ("default", {}),
                          ("random plan", {_lib.QS_TUNE_PANEL_SLICE_BYTES: int(rng.choice([1 << 12, 1 << 16, 1 << 20, 1 << 24])),
                                           _lib.QS_TUNE_TILE_ORDER: int(rng.choice([0, 1 | 4 << 16, 2 | 32 << 16, 4 | 16 << 16, 3 | 7 << 16])),
-                                          _lib.QS_TUNE_CLASS_PCT: int(rng.choice([0, 10, 60, 100]))})):
+                                          _lib.QS_TUNE_CLASS_PCT: int(rng.choice([0, 10, 60, 100])),
+                                          _lib.QS_TUNE_CLASS_MIN_TREES: int(rng.choice([1, 8, 64, 1024]))})):
         ctx = engine.Context(n, bits, d_lo=d_lo, d_hi=d_hi)
         for k_, v_ in tuning.items():
             ctx.set_tuning(k_, v_)
