@@ -90,8 +90,9 @@ def parse_args():
                     help="a third of the trees binary and full, a third with --dropout (default 0.1), a third with --collapse (default 0.2), interleaved")
     ap.add_argument("--reduce", choices=["scatter", "all"], default="scatter",
                     help="N>1: reduce-scatter (each rank keeps and scores a shard of the reduced table) or all-reduce")
-    ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto",
-                    help="N>1: format of the table on the wire (auto: while the total number of trees < 65536, u16x2 for binary full trees, else u16)")
+    ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32x2", "u32"], default="auto",
+                    help="N>1: format of the table on the wire (auto: fewer than 65536 trees in total: u16x2 for binary full trees, else u16; "
+                         "from 65536 trees on: u32x2 = two u32 cells per tuple for binary full trees with reduce-scatter, else u32)")
     ap.add_argument("--table-shards", type=int, default=0, help="table-sharded mode: split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=-1, help="table-sharded mode on fewer ranks than shards: which shard this rank owns (default: its rank)")
     ap.add_argument("--slice-bytes", type=int, default=0, help="qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES); 0 = automatic")
@@ -486,10 +487,14 @@ def main():
             wire_fmt = "u16x2"
         elif args.wire == "u16" or (args.wire == "auto" and small):
             wire_fmt = "u16"
-    wire16 = wire_fmt is not None
+        elif args.wire == "u32x2" or (args.wire == "auto" and binary_full_trees and args.reduce == "scatter"):
+            wire_fmt = "u32x2"      # configs[3]: 100 000 trees need u32 cells; (n0, n1) travel, n2 = total - n0 - n1 is restored: 8 B / tuple
+    wire32x2 = wire_fmt == "u32x2"
+    wire16 = wire_fmt is not None and not wire32x2
     if wire16:
         assert total_trees_reduced < 65536, "--wire u16 / u16x2 need fewer than 65536 trees in total"
-    assert wire_fmt != "u16x2" or binary_full_trees, "--wire u16x2 needs binary trees that hold all taxa"
+    assert wire_fmt not in ("u16x2", "u32x2") or binary_full_trees, "--wire u16x2 / u32x2 need binary trees that hold all taxa"
+    assert not wire32x2 or args.reduce == "scatter", "--wire u32x2 is a reduce-scatter format"
     reduce_mode = args.reduce if collective else None
     bits_wire = 16 if wire16 else count_bits
     layout_wire = wire_fmt or count_bits
@@ -500,7 +505,7 @@ def main():
         recv = [torch.zeros(chunk_words, dtype=torch.int32, device=dev) for _ in range(2)]
     elif reduce_mode == "all":
         send_words = ctx.table_tuples if wire_fmt == "u16x2" else distributed.table_words(ctx.table_tuples, bits_wire)
-    if wire16:
+    if wire16 or wire32x2:
         wire = [torch.zeros(send_words, dtype=torch.int32, device=dev) for _ in range(2)]
     elif collective:
         table = torch.zeros(max(n_words, send_words), dtype=torch.int32, device=dev)  # padded to world chunks
@@ -518,7 +523,7 @@ def main():
     step_algo = algo | engine.QS_COUNT_OVERWRITE if args.algo == "gather" else algo
 
     def step(timed=False):
-        i = step_no[0] % (2 if wire16 else len(tables))
+        i = step_no[0] % (2 if (wire16 or wire32x2) else len(tables))
         step_no[0] += 1
         if pending[i] is not None:       # the collective that last used this buffer must be done
             pending[i].wait()
@@ -538,6 +543,9 @@ def main():
                 src = wire[i]
             elif wire16:
                 (ctx.table_pack16x2 if wire_fmt == "u16x2" else ctx.table_pack16)(wire[i])
+                src = wire[i]
+            elif wire32x2:
+                ctx.table_pack32x2(wire[i])      # (n0, n1) of every tuple: one pass over the table, 8 instead of 12 bytes per tuple on xGMI
                 src = wire[i]
             else:
                 src = tables[i]
@@ -609,7 +617,7 @@ def main():
     # collective alone (N > 1): the same buffers, nothing else on the GPU, a few repetitions
     coll_alone_ms = None
     if collective and steps > 0:
-        src = (wire if wire16 else tables)[last_buf[0]]
+        src = (wire if (wire16 or wire32x2) else tables)[last_buf[0]]
         fence()
         c0 = time.perf_counter()
         reps = 3
@@ -631,13 +639,20 @@ def main():
             own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
             red, n_red = recv[last_buf[0]], own_n
         else:
-            red, n_red = (wire if wire16 else tables)[last_buf[0]], nq
+            red, n_red = (wire if (wire16 or wire32x2) else tables)[last_buf[0]], nq
         if wire_fmt == "u16x2":            # restore the third cell of the reduced tuples (a u16 table again)
             shard16 = torch.zeros(distributed.table_words(max(n_red, 1), 16), dtype=torch.int32, device=dev)
             ctx.unpack16x2(red, n_red, total_trees_reduced, shard16)
             ctx.sync()                     # raises if a reduced tuple exceeds the total
             w_ = red[:n_red]
             ok_local = bool((((w_ & 0xFFFF) + ((w_ >> 16) & 0xFFFF)) <= total_trees_reduced).all().item())
+        elif wire32x2:                     # restore the third cell of the reduced tuples (u32 cells again); raises if a tuple exceeds the total
+            shard16 = torch.zeros(distributed.table_words(max(n_red, 1), 32), dtype=torch.int32, device=dev)
+            ctx.unpack32x2(red, n_red, total_trees_reduced, shard16)
+            ctx.sync()
+            pr = red[: 2 * n_red].view(-1, 2).to(torch.int64)
+            ok_local = bool((pr.sum(dim=1) <= total_trees_reduced).all().item())
+            del pr
         elif binary_full_trees:
             ok_local = True
             for c0_ in range(0, n_red, 1 << 26):   # chunked: the shard can be GBs
@@ -698,7 +713,7 @@ def main():
             elif reduce_mode == "scatter" and steps > 0:
                 # every rank scores the shard it received (view), accumulators combined with small collectives
                 own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, layout_wire)
-                ctx.score_set_view(shard16 if wire_fmt == "u16x2" else recv[last_buf[0]], bits_wire, own_lo, own_n)
+                ctx.score_set_view(shard16 if wire_fmt in ("u16x2", "u32x2") else recv[last_buf[0]], bits_wire, own_lo, own_n)
                 distributed.score_sharded(ctx, ref)
                 ctx.score_set_view(None, 0, 0, 0)
                 ph = None
@@ -858,7 +873,7 @@ def main():
             "table_shard": [d_lo, d_hi] if shards > 1 else None,
             "algo": variant,
             "step": (("panel build + count kernel per slice (1st slice stores)" if args.algo == "gather" else "table clear + count kernel")
-                     + ((" + " + {"u16": "pack u16 + ", "u16x2": "1 word/tuple wire + ", None: ""}[wire_fmt] + ("RCCL reduce-scatter" if reduce_mode == "scatter" else "RCCL all-reduce") + ", async, 2 buffers") if collective_saved else ""))[:100],
+                     + ((" + " + {"u16": "pack u16 + ", "u16x2": "1 word/tuple wire + ", "u32x2": "2 u32 cells/tuple wire + ", None: ""}[wire_fmt] + ("RCCL reduce-scatter" if reduce_mode == "scatter" else "RCCL all-reduce") + ", async, 2 buffers") if collective_saved else ""))[:100],
             "collective": reduce_mode,
             "collective_input_bytes_per_rank": send_words * 4 if collective_saved else None,
             "collective_alone_ms": coll_alone_ms,

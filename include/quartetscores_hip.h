@@ -324,15 +324,21 @@ int qs_score_prepare(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t n_trees_total
  *                    For tables from 1 GB (QS_TUNE_SCORE_PASSES) this pass also LOGS, in the context, every quartet within
  *                    the tolerance of the bound it knows for its node pair -- a superset of what pass 2 can ask for as long
  *                    as min_dev there is <= this context's own minima (it is: the MIN over the shards) -- so that
+ *                    the pass 2 that follows can filter the log instead of reading the table again. Asynchronous on the
+ *                    context's stream -- except in that automatic mode, where the call waits once on the host for a
+ *                    counter (the sample that predicts the log's size: ~0.3 ms of kernels) before it enqueues the pass.
  *   qs_score_pass2 : cand_dev[QS_SCORE_CAND_SLOTS*P] = distinct gcd-reduced count triples of this context
- *                    whose QIC is within 1e-12 of min_dev (-1 = empty slot) -> all-gather over shards.
+ *                    whose QIC is within 1e-12 of min_dev (-1 = empty slot; bit 63 of a slot: the reference evaluates
+ *                    this triple a second time with q2 and q3 exchanged -- degree-2 root, DESIGN.md 1 Q5 -- and
+ *                    qs_score_finish takes both) -> all-gather over shards.
  *                    Filters the log of the qs_score_pass1 that preceded it on the same context, table / view and
  *                    reference (the table is then read ONCE); reads the table again if there is no such log (any
  *                    qs_count_* / qs_table_* / qs_set_tuning / qs_score_set_view call in between discards it, and the
  *                    caller must not write into an attached table between the two passes) or if the log overflowed.
  *                    A node pair with more than 8 such triples (or one whose reduced counts need more than 21
  *                    bits) is MARKED in cand_dev instead of failing the run:
- *   qs_score_overflow: lists every near-minimal quartet (key, q1, q2, q3; 4 int64 per entry, sorted, distinct) of
+ *   qs_score_overflow: lists every near-minimal quartet (key, q1, q2, q3; 4 int64 per entry, sorted, distinct; bit 32 of the
+ *                    key word = the same "both orders" flag) of
  *                    this context's marked pairs into a malloc'ed host array (*list_out, free with qs_free_host;
  *                    NULL / 0 when nothing was marked -- the usual case) -> concatenate over the shards
  *   qs_score_finish: pure host arithmetic on the reduced sums, the n_cand_parts gathered candidate arrays (each
