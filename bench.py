@@ -807,6 +807,15 @@ def main():
         step()                           # the gates / scoring below read the table of a plain step
         ctx.sync()
 
+    # how fast THIS device runs the count kernel's bare instruction slot (qs_issue_probe: 24 v_bitop3 + 4 v_bcnt in registers, 4
+    # waves per SIMD): boxes of one pool differ by several per cent; the figure makes lines from different boxes comparable
+    box_probe_ns = None
+    if rank == 0:
+        try:
+            box_probe_ns = ctx.issue_probe(60000)
+        except Exception:        # diagnostic only
+            box_probe_ns = None
+
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -895,6 +904,8 @@ def main():
             "score_phases_ms_cold": score_phases_cold,
             "score_roofline": score_roofline,
             "input_generation_s": gen_s,
+            "box_issue_probe_ns_per_inst": box_probe_ns,
+            "box_issue_probe_note": "bare 24 v_bitop3 + 4 v_bcnt slot at 4 waves/SIMD on this device; 1.39-1.40 in profiles/r03_valu_yardstick.txt",
         },
     }
     # e2e: what the product delivers when the inputs are NOT yet resident (never `value`)

@@ -391,6 +391,11 @@ int qs_last_score_ms(qs_ctx *ctx, float out_ms[6]);
 uint64_t qs_last_score_log(const qs_ctx *ctx);
 /* Automatic mode: the log size the most recent qs_score predicted from its sample (hits of the sample x S); 0 = no estimate ran. */
 uint64_t qs_last_score_estimate(const qs_ctx *ctx);
+/* Diagnostic: nanoseconds per wave instruction and SIMD of the count kernel's bare instruction slot (24 v_bitop3 + 4 v_bcnt,
+ * operands in registers, 4 waves per SIMD on every CU) on THIS device -- devices of one pool hold different clocks under a
+ * VALU-dense load, and the figure makes measurements from different boxes comparable. `iterations` loop trips of 4 slots
+ * each (100000 = ~60 ms); synchronous. */
+int qs_issue_probe(qs_ctx *ctx, uint32_t iterations, float *ns_per_instruction);
 /* Name of the kernel variant the last qs_count_batch dispatched (for logs/profiles). */
 const char *qs_last_count_variant(const qs_ctx *ctx);
 /* How score passes 1 and 2 decompose the tuples [rank_lo, rank_lo + n_tuples) of an n_taxa table (host arithmetic only,

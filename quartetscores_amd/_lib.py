@@ -29,7 +29,7 @@ EXPORTS = [
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
     "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
-    "qs_sum_words",
+    "qs_sum_words", "qs_issue_probe",
 ]
 
 
@@ -95,6 +95,8 @@ def load():
     L.qs_table_pack32x2.argtypes = [vp, vp, u64]
     L.qs_unpack32x2.restype = i32
     L.qs_unpack32x2.argtypes = [vp, vp, u64, u64, vp]
+    L.qs_issue_probe.restype = i32
+    L.qs_issue_probe.argtypes = [vp, u32, vp]
     L.qs_sum_words.restype = i32
     L.qs_sum_words.argtypes = [vp, vp, vp, u32, u64]
     L.qs_table_device_ptr.restype = vp

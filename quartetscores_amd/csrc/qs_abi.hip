@@ -712,6 +712,71 @@ extern "C" int qs_sum_words(qs_ctx *c, void *dst_device, const void *const *src_
     return QS_OK;   // asynchronous on the context's stream
 }
 
+// ---- issue probe: how fast does THIS device run the count kernel's instruction mix? ------------------------------------
+// MI355X devices of one pool differ by several per cent in the clock they hold under a VALU-dense load (the guide measures up
+// to 12 % between devices), more than a round of kernel work moves the headline. The probe runs the bare slot of the hot
+// instance at B = 5 -- two magnitude comparisons of 6 planes sharing one operand (24 v_bitop3) + 4 v_bcnt with accumulate, all
+// operands in registers -- at 4 waves per SIMD on every CU and returns nanoseconds per wave instruction and SIMD, the figure
+// profiles/r03_valu_yardstick.txt calls the slot's cost (1.39-1.40 ns on the boxes it was written on). bench.py prints it
+// beside its line so that lines from different boxes can be compared.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void issue_probe_kernel(const uint32_t *__restrict__ seed, uint32_t *__restrict__ out, uint32_t iters) {
+    uint32_t l1[6], l2[6], r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        l1[k] = seed[(threadIdx.x * 19u + k) & 1023u];
+        l2[k] = seed[(threadIdx.x * 23u + k + 6) & 1023u];
+        r[k] = seed[(threadIdx.x * 29u + k + 12) & 1023u];
+    }
+    uint32_t g1 = 0, t1 = 0, g2 = 0, t2 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {       // the truth tables of cmp_planes (qs_count.hip): greater-than / less-than steps
+                g1 = __builtin_amdgcn_bitop3_b32(l1[k], r[(k + u) % 6], g1, 0xb2);
+                t1 = __builtin_amdgcn_bitop3_b32(l1[k], r[(k + u) % 6], t1, 0x8e);
+                g2 = __builtin_amdgcn_bitop3_b32(l2[k], r[(k + u) % 6], g2, 0xb2);
+                t2 = __builtin_amdgcn_bitop3_b32(l2[k], r[(k + u) % 6], t2, 0x8e);
+            }
+            c0 += (uint32_t)__builtin_popcount(g1); c1 += (uint32_t)__builtin_popcount(t1);
+            c2 += (uint32_t)__builtin_popcount(g2); c3 += (uint32_t)__builtin_popcount(t2);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c0 ^ c1 ^ c2 ^ c3;
+}
+
+extern "C" int qs_issue_probe(qs_ctx *c, uint32_t iterations, float *ns_per_instruction) {
+    if (!c || !ns_per_instruction || iterations == 0) return fail(c, QS_ERR_ARG, "qs_issue_probe: bad argument");
+    QS_HIP(c, hipSetDevice(c->device));
+    if (c->n_cu == 0) { int v = 0; QS_HIP(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cu = std::max(1, v); }
+    const uint32_t blocks = (uint32_t)c->n_cu * 4u;              // 4 workgroups of 4 waves per CU = 4 waves per SIMD
+    uint32_t *buf = nullptr;
+    QS_HIP(c, hipMalloc((void **)&buf, (1024 + (size_t)blocks * 256) * 4));
+    std::vector<uint32_t> host(1024);
+    uint32_t x = 0x9E3779B9u;
+    for (uint32_t &w : host) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; w = x; }   // random operands: all-zero words let the clock rise
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMemcpyAsync(buf, host.data(), 4096, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.f;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(issue_probe_kernel, dim3(blocks), dim3(256), 0, c->stream, buf, buf + 1024, iterations);   // warm-up: clocks, code object
+        e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) { hipLaunchKernelGGL(issue_probe_kernel, dim3(blocks), dim3(256), 0, c->stream, buf, buf + 1024, iterations); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(c, QS_ERR_HIP, std::string("qs_issue_probe: ") + hipGetErrorString(e));
+    // per SIMD: 4 waves x iterations x 4 slots x 28 instructions
+    *ns_per_instruction = ms * 1e6f / ((float)iterations * 4.f * 28.f * 4.f);
+    return QS_OK;
+}
+
 // ---- batches -----------------------------------------------------------------------------
 
 extern "C" void qs_batch_free(qs_ctx *c, qs_device_batch *b) {

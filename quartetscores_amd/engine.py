@@ -97,6 +97,12 @@ class Context:
         self._chk(self.L.qs_table_attach(self.h, C.c_void_p(tensor.data_ptr()), nbytes))
         self._attached = tensor
 
+    def issue_probe(self, iterations: int = 100000) -> float:
+        """qs_issue_probe: ns per wave instruction and SIMD of the count kernel's bare instruction slot on this device."""
+        out = C.c_float(0)
+        self._chk(self.L.qs_issue_probe(self.h, iterations, C.byref(out)))
+        return float(out.value)
+
     def sum_words(self, dst, sources):
         """qs_sum_words: dst += sum of the source tensors, as 32-bit words (torch CUDA tensors of equal size; the sources may
         live on peer devices this process has enabled access to); asynchronous."""

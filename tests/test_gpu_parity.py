@@ -1576,3 +1576,15 @@ def test_rooted_reference_soak_against_the_oracle(eng, monkeypatch, seed):
         assert set(got) == set(want)
         for k in got:
             assert got[k] == want[k], (n, m, kw, route, exact, sorted(k), got[k], want[k])
+
+
+def test_issue_probe_reports_a_plausible_rate(eng):
+    """qs_issue_probe: the bare instruction slot of the count kernel (24 v_bitop3 + 4 v_bcnt, registers only, 4 waves per SIMD):
+    between 1.0 and 2.5 ns per wave instruction and SIMD on any MI355X (1.39-1.40 on the boxes of profiles/r03_valu_yardstick.txt);
+    twice the iterations take twice the time."""
+    ctx = eng.Context(8, 32)
+    a = ctx.issue_probe(20000)
+    b = ctx.issue_probe(40000)
+    assert 1.0 < a < 2.5 and 1.0 < b < 2.5, (a, b)
+    assert abs(a / b - 1.0) < 0.1, (a, b)
+    ctx.close()
