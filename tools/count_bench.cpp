@@ -93,12 +93,6 @@ int main(int argc, char **argv) {
         const double nq = c4(dhi ? dhi : n) - c4(dlo);
         printf("%-44s %-44s count %9.4f ms (min %9.4f, %d launches)  panel %8.4f ms  %.3e q/s  checksum %016llx\n", argv[li], qs_last_count_variant(c),
                cnt[cnt.size() / 2], cnt[0], launches, pan[pan.size() / 2], nq * (double)m / (cnt[cnt.size() / 2] * 1e-3), (unsigned long long)sum);
-        if (auto dbg = (int (*)(unsigned long long *))dlsym(h, "qs_debug_stamps")) {   // diagnostic builds (QS_EXP & 32)
-            unsigned long long st[8];
-            if (dbg(st) == 0 && st[0])
-                printf("    stamps over %llu waves (all launches since load): loop %.0f cycles per wave, at the barrier %.1f %%, draining panel loads %.1f %%\n",
-                       st[0], (double)st[1] / st[0], 100.0 * st[2] / st[1], 100.0 * st[3] / st[1]);
-        }
         fflush(stdout);
         qs_batch_free(c, db);
         qs_destroy(c);
