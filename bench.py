@@ -842,12 +842,12 @@ def main():
     mode = head if head in MODES else ("mixed" if head == "mixed" else None)
     # minimal VALU lane-operations per (tree, quartet) of the bit-sliced four-point test, DESIGN.md 3.1:
     #   binary_full: [L > R] and [L < R] over B+1 planes (2 v_bitop3 per plane) + 2 v_bcnt per 32 trees
-    #   binary_partial: + 2 presence masks + 1 combine (the third topology = what is left of the trees holding all four) + 1 v_bcnt
-    #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 combine + 1 v_bcnt; partial: + 3 presence masks + presence AND
+    #   binary_partial: + 1 presence AND + 2 masks + 1 v_bcnt (the trees holding all four; the third topology is that minus the other two)
+    #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 v_bcnt; partial: + 3 presence masks + presence AND
     # The batch is counted in classes (mode of a tree x bits B of its deepest LCA)
     def ops_of(bits_, mode_):
-        return {"binary_full": 2 * (bits_ + 1) + 2, "binary_partial": 2 * (bits_ + 1) + 6,
-                "general_full": 3 * (bits_ + 1) + 4, "partial": 3 * (bits_ + 1) + 8}[mode_]
+        return {"binary_full": 2 * (bits_ + 1) + 2, "binary_partial": 2 * (bits_ + 1) + 5,
+                "general_full": 3 * (bits_ + 1) + 3, "partial": 3 * (bits_ + 1) + 7}[mode_]
     POPS = {"binary_full": 2, "binary_partial": 3, "general_full": 3, "partial": 3}
     classes = []                                     # (bits, trees, mode)
     for mo_, b_, cnt_ in re.findall(r"(?:(binary_full|binary_partial|general_full|partial)\.)?bitslice_b(\d+)(?:x2)?(?::(\d+))?", variant):

@@ -726,7 +726,6 @@ template <int TT> __device__ __forceinline__ uint32_t lut3(uint32_t a, uint32_t 
 constexpr int kTT_XOR3 = 0xF0 ^ 0xCC ^ 0xAA;                                  // a ^ b ^ c
 constexpr int kTT_LT = ((0x0F & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (~a & b) | (~(a ^ b) & c): borrow / less-than step
 constexpr int kTT_GT = ((0xF0 & 0x33) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;      // (a & ~b) | (~(a ^ b) & c): greater-than step
-constexpr int kTT_NOR_AND = (0xF0 & ~(0xCC | 0xAA)) & 0xFF;                   // a & ~(b | c)
 
 // LDS image with HW (1, 2, 4 or 8) upper words per slot: words 0..3 at buf[e], the upper words in an array
 // of HW-word records behind the `stride` 16-byte slots
@@ -1039,7 +1038,8 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     const uint32_t group_bytes = npairs * (uint32_t)(NW * 4), hi_base = npairs * 16u;
 
     // counters per d slot: x0 / x1 = ab|cd, ac|bd of (a1,b); y0 / y1 the same of (a2,b); z0 / z1 = ad|bc of (a1,b) / (a2,b)
-    // (binary_full: the third count is m minus the other two, z0 / z1 stay unused).
+    // (binary_full: the third count is m minus the other two, z0 / z1 stay unused; binary_partial: z0 / z1 count the trees that
+    // hold all four taxa and the third count is that minus the other two).
     uint32_t x0[kDB], x1[kDB], y0[kDB], y1[kDB], z0[kDB], z1[kDB];
 #pragma unroll
     for (int j = 0; j < kDB; ++j) x0[j] = x1[j] = y0[j] = y1[j] = z0[j] = z1[j] = 0;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                     if (BP) {
                         const uint32_t v = L1.w[kPres] & Rb.w[kPres];   // a1, b, c, d all present
                         gt &= v; lt &= v;
-                        popc_acc(lut3<kTT_NOR_AND>(v, gt, lt), z0[j]);   // a binary tree that holds all four resolves the quartet
+                        popc_acc(v, z0[j]);   // trees that hold all four: a binary one resolves the quartet, so ad|bc = this count - the other two (epilogue)
                     }
                     popc_acc(gt, x0[j]);
                     popc_acc(lt, x1[j]);
@@ -1127,14 +1127,16 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                         if (BP) {
                             const uint32_t v2 = L2.w[kPres] & Rb.w[kPres];
                             gt2 &= v2; lt2 &= v2;
-                            popc_acc(lut3<kTT_NOR_AND>(v2, gt2, lt2), z1[j]);
+                            popc_acc(v2, z1[j]);
                         }
                         popc_acc(gt2, y0[j]);
                         popc_acc(lt2, y1[j]);
                     }
                 } else {
                     const Planes Ra = lload(cur, j * RC + colA1);    // M[a1 d] - M[cd] + 2^B
-                    uint32_t g3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra, G1), gt, lt); // S1 == S2 and S3 > S1
+                    // [S3 > S1]. In a tree the two smaller of the three sums are equal (four-point condition), so S3 > S1 already
+                    // implies S1 == S2: no masking with ~(gt | lt) (round 4: one instruction per quartet less)
+                    uint32_t g3 = gt_planes<NB>(Ra, G1);
                     if (PART) {
                         const uint32_t v = L1.w[kPres] & Rb.w[kPres]; // a1, b, c, d all present
                         gt &= v; lt &= v; g3 &= v;
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                         const Planes Ra2 = lload(cur, j * RC + colA2);
                         uint32_t gt2, lt2;
                         cmp_planes<NB>(L2, Rb, gt2, lt2);
-                        uint32_t h3 = lut3<kTT_NOR_AND>(gt_planes<NB>(Ra2, G2), gt2, lt2);
+                        uint32_t h3 = gt_planes<NB>(Ra2, G2);
                         if (PART) {
                             const uint32_t v2 = L2.w[kPres] & Rb.w[kPres];
                             gt2 &= v2; lt2 &= v2; h3 &= v2;
@@ -1243,14 +1245,14 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         if (d < d1 && d > c) {
             if (v1) {
                 const uint64_t idx = (base + pi1) * 3;
-                uint32_t w0 = x0[j], w1 = x1[j], w2 = MODE == MODE_BINARY_FULL ? m_trees - x0[j] - x1[j] : z0[j];
+                uint32_t w0 = x0[j], w1 = x1[j], w2 = MODE == MODE_BINARY_FULL ? m_trees - x0[j] - x1[j] : BP ? z0[j] - x0[j] - x1[j] : z0[j];
                 if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 store_tuple(table + idx, w0, w1, w2);
             }
             if (v2) {
                 const uint64_t idx = (base + pi2) * 3;
-                uint32_t w0 = y0[j], w1 = y1[j], w2 = MODE == MODE_BINARY_FULL ? m_trees - y0[j] - y1[j] : z1[j];
+                uint32_t w0 = y0[j], w1 = y1[j], w2 = MODE == MODE_BINARY_FULL ? m_trees - y0[j] - y1[j] : BP ? z1[j] - y0[j] - y1[j] : z1[j];
                 if (!overwrite) { const Tuple3<CT> t = load_tuple(table + idx); w0 += t.a; w1 += t.b; w2 += t.c; }
                 if (sizeof(CT) == 2 && ((w0 | w1 | w2) > 0xFFFFu)) atomicOr(overflow_flag, 1u);
                 store_tuple(table + idx, w0, w1, w2);
