@@ -1588,3 +1588,37 @@ def test_issue_probe_reports_a_plausible_rate(eng):
     assert 1.0 < a < 2.5 and 1.0 < b < 2.5, (a, b)
     assert abs(a / b - 1.0) < 0.1, (a, b)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["F2", "four_modes"])
+@pytest.mark.parametrize("split_classes", [False, True])
+def test_modes_fixture_on_the_gpu(eng, monkeypatch, case, split_classes):
+    """The committed fixtures of tests/golden/modes.json (F2 of SURVEY 8(c): taxon dropout + collapsed edges; all four kernel
+    modes interleaved in one batch): table hash in canonical taxon order and every internal edge's LQ/QP/EQP-IC as hex doubles --
+    with the default class floors (the small classes join the most general mode) and with every mode in a class of its own."""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+    from helpers import remap_table
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = json.load(open(os.path.join(here, "modes.json")))[case]
+    spec = importlib.util.spec_from_file_location("make_modes_fixture", os.path.join(here, "make_modes_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    trees = mod.trees_of(fx)
+    assert synth.reference_tree(fx["n"], fx["ref_seed"]) == fx["ref"] and trees[0] == fx["first_tree"] and trees[-1] == fx["last_tree"]
+    if split_classes:
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
+    qsc = eng.QuartetScoreComputer(fx["ref"], trees, device=0)
+    v = qsc.quartetCounterLookup.ctx.last_count_variant()
+    assert ("gather/mixed/" in v) == split_classes, v
+    names = list(qsc.ref.names)
+    perm = [names.index(f"t{i}") for i in range(fx["n"])]
+    table = remap_table(qsc.quartetCounterLookup.table(), perm).astype("<u4")
+    assert int(table.astype(np.uint64).sum()) == fx["checksum"]
+    assert hashlib.sha256(np.ascontiguousarray(table).tobytes()).hexdigest() == fx["table_sha256"]
+    got = {",".join(sorted(k, key=lambda s: int(s[1:]))): [float(x).hex() for x in v_]
+           for k, v_ in qsc.scores_by_bipartition().items()}
+    assert got == fx["scores_lq_qp_eqp_hex"]

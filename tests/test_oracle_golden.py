@@ -222,3 +222,16 @@ def test_config1_fixture_is_reproduced_by_the_oracle():
     got = mod.build()
     want = json.load(open(os.path.join(here, "config1.json")))
     assert got == want
+
+
+def test_modes_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/modes.json (SURVEY 8(c) fixture F2: dropout + collapsed edges; a batch interleaving all four kernel modes),
+    frozen by make_modes_fixture.py: the oracle and the tree generator of today still give the committed table hashes and scores."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_modes_fixture", os.path.join(here, "make_modes_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.build() == json.load(open(os.path.join(here, "modes.json")))
