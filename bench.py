@@ -327,6 +327,37 @@ def run_cli_e2e(ref_nw, eval_text, threads=8):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# kernel variant -> classes and the minimal instruction count the roofline prices
+#   "gather/<mode>/bitslice_b4x2:2358+bitslice_b5x2:7642/count_u32", or classes of several modes:
+#   "gather/mixed/binary_full.bitslice_b4x2:120+binary_partial.bitslice_b5x2:80+.../count_u32"
+MODES = ("binary_full", "binary_partial", "general_full", "partial")
+POPS = {"binary_full": 2, "binary_partial": 3, "general_full": 3, "partial": 3}        # v_bcnt per (quartet, 32 trees)
+
+
+def ops_of(bits_, mode_):
+    """Minimal VALU wave-instructions per (quartet, 32 trees) of the bit-sliced four-point test, DESIGN.md 3.1:
+      binary_full:    [L > R] and [L < R] over B+1 planes (2 v_bitop3 per plane) + 2 v_bcnt
+      binary_partial: + 1 presence AND + 2 masks + 1 v_bcnt (the trees holding all four; the third topology is that minus the other two)
+      general_full:   + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 v_bcnt;   partial: + 3 presence masks + the presence AND"""
+    return {"binary_full": 2 * (bits_ + 1) + 2, "binary_partial": 2 * (bits_ + 1) + 5,
+            "general_full": 3 * (bits_ + 1) + 3, "partial": 3 * (bits_ + 1) + 7}[mode_]
+
+
+def parse_variant(variant, m):
+    """(mode | "mixed" | None, [(depth bits, trees, mode)], mean minimal instructions per (quartet, 32 trees) or None)."""
+    import re
+    head = variant.split("/")[1] if variant.count("/") >= 2 else ""
+    mode = head if head in MODES else ("mixed" if head == "mixed" else None)
+    classes = []
+    for mo_, b_, cnt_ in re.findall(r"(?:(binary_full|binary_partial|general_full|partial)\.)?bitslice_b(\d+)(?:x2)?(?::(\d+))?", variant):
+        classes.append((int(b_), int(cnt_) if cnt_ else m, mo_ or mode))
+    ops32 = None
+    if classes and "depth_u" not in variant and mode and all(mo_ in MODES for _, _, mo_ in classes):
+        ops32 = sum(ops_of(b_, mo_) * cnt_ for b_, cnt_, mo_ in classes) / float(sum(cnt_ for _, cnt_, _ in classes))
+    return mode, classes, ops32
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def kernel_source_sha():
     h = hashlib.sha256()
     for fn in ("qs_count.hip", "qs_common.hpp"):
@@ -835,27 +866,9 @@ def main():
     units_per_launch = m * nq / launches
     launch_ms = count_ms / launches
     import re
-    # kernel variant: "gather/<mode>/bitslice_b4x2:2358+bitslice_b5x2:7642/count_u32", or classes of several modes:
-    # "gather/mixed/binary_full.bitslice_b4x2:120+binary_partial.bitslice_b5x2:80+..."
-    MODES = ("binary_full", "binary_partial", "general_full", "partial")
-    head = variant.split("/")[1] if variant.count("/") >= 2 else ""
-    mode = head if head in MODES else ("mixed" if head == "mixed" else None)
-    # minimal VALU lane-operations per (tree, quartet) of the bit-sliced four-point test, DESIGN.md 3.1:
-    #   binary_full: [L > R] and [L < R] over B+1 planes (2 v_bitop3 per plane) + 2 v_bcnt per 32 trees
-    #   binary_partial: + 1 presence AND + 2 masks + 1 v_bcnt (the trees holding all four; the third topology is that minus the other two)
-    #   general_full: + [M[ad]-M[cd] > M[ab]-M[bc]] (B+1) + 1 v_bcnt; partial: + 3 presence masks + presence AND
-    # The batch is counted in classes (mode of a tree x bits B of its deepest LCA)
-    def ops_of(bits_, mode_):
-        return {"binary_full": 2 * (bits_ + 1) + 2, "binary_partial": 2 * (bits_ + 1) + 5,
-                "general_full": 3 * (bits_ + 1) + 3, "partial": 3 * (bits_ + 1) + 7}[mode_]
-    POPS = {"binary_full": 2, "binary_partial": 3, "general_full": 3, "partial": 3}
-    classes = []                                     # (bits, trees, mode)
-    for mo_, b_, cnt_ in re.findall(r"(?:(binary_full|binary_partial|general_full|partial)\.)?bitslice_b(\d+)(?:x2)?(?::(\d+))?", variant):
-        classes.append((int(b_), int(cnt_) if cnt_ else m, mo_ or mode))
+    mode, classes, ops32 = parse_variant(variant, m)
     depth_bits = max((b_ for b_, _, _ in classes), default=None)
-    ops32 = None
-    if classes and "depth_u" not in variant and mode:
-        ops32 = sum(ops_of(b_, mo_) * cnt_ for b_, cnt_, mo_ in classes) / float(sum(cnt_ for _, cnt_, _ in classes))
+    import re
     wl_name = (f"configs[{cfg_no}]" if not custom else "custom")
     workload_key = f"n{n}_m{m}_u{count_bits}_shard{d_lo}-{d_hi}_{'ladder' if args.shape == 'ladder' else 'nni' if args.nni else 'random'}" + ("" if binary_full_trees else f"_c{args.collapse}_d{args.dropout}" + ("_mixed" if args.mixed else ""))
     out = {

@@ -77,3 +77,21 @@ def test_a_rank_refuses_a_world_size_that_contradicts_gpus():
     env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     p = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_the_roofline_prices_every_class_with_its_own_mode():
+    """bench.parse_variant: the kernel variant string -> (depth bits, trees, mode) classes and the mean minimal instruction count
+    per (quartet, 32 trees): 2(B+1)+2 for full binary trees, 2(B+1)+5 with missing taxa, 3(B+1)+3 / +7 for multifurcating trees."""
+    sys.path.insert(0, ROOT)
+    import bench
+    mode, classes, ops = bench.parse_variant("gather/binary_full/bitslice_b4x2:2428+bitslice_b5x2:7572/count_u32", 10000)
+    assert mode == "binary_full" and classes == [(4, 2428, "binary_full"), (5, 7572, "binary_full")]
+    assert abs(ops - (12 * 2428 + 14 * 7572) / 10000) < 1e-12
+    mode, classes, ops = bench.parse_variant("gather/binary_partial/bitslice_b5x2/count_u32", 1500)
+    assert mode == "binary_partial" and classes == [(5, 1500, "binary_partial")] and ops == 17
+    mode, classes, ops = bench.parse_variant("gather/mixed/binary_partial.bitslice_b5x2:1000+general_full.bitslice_b5x2:500/count_u32", 1500)
+    assert mode == "mixed" and classes == [(5, 1000, "binary_partial"), (5, 500, "general_full")]
+    assert abs(ops - (17 * 1000 + 21 * 500) / 1500) < 1e-12
+    assert bench.parse_variant("gather/partial/bitslice_b4x2:1418+bitslice_b5x2:82/count_u16", 1500)[2] == (22 * 1418 + 25 * 82) / 1500
+    assert bench.parse_variant("gather/partial/depth_u16/count_u32", 40)[2] is None          # byte-SWAR kernel: priced against HBM
+    assert bench.parse_variant("scatter/atomic/count_u32", 40) == (None, [], None)
