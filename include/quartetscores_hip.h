@@ -310,7 +310,9 @@ int qs_score(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags, double *lqic, 
 /* Optional: what a first qs_score / qs_score_pass1 does before its kernels (reference tree and LCA matrix on the device, log
  * table for n_trees_total trees, round tables, accumulators with their pinned host copy, the candidate log), ahead of time.
  * May be called while count kernels of this context are still in flight (from the context's host thread): it uses the
- * copy stream and never waits for the count stream. The CLI calls it behind its last qs_count_batch. */
+ * copy stream and does not wait for the count stream -- with one exception: if the context already caches a DIFFERENT
+ * reference tree, replacing it waits for the count stream first (kernels may still read the old one). The copy stream is
+ * drained on every exit path, also on errors. The CLI calls it behind its last qs_count_batch. */
 int qs_score_prepare(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t n_trees_total);
 
 /*
