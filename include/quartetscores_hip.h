@@ -194,6 +194,11 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_CLASS_PCT 15u         /* batches are counted class by class (kernel mode of a tree x its depth bits); a class holding less than this
                                        * share of the trees, or fewer than QS_TUNE_CLASS_MIN_TREES, joins a more general mode / the next deeper
                                        * class: every class costs a table pass (default 10) */
+#define QS_TUNE_DEPTH_CLAMP 17u       /* depth clamp: a tree may be counted in a class BELOW its own depth bits (its LCA depths cut at the class's
+                                       * largest value; the quartets the cut ties -- three leaves below one node of that depth -- are added by a
+                                       * correction kernel with atomics) when that costs at most `value` millionths of C(n,4) (tree, quartet)
+                                       * corrections per depth bit saved (default 20; 16 x that for the trees of a class too small for a pass of
+                                       * its own); 0 = every tree in the class of its own depth bits. Read by qs_batch_upload. */
 #define QS_TUNE_CLASS_MIN_TREES 16u   /* ... and the absolute floor of a class (default 1024 trees; tests lower it to split small batches) */
 #define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel, shape of the table loads: 0 (default) = every lane loads its own row in 16-byte pieces;
                                        * 2 = ... and requests the next chunk before it processes the current one; 1 = eight lanes load the
@@ -383,6 +388,17 @@ int qs_raw_qic_lex(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t i0, uint64_t nq
  * qs_last_count_launches: how many count-kernel launches [1] covers (0 if the call was not timed). */
 int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 int qs_last_count_launches(const qs_ctx *ctx);
+/* ... and the share of [1] spent in the depth-clamp correction kernels (QS_TUNE_DEPTH_CLAMP; 0 without clamped trees). */
+float qs_last_count_fix_ms(qs_ctx *ctx);
+/* Depth clamp of an uploaded batch: out[0] = trees counted in a class below their own depth bits, out[1] = the (tree, quartet)
+ * corrections they cost, out[2] = workgroups of the correction kernel. */
+int qs_batch_clamp_info(const qs_device_batch *batch, uint64_t out[3]);
+/* Host-only (runs without a GPU): the per-tree class plan qs_batch_upload applies for n_taxa taxa and the budget `ppm`
+ * (QS_TUNE_DEPTH_CLAMP): own_bits[t] = depth bits of tree t's deepest LCA (4 .. 10, 11 = deeper), class_bits[t] = depth bits of the
+ * cheapest class the budget allows it, corrections[t] = (tree, quartet) corrections of that choice. Any output may be NULL.
+ * The reference's loop is shape-independent (QuartetCounterLookup.hpp:65-106): this replaces nothing there. */
+int qs_depth_clamp_plan(uint32_t n_taxa, const qs_tree_batch *batch, uint32_t ppm, uint8_t *own_bits, uint8_t *class_bits,
+                        uint64_t *corrections);
 /* Phases of the most recent qs_score call in milliseconds: [0] the whole call (host clock), [1] set-up (accumulator
  * allocation, reference tree + LCA matrix, log table: near zero once cached in the context), [2] pass 1 and [3] pass 2
  * (HIP events on the context's stream; [3] = the filter over pass 1's candidate log in single-read mode), [4] host wait for the passes incl. the overflow pass and the accumulators' way

@@ -19,6 +19,7 @@ QS_SCORE_CAND_SLOTS = 8
 QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
 QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD, QS_TUNE_CLASS_PCT, QS_TUNE_CLASS_MIN_TREES = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
+QS_TUNE_DEPTH_CLAMP = 17
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 
 # every symbol include/quartetscores_hip.h declares
@@ -29,7 +30,7 @@ EXPORTS = [
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
     "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
-    "qs_sum_words", "qs_issue_probe",
+    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan",
 ]
 
 
@@ -163,5 +164,11 @@ def load():
     L.qs_score_plan.argtypes = [u32, u64, u64, vp, vp, vp]
     L.qs_last_count_variant.restype = C.c_char_p
     L.qs_last_count_variant.argtypes = [vp]
+    L.qs_last_count_fix_ms.restype = C.c_float
+    L.qs_last_count_fix_ms.argtypes = [vp]
+    L.qs_batch_clamp_info.restype = i32
+    L.qs_batch_clamp_info.argtypes = [vp, C.POINTER(u64 * 3)]
+    L.qs_depth_clamp_plan.restype = i32
+    L.qs_depth_clamp_plan.argtypes = [u32, C.POINTER(TreeBatchC), u32, vp, vp, vp]
     _lib = L
     return L

@@ -23,6 +23,7 @@ using namespace qs;
 
 struct qs_device_batch {
     DeviceBatch d;
+    std::vector<uint32_t> fix_slot;   // depth clamp: slot (in the class-ordered batch) of the tree behind every correction unit, ascending
 };
 
 // the reference tree, flattened and indexed for scoring (build_ref)
@@ -77,7 +78,7 @@ struct qs_ctx {
     size_t panel_bytes = 0;
     uint32_t *dev_flags = nullptr; // [0] counter overflow, [1] score flags, [3] two-cell wire format: tuple sum mismatch
     std::vector<hipEvent_t> evs;   // QS_COUNT_TIMED: evs[0] = start, then one event after every kernel launch
-    std::vector<uint8_t> ev_kind;  // per event after evs[0]: 0 = panel build, 1 = count kernel
+    std::vector<uint8_t> ev_kind;  // per event after evs[0]: 0 = panel build, 1 = count kernel, 2 = depth-clamp corrections (clamp_fix_kernel)
     uint32_t ev_used = 0;
     bool last_timed = false;
     // qs_set_tuning
@@ -132,6 +133,7 @@ struct qs_ctx {
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
     uint32_t tune_class_min = 1024;              // QS_TUNE_CLASS_MIN_TREES
     uint32_t tune_class_pct = 10;                // QS_TUNE_CLASS_PCT: a depth class below this share of the batch's trees is merged into the next one
+    uint32_t tune_clamp_ppm = 20;                // QS_TUNE_DEPTH_CLAMP: corrections a tree may cost per depth bit it saves, in millionths of C(n,4); 0 = no clamp
     uint32_t tune_score_load = 0;                // QS_TUNE_SCORE_LOAD: 0 = a lane loads its row in 16-byte pieces, 1 = eight lanes load a row's chunk (LDS hand-over)
     uint32_t tune_score_dedupe = 1;              // QS_TUNE_SCORE_DEDUPE: the logging pass skips a quartet that repeats its node pair's last logged triple
     uint32_t tune_score_sample = 64u | 65536u;             // QS_TUNE_SCORE_SAMPLE: pre-pass of the single-read scoring (0 = none; S | by-round bit 16)
@@ -365,6 +367,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
             c->tune_score_sample = (uint32_t)value; return QS_OK;
         }
         case QS_TUNE_CLASS_MIN_TREES: c->tune_class_min = (uint32_t)std::min<uint64_t>(value, 0xFFFFFFFFull); return QS_OK;
+        case QS_TUNE_DEPTH_CLAMP: c->tune_clamp_ppm = (uint32_t)std::min<uint64_t>(value, 1000000ull); return QS_OK;
         case QS_TUNE_CLASS_PCT: if (value > 100) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_CLASS_PCT takes 0 .. 100"); c->tune_class_pct = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_LOAD: if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3"); c->tune_score_load = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
@@ -850,6 +853,68 @@ struct Stager {
     }
 };
 
+// ---- depth clamp (qs_count.hip clamp_fix_kernel) -----------------------------------------------------------------------------
+// (tree, quartet) corrections a tree costs when its LCA depths are cut at `cut`: the quartets with at least three leaves in one
+// maximal run of tour-adjacent LCA depths >= cut (a subtree below a node of depth `cut`): C(s,3)(L - s) + C(s,4) per run of s
+// leaves. ~0 when a run is longer than the kernel's LDS table takes. runs (optional): (first position, leaves) of every run.
+constexpr uint32_t kClampMaxRun = 64;   // = kFixMaxRun of qs_count.hip
+static uint64_t clamp_cost(const uint16_t *adj, uint32_t L, uint32_t cut, std::vector<std::pair<uint32_t, uint32_t>> *runs) {
+    uint64_t cost = 0;
+    for (uint32_t i = 0; i + 1 < L;) {
+        if (adj[i] < cut) { ++i; continue; }
+        uint32_t j = i;
+        while (j + 1 < L && adj[j] >= cut) ++j;
+        const uint64_t s_ = (uint64_t)(j - i) + 1;
+        if (s_ >= 3) {
+            if (s_ > kClampMaxRun) return ~0ull;
+            cost += binom3(s_) * (L - s_) + binom4(s_);
+            if (runs) runs->emplace_back(i, (uint32_t)s_);
+        }
+        i = j;
+    }
+    return cost;
+}
+static uint32_t depth_class_of(uint32_t depth) {   // depth bits of a tree's class: 4 .. 10, 11 = beyond the bit-sliced instances
+    uint32_t bb = 1;
+    while ((1u << bb) <= depth) ++bb;
+    return bb <= 4 ? 4u : (bb <= 10 ? bb : 11u);
+}
+// The cheapest class (depth bits) a tree may be counted in: its own, or a lower one when the corrections of the cut stay within
+// `budget_per_bit` (tree, quartet) pairs per bit saved -- soft: the rule for every tree; hard (16 x): for the trees of a class
+// that would otherwise be too small to pay for its own pass over the table.
+static void clamp_choice(const uint16_t *adj, uint32_t L, uint32_t own_bits, uint64_t budget_per_bit, uint8_t &soft, uint8_t &hard) {
+    soft = hard = (uint8_t)own_bits;
+    if (budget_per_bit == 0 || own_bits <= 4) return;
+    for (uint32_t tb = 4; tb < own_bits; ++tb) {
+        const uint64_t cost = clamp_cost(adj, L, (1u << tb) - 1u, nullptr);
+        if (cost == ~0ull) continue;
+        const uint64_t bits_saved = own_bits - tb;
+        if (hard == own_bits && cost <= 16 * budget_per_bit * bits_saved) hard = (uint8_t)tb;
+        if (cost <= budget_per_bit * bits_saved) { soft = (uint8_t)tb; return; }
+    }
+}
+
+/* Host-only (no device call): the class plan of qs_batch_upload for the trees of `hb` on n_taxa taxa with the depth-clamp budget
+ * `ppm` (QS_TUNE_DEPTH_CLAMP): per tree its own depth bits, the depth bits of the cheapest class the budget allows, and the
+ * (tree, quartet) corrections that class costs. For tests and tools; qs_batch_upload applies the same functions. */
+extern "C" int qs_depth_clamp_plan(uint32_t n_taxa, const qs_tree_batch *hb, uint32_t ppm, uint8_t *own_bits, uint8_t *class_bits,
+                                   uint64_t *corrections) {
+    if (!hb || !hb->leaf_off || (hb->n_trees && !hb->adj_depth) || n_taxa < 4) return QS_ERR_ARG;
+    const uint64_t budget = (uint64_t)((double)binom4(n_taxa) * (double)ppm * 1e-6);
+    for (uint32_t t = 0; t < hb->n_trees; ++t) {
+        const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
+        uint32_t depth = 0;
+        for (uint32_t i = 0; i + 1 < L; ++i) depth = std::max<uint32_t>(depth, hb->adj_depth[base + i]);
+        const uint32_t own = depth_class_of(depth);
+        uint8_t soft, hard;
+        clamp_choice(hb->adj_depth + base, L, own, budget, soft, hard);
+        if (own_bits) own_bits[t] = (uint8_t)own;
+        if (class_bits) class_bits[t] = soft;
+        if (corrections) corrections[t] = soft < own ? clamp_cost(hb->adj_depth + base, L, (1u << soft) - 1u, nullptr) : 0;
+    }
+    return QS_OK;
+}
+
 extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_batch **out) {
     if (!c || !hb || !out) return fail(c, QS_ERR_ARG, "qs_batch_upload: NULL argument");
     *out = nullptr;
@@ -861,6 +926,8 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     struct Part { uint32_t max_depth = 0; bool all_full = true, all_binary = true; uint32_t err_tree = 0xFFFFFFFFu; std::string err; };
     std::vector<uint16_t> tree_depth(nt, 0); // deepest LCA of every tree
     std::vector<uint8_t> tree_mode(nt, 0);   // CountMode of every tree: the cheapest kernel instance that is exact for it
+    std::vector<uint8_t> eff_soft(nt, 0), eff_hard(nt, 0);   // depth clamp: the lowest class (depth bits) the budget allows the tree (clamp_choice)
+    const uint64_t clamp_budget = (uint64_t)((double)binom4(n) * (double)c->tune_clamp_ppm * 1e-6);
     auto check = [&](uint32_t t0, uint32_t t1, Part &P) {
         std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
         std::vector<uint32_t> stack;
@@ -890,6 +957,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
             const bool binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
             if (!binary) P.all_binary = false;
             tree_mode[t] = (uint8_t)(L == n ? (binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL) : (binary ? MODE_BINARY_PARTIAL : MODE_PARTIAL));
+            clamp_choice(hb->adj_depth + base, L, depth_class_of(tree_depth[t]), clamp_budget, eff_soft[t], eff_hard[t]);
         }
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -926,16 +994,18 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     // partial; binary_partial, general_full -> partial), then a depth class joins the next deeper one of its mode.
     // (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
     std::vector<uint32_t> order_host;
+    std::vector<FixUnit> fix_units;
     {
         constexpr uint32_t top_bits = 10, deep = 11;   // depth class id = depth bits; `deep` = beyond the bit-sliced instances
         constexpr uint32_t kModes = 4, kBits = 12;
-        auto cls_of = [&](uint32_t depth) { uint32_t bb = 1; while ((1u << bb) <= depth) ++bb; return bb <= 4 ? 4u : (bb <= top_bits ? bb : deep); };
+        // Depth clamp: a tree may sit in a class BELOW its own depth bits -- the panel builders cut its depths at the class's
+        // largest value and clamp_fix_kernel adds the quartets the cut ties (qs_count.hip) -- when that costs less than the
+        // instructions it saves (eff_soft: 2 of 2(B+1)+2 per bit and quartet against a few thousand atomics per tree).
         uint32_t cnt[kModes][kBits] = {{0}}, mx[kModes][kBits] = {{0}};
         std::vector<uint8_t> cls(nt);
         for (uint32_t t = 0; t < nt; ++t) {
-            cls[t] = (uint8_t)cls_of(tree_depth[t]);
+            cls[t] = eff_soft[t];
             cnt[tree_mode[t]][cls[t]]++;
-            mx[tree_mode[t]][cls[t]] = std::max<uint32_t>(mx[tree_mode[t]][cls[t]], tree_depth[t]);
         }
         const uint32_t small = std::max<uint32_t>(c->tune_class_min, (uint32_t)((uint64_t)nt * c->tune_class_pct / 100));
         uint32_t mode_map[kModes] = {0, 1, 2, 3};
@@ -953,6 +1023,17 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
         join_mode(MODE_BINARY_FULL, {MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL});
         join_mode(MODE_BINARY_PARTIAL, {MODE_PARTIAL});
         join_mode(MODE_GENERAL_FULL, {MODE_PARTIAL});
+        auto final_mode = [&](uint32_t mo) { while (mode_map[mo] != mo) mo = mode_map[mo]; return mo; };
+        // a class too small for a pass of its own: its trees go DOWN to a class that is large enough where the 16-fold budget allows
+        // it (what is left joins the next deeper class below, as before)
+        if (c->tune_clamp_ppm)
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t mo = final_mode(tree_mode[t]), bb = cls[t];
+                if (cnt[mo][bb] >= small || eff_hard[t] >= bb) continue;
+                for (uint32_t lo = bb - 1; lo >= eff_hard[t] && lo >= 4; --lo)
+                    if (cnt[mo][lo] >= small) { cnt[mo][bb]--; cnt[mo][lo]++; cls[t] = (uint8_t)lo; break; }
+            }
+        for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(tree_mode[t]); mx[mo][cls[t]] = std::max<uint32_t>(mx[mo][cls[t]], tree_depth[t]); }
         uint32_t remap[kModes][kBits];
         for (uint32_t mo = 0; mo < kModes; ++mo) {
             for (uint32_t bb = 0; bb < kBits; ++bb) remap[mo][bb] = bb;
@@ -964,7 +1045,6 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
                 cnt[mo][up] += cnt[mo][bb]; mx[mo][up] = std::max(mx[mo][up], mx[mo][bb]); cnt[mo][bb] = 0; remap[mo][bb] = up;
             }
         }
-        auto final_mode = [&](uint32_t mo) { while (mode_map[mo] != mo) mo = mode_map[mo]; return mo; };
         auto final_cls = [&](uint32_t mo, uint32_t k) { while (remap[mo][k] != k) k = remap[mo][k]; return k; };
         d.n_classes = 0;
         uint32_t run = 0, start[kModes][kBits] = {{0}};
@@ -983,6 +1063,31 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
         if (d.n_classes > 1) {
             order_host.resize(nt);
             for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(tree_mode[t]); order_host[start[mo][final_cls(mo, cls[t])]++] = t; }
+        }
+        // correction units of the trees whose class holds fewer depth bits than they need, by slot (a slice of a class = a range of
+        // slots = a range of units). One unit = one workgroup = a stretch of a run's triples worth ~32 K fourth leaves.
+        if (c->tune_clamp_ppm) {
+            std::vector<std::pair<uint32_t, uint32_t>> runs;
+            auto emit = [&](uint32_t slot, uint32_t t) {
+                const uint32_t mo = final_mode(tree_mode[t]), fb = final_cls(mo, cls[t]);
+                if (fb > top_bits || depth_class_of(tree_depth[t]) <= fb) return;
+                const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
+                runs.clear();
+                const uint64_t cost = clamp_cost(hb->adj_depth + base, L, (1u << fb) - 1u, &runs);
+                if (cost == ~0ull) return;   // cannot happen: the cut of a lower class was accepted, and runs only shrink with the cut
+                d.fix_quartets += cost; d.clamped_trees++;
+                const uint32_t per_unit = std::max<uint32_t>(1u, 32768u / std::max<uint32_t>(L, 1u));
+                for (const auto &r : runs) {
+                    const uint32_t triples = (uint32_t)binom3(r.second);
+                    for (uint32_t t0 = 0; t0 < triples; t0 += per_unit) {
+                        fix_units.push_back(FixUnit{t, r.first | (r.second << 16), t0, std::min(triples, t0 + per_unit)});
+                        b->fix_slot.push_back(slot);
+                    }
+                }
+            };
+            if (order_host.empty()) for (uint32_t t = 0; t < nt; ++t) emit(t, t);
+            else for (uint32_t sl = 0; sl < nt; ++sl) emit(sl, order_host[sl]);
+            d.n_fix = (uint32_t)fix_units.size();
         }
     }
     // scatter batches: the tree of every inner node, and a bounds check of the leaf ranges (host side, before any copy)
@@ -1007,7 +1112,8 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     hipError_t e = hipSetDevice(c->device);
     Stager st;
     if (e == hipSuccess) {
-        size_t need = Stager::padded(((size_t)nt + 1) * 4) + 2 * Stager::padded((size_t)d.total_leaves * 2) + Stager::padded(order_host.size() * 4);
+        size_t need = Stager::padded(((size_t)nt + 1) * 4) + 2 * Stager::padded((size_t)d.total_leaves * 2) + Stager::padded(order_host.size() * 4) +
+                      Stager::padded(fix_units.size() * sizeof(FixUnit));
         if (with_nodes) need += Stager::padded(((size_t)nt + 1) * 4) + Stager::padded(((size_t)d.n_nodes + 1) * 4) + Stager::padded((size_t)d.n_nodes * 4) + Stager::padded((size_t)2 * d.n_links * 2);
         e = st.begin(c, need);
     }
@@ -1016,6 +1122,7 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
         d.leaf_ids = st.put(hb->leaf_ids, d.total_leaves);
         d.adj_depth = st.put(hb->adj_depth, d.total_leaves);
         if (!order_host.empty()) d.tree_order = st.put(order_host.data(), order_host.size());
+        if (!fix_units.empty()) d.fix_units = st.put(fix_units.data(), fix_units.size());
         if (with_nodes) {
             d.node_off = st.put(hb->node_off, (size_t)nt + 1);
             d.rng_off = st.put(hb->rng_off, (size_t)d.n_nodes + 1);
@@ -1036,6 +1143,14 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
 extern "C" uint32_t qs_batch_flags(const qs_device_batch *b) {
     if (!b) return 0;
     return (b->d.all_full ? QS_BATCH_ALL_TAXA : 0u) | (b->d.all_binary ? QS_BATCH_BINARY : 0u);
+}
+
+// corrections of the depth clamp for the trees in slots [slot_lo, slot_hi) of the batch, after their count kernel
+static hipError_t clamp_fix_slots(qs_ctx *c, const qs_device_batch *b, uint32_t slot_lo, uint32_t slot_hi, int mode, uint32_t *wire) {
+    const auto lo = std::lower_bound(b->fix_slot.begin(), b->fix_slot.end(), slot_lo), hi = std::lower_bound(lo, b->fix_slot.end(), slot_hi);
+    if (lo == hi) return hipSuccess;
+    return launch_clamp_fix(c->stream, b->d, b->d.fix_units + (lo - b->fix_slot.begin()), (uint32_t)(hi - lo), std::max(c->d_lo, 3u), c->d_hi,
+                            c->rank_lo, c->table, (int)c->count_bits, mode, wire);
 }
 
 // QS_COUNT_WIRE16X2: count a binary_full batch straight into the attached wire buffer (one word per tuple)
@@ -1089,11 +1204,13 @@ static int count_batch_wire(qs_ctx *c, const qs_device_batch *b, uint32_t algo) 
             QS_HIP(c, launch_count_bitslice3(c->stream, g, c->panel, (int)depth_bits, MODE_BINARY_FULL, nch, nt, nullptr, 32, c->dev_flags,
                                              overwrite && first, c->wire_out));
             if (timed) QS_HIP(c, mark(c, 1));
+            if (d.n_fix) { QS_HIP(c, clamp_fix_slots(c, b, sub.slot0, sub.slot0 + nt, MODE_BINARY_FULL, c->wire_out)); if (timed) QS_HIP(c, mark(c, 2)); }
             first = false;
         }
         c->variant += (k ? "+b" : "b") + std::to_string(depth_bits) + "x2" + (d.n_classes > 1 ? ":" + std::to_string(s_hi - s_lo) : "");
     }
     c->variant += "/wire_u16x2";
+    if (d.n_fix) c->variant += "/clamp:" + std::to_string(d.clamped_trees);
     if (c->n_coop) c->variant += "/coop4";
     c->wire_trees = (overwrite ? 0 : c->wire_trees) + d.n_trees;
     c->last_timed = timed;
@@ -1203,6 +1320,10 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 else QS_HIP(c, launch_count_gather(c->stream, g, c->panel, bits, mode, nch, nt, c->table, (int)c->count_bits, c->dev_flags, overwrite && first));
                 first = false;
                 if (timed) QS_HIP(c, mark(c, 1));
+                if (use_bitslice && d.n_fix) {   // (never with QS_IMPL_SWAR: the byte panel holds the trees' own depths)
+                    QS_HIP(c, clamp_fix_slots(c, b, sub.slot0, sub.slot0 + nt, mode, nullptr));
+                    if (timed) QS_HIP(c, mark(c, 2));
+                }
             }
             // kernel variant of the class; several classes: "a:trees+b:trees", classes of several modes: "mode.a:trees+..."
             std::string nm = use_bitslice ? "bitslice_b" + std::to_string(std::max(depth_bits, 4u)) + (bin_tiles ? "x2" : "")
@@ -1214,6 +1335,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         const int one_mode = all_swar ? batch_mode : (int)d.class_mode[0];
         c->variant = std::string("gather/") + (mixed ? "mixed" : mode_names[(!all_swar && d.class_bits[0] > top_bits && one_mode == MODE_BINARY_PARTIAL) ? (int)MODE_PARTIAL : one_mode]) + "/" + names + "/count_u" + std::to_string(c->count_bits);
         if (any_coop) c->variant += "/coop4";   // tiles with two a-blocks of binary_full classes: count_bitslice4_kernel
+        if (!all_swar && d.n_fix) c->variant += "/clamp:" + std::to_string(d.clamped_trees);   // trees counted below their own depth bits + clamp_fix_kernel
     } else if (algo == QS_ALGO_SCATTER) {
         if (!d.node_off) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_ALGO_SCATTER needs node_off/rng_off/ranges in the batch");
         if (c->n > 4096) return fail(c, QS_ERR_UNSUPPORTED, "scatter: n too large");
@@ -1262,7 +1384,7 @@ extern "C" int qs_last_count_ms(qs_ctx *c, float out_ms[3]) {
     for (uint32_t i = 1; i < c->ev_used; ++i) {
         float ms = 0.f;
         QS_HIP(c, hipEventElapsedTime(&ms, c->evs[i - 1], c->evs[i]));
-        out_ms[c->ev_kind[i] ? 1 : 0] += ms;
+        out_ms[c->ev_kind[i] ? 1 : 0] += ms;   // (the depth-clamp corrections count as count-kernel time: qs_last_count_fix_ms has their share)
     }
     QS_HIP(c, hipEventElapsedTime(&out_ms[2], c->evs[0], c->evs[c->ev_used - 1]));
     return QS_OK;
@@ -1271,8 +1393,25 @@ extern "C" int qs_last_count_ms(qs_ctx *c, float out_ms[3]) {
 extern "C" int qs_last_count_launches(const qs_ctx *c) {
     if (!c || !c->last_timed) return 0;
     int k = 0;
-    for (uint32_t i = 1; i < c->ev_used; ++i) k += c->ev_kind[i] ? 1 : 0;
+    for (uint32_t i = 1; i < c->ev_used; ++i) k += c->ev_kind[i] == 1 ? 1 : 0;
     return k;
+}
+
+extern "C" float qs_last_count_fix_ms(qs_ctx *c) {
+    if (!c || !c->last_timed || c->ev_used < 2) return 0.f;
+    if (hipEventSynchronize(c->evs[c->ev_used - 1]) != hipSuccess) return 0.f;
+    float sum = 0.f;
+    for (uint32_t i = 1; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        if (c->ev_kind[i] == 2 && hipEventElapsedTime(&ms, c->evs[i - 1], c->evs[i]) == hipSuccess) sum += ms;
+    }
+    return sum;
+}
+
+extern "C" int qs_batch_clamp_info(const qs_device_batch *b, uint64_t out[3]) {
+    if (!b || !out) return QS_ERR_ARG;
+    out[0] = b->d.clamped_trees; out[1] = b->d.fix_quartets; out[2] = b->d.n_fix;
+    return QS_OK;
 }
 
 extern "C" const char *qs_last_count_variant(const qs_ctx *c) { return c ? c->variant.c_str() : ""; }

@@ -511,7 +511,9 @@ __global__ __launch_bounds__(kBPThreads) void build_bitpanel_kernel(const uint32
             for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
             for (uint32_t i = lane; i < L; i += kWave) {
                 pos[leaf_ids[base + i]] = (uint16_t)i;
-                st[i] = (DT)adj_depth[base + i];
+                // depths beyond the planes of this class are cut at the largest value they hold (trees placed in a class below
+                // their own depth bits: depth clamp, clamp_fix_kernel); cut before the narrowing store, min() commutes with it
+                st[i] = (DT)min((uint32_t)adj_depth[base + i], (1u << kPlanes) - 1u);
             }
             for (uint32_t k = 1; k < levels; ++k) {
                 const uint32_t half = 1u << (k - 1), span = 1u << k;
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const uint32_t g = blockIdx.y, p0 = blockIdx.x * kBPSThreads;
     constexpr int kWaves = kBPSThreads / kWave;
+    constexpr int kPlanes = PARTIAL ? NWC - 1 : NWC; // partial elements end with the presence word
 
     for (int j = (int)wave; j < kBitTrees; j += kWaves) {
         const uint32_t slot = g * kBitTrees + j;
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
         for (uint32_t x = lane; x < n; x += kWave) pos[x] = 0xFFFFu;
         for (uint32_t i = lane; i < L; i += kWave) {
             pos[leaf_ids[base + i]] = (uint16_t)i;
-            st[i] = (uint8_t)adj_depth[base + i];
+            st[i] = (uint8_t)min((uint32_t)adj_depth[base + i], (1u << kPlanes) - 1u);   // (depth clamp, as in build_bitpanel_kernel)
         }
         for (uint32_t k = 1; k < levels; ++k) {
             const uint32_t half = 1u << (k - 1), span = 1u << k;
@@ -606,7 +609,6 @@ __global__ __launch_bounds__(kBPSThreads) void build_bitpanel_small_kernel(const
     if (p >= npairs) return;
     uint32_t x, y;
     unrank2(p, x, y);
-    constexpr int kPlanes = PARTIAL ? NWC - 1 : NWC; // partial elements end with the presence word
     uint32_t w[kBitWords];
 #pragma unroll
     for (int k = 0; k < kBitWords; ++k) w[k] = 0;
@@ -1622,6 +1624,107 @@ hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n,
     else
         hipLaunchKernelGGL(count_scatter_kernel<uint16_t>, grid, block, 0, s, b.leaf_off, b.leaf_ids, b.node_tree, b.rng_off,
                            b.ranges, d_lo, d_hi, rank_lo, (uint16_t *)table);
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// depth clamp: the corrections of trees counted in a class below their own depth bits
+// ======================================================================================
+// The bit-sliced kernel's work per (quartet, 32 trees) is 2(B+1)+2 instructions with B the depth bits of the CLASS. The
+// four-point test does not need depths: any labelling of the inner nodes that grows strictly along every root-to-leaf path
+// gives the same answers, and one that grows WEAKLY gives either the same answer or "all three sums equal" -- never a
+// wrong topology (the two equal sums of a quartet are equal by node identity). So a tree whose deepest LCA needs B+1 bits
+// can be counted in the B-bit class with every depth cut at 2^B - 1 (the panel builders do that), at the price of the
+// quartets the cut ties: exactly those with at least THREE leaves below one node of depth 2^B - 1 -- in centred random
+// trees a handful of small subtrees (512 taxa: 76 % of the trees need 5 bits, median 5 600 such quartets of 2.8e9 per
+// tree). In the tour arrays such a subtree is a maximal run of adjacent-LCA depths >= 2^B - 1 (qs_abi.hip plan_depth_clamp
+// finds them and decides per tree whether the cut pays). This kernel adds what the cut lost: for every triple (i < j < k)
+// of a run and every fourth leaf -- outside the run: the triple's cherry pairs up, the topology follows from the two
+// adjacent LCA depths of the triple alone; inside the run behind k: the four-point rule on the three adjacent depths --
+// one atomic increment of the true topology's cell; in the binary modes the count kernel has put the tied quartet into
+// the third cell (n2 = trees - n0 - n1), so that cell is decremented when the true topology is another one.
+// Workgroup = one unit = (tree, run, a stretch of the run's triples in colex order); threads = the fourth leaves.
+// Replaces nothing in the reference: its loop is shape-independent (QuartetCounterLookup.hpp:65-106).
+constexpr int kFixMaxRun = 64;      // leaves of a run (longer runs: the tree keeps its own depth class)
+constexpr int kFixThreads = 256;
+enum FixRule { FIX_BINARY = 0, FIX_GENERAL = 1, FIX_WIRE = 2 };
+
+template <typename CT> __device__ __forceinline__ void table_atomic_dec(CT *table, uint64_t cell);
+template <> __device__ __forceinline__ void table_atomic_dec<uint32_t>(uint32_t *table, uint64_t cell) { atomicSub(&table[cell], 1u); }
+template <> __device__ __forceinline__ void table_atomic_dec<uint16_t>(uint16_t *table, uint64_t cell) {
+    // the cell holds at least the tied quartet's own count at this point (the count kernel of the slice ran before): no borrow
+    uint32_t *w = reinterpret_cast<uint32_t *>(table) + (cell >> 1);
+    atomicSub(w, (cell & 1) ? 0x10000u : 1u);
+}
+
+template <typename CT, int RULE>
+__global__ __launch_bounds__(kFixThreads) void clamp_fix_kernel(const FixUnit *__restrict__ units, const uint32_t *__restrict__ leaf_off,
+                                                                const uint16_t *__restrict__ leaf_ids, const uint16_t *__restrict__ adj_depth,
+                                                                uint32_t d_lo, uint32_t d_hi, uint64_t rank_lo, CT *__restrict__ table,
+                                                                uint32_t *__restrict__ wire) {
+    __shared__ uint16_t ids[kScatterMaxLeaves];
+    __shared__ uint16_t rm[kFixMaxRun][kFixMaxRun];   // rm[a][b], a < b: LCA depth of the run's leaves a and b
+    const FixUnit u = units[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = leaf_off[u.tree], L = leaf_off[u.tree + 1] - base;
+    const uint32_t i0 = u.run & 0xFFFFu, s = u.run >> 16;
+    for (uint32_t i = tid; i < L; i += kFixThreads) ids[i] = leaf_ids[base + i];
+    for (uint32_t a = tid; a + 1 < s; a += kFixThreads) {
+        uint32_t m = 0xFFFFu;
+        for (uint32_t b = a + 1; b < s; ++b) { m = min(m, (uint32_t)adj_depth[base + i0 + b - 1]); rm[a][b] = (uint16_t)m; }
+    }
+    __syncthreads();
+    // triple t_lo in colex order: t = C(k,3) + C(j,2) + i, i < j < k
+    uint32_t k = 2, rest = u.t_lo;
+    while ((uint32_t)binom3(k + 1) <= rest) ++k;
+    rest -= (uint32_t)binom3(k);
+    uint32_t j = 1;
+    while ((uint32_t)binom2(j + 1) <= rest) ++j;
+    uint32_t i = rest - (uint32_t)binom2(j);
+    const uint32_t n_out = L - s;
+    for (uint32_t t = u.t_lo; t < u.t_hi; ++t) {
+        const uint32_t mij = rm[i][j], mjk = rm[j][k];
+        const uint32_t x1 = ids[i0 + i], x2 = ids[i0 + j], x3 = ids[i0 + k];
+        const uint32_t n_in = s - 1 - k;
+        // fourth leaf outside the run: cherry (x1,x2) if lca(i,j) is the deeper one, (x2,x3) if lca(j,k) is; equal: the triple is
+        // unresolved in the tree itself (a multifurcation), nothing to add
+        const uint32_t q0 = mij != mjk ? 0u : n_out;
+        for (uint32_t q = q0 + tid; q < n_out + n_in; q += kFixThreads) {
+            uint32_t pa, pb, oa, ob;   // the tree displays pa pb | oa ob
+            if (q < n_out) {
+                const uint32_t x = ids[q < i0 ? q : q + s];
+                if (mij > mjk) { pa = x1; pb = x2; oa = x3; ob = x; } else { pa = x2; pb = x3; oa = x1; ob = x; }
+            } else {
+                const uint32_t l = k + 1 + (q - n_out), x4 = ids[i0 + l];
+                const uint32_t mkl = rm[k][l], mx = max(mij, mkl);
+                if (mjk < mx) { pa = x1; pb = x2; oa = x3; ob = x4; }
+                else if (mjk > mx) { pa = x1; pb = x4; oa = x2; ob = x3; }
+                else continue;
+            }
+            const uint32_t lo1 = min(pa, pb), hi1 = max(pa, pb), lo2 = min(oa, ob), hi2 = max(oa, ob);
+            const uint32_t s0 = min(lo1, lo2), s3 = max(hi1, hi2), m1 = max(lo1, lo2), m2 = min(hi1, hi2);
+            if (s3 < d_lo || s3 >= d_hi) continue;
+            const uint32_t s1 = min(m1, m2), s2 = max(m1, m2);
+            const int slot = slot_of_pairing(pa, pb, oa, ob);
+            const uint64_t tup = rank4(s0, s1, s2, s3) - rank_lo;
+            if (RULE == FIX_WIRE) { if (slot < 2) atomicAdd(&wire[tup], slot ? 0x10000u : 1u); }   // n0 | n1 << 16; n2 is implied
+            else if (RULE == FIX_GENERAL) table_atomic_inc<CT>(table, tup * 3 + (uint64_t)slot);    // the tie counted nothing
+            else if (slot != 2) { table_atomic_inc<CT>(table, tup * 3 + (uint64_t)slot); table_atomic_dec<CT>(table, tup * 3 + 2); }
+        }
+        if (++i == j) { i = 0; if (++j == k) { j = 1; ++k; } }
+    }
+}
+
+hipError_t launch_clamp_fix(hipStream_t s, const DeviceBatch &b, const FixUnit *units, uint32_t n_units, uint32_t d_lo, uint32_t d_hi,
+                            uint64_t rank_lo, void *table, int count_bits, int mode, uint32_t *wire) {
+    if (n_units == 0) return hipSuccess;
+    dim3 grid(n_units), block(kFixThreads);
+    const bool gen = mode == MODE_GENERAL_FULL || mode == MODE_PARTIAL;
+#define QS_FIX(CT, RULE) hipLaunchKernelGGL((clamp_fix_kernel<CT, RULE>), grid, block, 0, s, units, b.leaf_off, b.leaf_ids, b.adj_depth, d_lo, d_hi, rank_lo, (CT *)table, wire)
+    if (wire) QS_FIX(uint32_t, FIX_WIRE);
+    else if (count_bits == 32) { if (gen) QS_FIX(uint32_t, FIX_GENERAL); else QS_FIX(uint32_t, FIX_BINARY); }
+    else { if (gen) QS_FIX(uint16_t, FIX_GENERAL); else QS_FIX(uint16_t, FIX_BINARY); }
+#undef QS_FIX
     return hipGetLastError();
 }
 

@@ -27,6 +27,10 @@ constexpr uint32_t kMaxDepthU16Partial = 8191;
 // the batch was freed (the slab is handed to a later upload, whose copy waits for it)
 struct BatchSlab { void *p = nullptr; size_t cap = 0; hipEvent_t last_use = nullptr; };
 
+// one workgroup of clamp_fix_kernel (qs_count.hip): the triples [t_lo, t_hi) (colex order) of the run of `run >> 16` leaves that
+// starts at tour position `run & 0xFFFF` of tree `tree`
+struct FixUnit { uint32_t tree, run, t_lo, t_hi; };
+
 struct DeviceBatch {
     uint32_t n_trees = 0;
     uint32_t total_leaves = 0;
@@ -51,6 +55,12 @@ struct DeviceBatch {
     uint32_t n_nodes = 0, n_links = 0;
     uint32_t *node_off = nullptr, *rng_off = nullptr, *node_tree = nullptr;
     uint16_t *ranges = nullptr;
+    // depth clamp (qs_abi.hip plan_depth_clamp): the correction units of the trees counted in a class below their own depth bits,
+    // ordered by the tree's slot in the class-ordered batch (qs_device_batch::fix_slot = that slot per unit, host)
+    FixUnit *fix_units = nullptr;   // device
+    uint32_t n_fix = 0;
+    uint64_t fix_quartets = 0;      // (tree, quartet) corrections of the whole batch
+    uint32_t clamped_trees = 0;
     BatchSlab slab;                 // owns the arrays above
     hipEvent_t ready = nullptr;     // fires when the batch's arrays have arrived (copy stream); the count waits for it
 };
@@ -83,6 +93,8 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite, uint32_t *wire); // wire != NULL (binary_full only): one word n0 | n1 << 16 per tuple instead of the table
+hipError_t launch_clamp_fix(hipStream_t s, const DeviceBatch &b, const FixUnit *units, uint32_t n_units, uint32_t d_lo, uint32_t d_hi,
+                            uint64_t rank_lo, void *table, int count_bits, int mode, uint32_t *wire); // corrections of the depth clamp (after the class's count kernel)
 uint32_t bitslice3_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of count_bitslice3_kernel
 hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n, uint32_t d_lo, uint32_t d_hi,
                                 uint64_t rank_lo, void *table, int count_bits);

@@ -218,6 +218,16 @@ class Context:
     def last_count_launches(self) -> int:
         return int(self.L.qs_last_count_launches(self.h))
 
+    def last_count_fix_ms(self) -> float:
+        """Share of last_count_ms()[1] spent in the depth-clamp correction kernels (QS_TUNE_DEPTH_CLAMP)."""
+        return float(self.L.qs_last_count_fix_ms(self.h))
+
+    def batch_clamp_info(self, hb) -> Tuple[int, int, int]:
+        """(trees counted in a class below their own depth bits, their (tree, quartet) corrections, correction workgroups)."""
+        out = (C.c_uint64 * 3)()
+        self._chk(self.L.qs_batch_clamp_info(hb, C.byref(out)))
+        return tuple(int(x) for x in out)
+
     def set_tuning(self, key: int, value: int):
         """qs_set_tuning: _lib.QS_TUNE_PANEL_SLICE_BYTES / QS_TUNE_GATHER_IMPL / QS_TUNE_PANEL_KERNEL (A/B runs, tests)."""
         self._chk(self.L.qs_set_tuning(self.h, key, value))

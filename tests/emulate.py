@@ -200,3 +200,57 @@ def scores_from_table(ref, T, qp_exact64=False):
         if len(edges) == 1:
             qp[edges[0]] = val
     return np.array(lq), np.array(qp), np.array(eqp)
+
+
+# ---- depth clamp of the bit-sliced count classes (qs_abi.hip plan_depth_clamp, qs_count.hip clamp_fix_kernel) ----
+
+def clamp_runs(adj_depth, L, clamp):
+    """Maximal runs of tour-adjacent LCA depths >= clamp: (first leaf position, leaves) of every subtree whose root sits at
+    depth `clamp` and that holds at least three leaves. With all labels cut at `clamp` the four-point test of a tree calls a
+    quartet unresolved exactly when three of its leaves lie in one such subtree (otherwise it answers as before)."""
+    runs, i, D = [], 0, [int(x) for x in adj_depth[: max(L - 1, 0)]]
+    while i < len(D):
+        if D[i] >= clamp:
+            j = i
+            while j < len(D) and D[j] >= clamp:
+                j += 1
+            if j - i + 1 >= 3:
+                runs.append((i, j - i + 1))
+            i = j
+        else:
+            i += 1
+    return runs
+
+
+def clamp_corrections(leaf_ids, adj_depth, clamp):
+    """The (sorted quartet, table slot) list the correction kernel adds for ONE tree whose labels were cut at `clamp`:
+    every quartet with >= 3 leaves in one run that the tree resolves, with its true topology."""
+    def slot_of_pairing(x, y, z, w):      # qs_common.hpp: position of the minimum's partner among the sorted ids, minus 1
+        partner = {x: y, y: x, z: w, w: z}[min(x, y, z, w)]
+        return sorted((x, y, z, w)).index(partner) - 1
+    L = len(leaf_ids)
+    ids = [int(x) for x in leaf_ids]
+    D = [int(x) for x in adj_depth[: max(L - 1, 0)]]
+    out = []
+    for i0, s in clamp_runs(adj_depth, L, clamp):
+        rm = lambda a, b: min(D[i0 + a: i0 + b])      # LCA depth of run positions a < b
+        for i in range(s):
+            for j in range(i + 1, s):
+                for k in range(j + 1, s):
+                    mij, mjk = rm(i, j), rm(j, k)
+                    x1, x2, x3 = ids[i0 + i], ids[i0 + j], ids[i0 + k]
+                    # fourth leaf outside the run: the triple's cherry decides
+                    if mij != mjk:
+                        pair, third = ((x1, x2), x3) if mij > mjk else ((x2, x3), x1)
+                        for p in list(range(0, i0)) + list(range(i0 + s, L)):
+                            x = ids[p]
+                            out.append((tuple(sorted((x1, x2, x3, x))), slot_of_pairing(pair[0], pair[1], third, x)))
+                    # fourth leaf inside the run, behind k (every inside quartet once)
+                    for l in range(k + 1, s):
+                        mkl, x4 = rm(k, l), ids[i0 + l]
+                        mx = max(mij, mkl)
+                        if mjk < mx:
+                            out.append((tuple(sorted((x1, x2, x3, x4))), slot_of_pairing(x1, x2, x3, x4)))
+                        elif mjk > mx:
+                            out.append((tuple(sorted((x1, x2, x3, x4))), slot_of_pairing(x1, x4, x2, x3)))
+    return out

@@ -460,6 +460,136 @@ def test_deep_ladders_9_and_10_bits(eng, monkeypatch, n, bits, kind):
     sys.setrecursionlimit(old_limit)
 
 
+def _ladder(n, order=None):
+    order = list(range(n)) if order is None else order
+    cat = f"(t{order[0]},t{order[1]})"
+    for i in order[2:]:
+        cat = "(" + cat + f",t{i})"
+    return cat + ";"
+
+
+@pytest.mark.parametrize("kind", ["binary_full", "binary_partial", "general_full", "partial"])
+@pytest.mark.parametrize("count_bits", [32, 16])
+def test_depth_clamp_counts_bit_exact(eng, monkeypatch, kind, count_bits):
+    """Depth clamp (QS_TUNE_DEPTH_CLAMP): trees counted in a class BELOW their own depth bits -- their LCA depths cut at the class's
+    largest value by the panel builders, the quartets the cut ties (three leaves below one node of that depth) added by
+    clamp_fix_kernel -- give the oracle's table, in every kernel mode and both cell widths: ladders and ladder + NNI trees of
+    44 taxa (up to 42 LCA levels, cut at 15: one run of 28 leaves, or two runs when recentred) among random trees that fit
+    the class as they are. The reference's loop is shape-independent (QuartetCounterLookup.hpp:65-106)."""
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_DEPTH_CLAMP, 1000000)     # any price per bit
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
+    n = 44
+    ref_nw = synth.reference_tree(n, 4400)
+    ref = flatten.flatten_reference(ref_nw)
+    rng = np.random.default_rng(44)
+    kw = {"binary_full": {}, "general_full": {"collapse": 0.2}, "partial": {"dropout": 0.1, "collapse": 0.15}, "binary_partial": {"dropout": 0.1}}[kind]
+    deep = [_ladder(n, list(rng.permutation(n))) for _ in range(3)]
+    deep += synth.nni_tree_set(deep[0], 12, 4401, mean_nni=5)
+    if kind in ("general_full", "partial"):       # multifurcations inside the cut subtrees as well
+        deep += [t.replace("(((t", "((t", 1).replace("),", ",", 1) for t in deep[:3]]
+    trees = deep + synth.tree_set(n, 20, 4402, **kw)
+    for recentre in (False, True):
+        batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=recentre)
+        ctx = eng.Context(n, count_bits)
+        ctx.table_alloc()
+        hb = ctx.batch_upload(batch, with_nodes=False)
+        clamped, quartets, units = ctx.batch_clamp_info(hb)
+        assert clamped >= 10 and quartets > 0 and units >= clamped, (clamped, quartets, units)
+        ctx.count_batch(hb, eng.QS_ALGO_GATHER)
+        ctx.sync()
+        v = ctx.last_count_variant()
+        assert f"/clamp:{clamped}" in v and "bitslice_b4" in v and "bitslice_b5" not in v and "bitslice_b6" not in v, v
+        T = ctx.table_download()
+        ctx.batch_free(hb)
+        o = oracle_counts(ref_nw, trees)
+        assert (T.astype(np.uint64) == o.counts()).all(), (kind, count_bits, recentre)
+    # the same batch without the clamp: the deep trees keep their own classes, same table
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_DEPTH_CLAMP, 0)
+    ctx, T0 = gpu_table(eng, ref, batch, count_bits)
+    assert "/clamp" not in ctx.last_count_variant() and (T0 == T).all()
+
+
+def test_depth_clamp_budget_and_long_runs(eng, monkeypatch):
+    """The clamp's decisions: the default budget (20 millionths of C(n,4) per bit saved) leaves a ladder alone (its cut subtree
+    is most of the tree), a run of more than 64 leaves is never cut whatever the budget, accumulation over two uploads and
+    several panel slices per class keep the corrections with their slice, and a table shard takes only its own quartets."""
+    n = 90
+    ref_nw = synth.reference_tree(n, 9000)
+    ref = flatten.flatten_reference(ref_nw)
+    trees = [_ladder(n)] * 2 + synth.tree_set(n, 30, 9001)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)     # ladder: 88 levels (7 bits), cut at 15: a run of 74
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    assert ctx.batch_clamp_info(hb)[0] == 0                                     # default budget: nothing is cut at this size
+    ctx.batch_free(hb)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_DEPTH_CLAMP, 1000000)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER)
+    ctx.sync()
+    v = ctx.last_count_variant()
+    # cut at 63 (6 bits) the ladder's run is 26 leaves, at 31 (5 bits) 58: allowed; at 15 it is 74 > 64: never
+    assert "bitslice_b5" in v and "bitslice_b7" not in v and "/clamp:2" in v, v
+    o = oracle_counts(ref_nw, trees)
+    assert (ctx.table_download().astype(np.uint64) == o.counts()).all()
+    ctx.batch_free(hb)
+    # recentred ladders + NNIs: accumulate two uploads, 3 panel slices per class, on two table shards
+    trees2 = synth.nni_tree_set(_ladder(n), 70, 9002, mean_nni=4) + synth.tree_set(n, 40, 9003)
+    batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id)
+    assert int(batch2.adj_depth.max()) >= 32
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_SLICE_BYTES, int(n * (n - 1) / 2) * 16 * 2)   # two tree groups per slice
+    want = oracle_counts(ref_nw, trees2).counts()
+    lo_tuples = 0
+    for d_lo, d_hi in ((0, 70), (70, n)):
+        c2 = eng.Context(n, 16, d_lo=d_lo, d_hi=d_hi)
+        c2.table_alloc()
+        for lo, hi in ((0, 50), (50, len(trees2))):
+            hb = c2.batch_upload(batch2.slice(lo, hi), with_nodes=False)
+            assert c2.batch_clamp_info(hb)[0] > 0
+            c2.count_batch(hb, eng.QS_ALGO_GATHER)
+            c2.batch_free(hb)
+        c2.sync()
+        T = c2.table_download().astype(np.uint64)
+        assert (T == want[lo_tuples:lo_tuples + len(T)]).all(), (d_lo, d_hi)
+        lo_tuples += len(T)
+    assert lo_tuples == len(want)
+
+
+def test_depth_clamp_in_the_wire_format(eng, monkeypatch):
+    """QS_COUNT_WIRE16X2 with clamped trees: the corrections go to the wire words (n0 | n1 << 16; n2 is implied)."""
+    import torch
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_DEPTH_CLAMP, 1000000)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
+    n = 40
+    ref_nw = synth.reference_tree(n, 4000)
+    ref = flatten.flatten_reference(ref_nw)
+    trees = synth.nni_tree_set(_ladder(n), 40, 4001, mean_nni=3) + synth.tree_set(n, 25, 4002)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    ctx.count_trees(batch)
+    assert "/clamp:" in ctx.last_count_variant()
+    want = torch.zeros(ctx.table_tuples, dtype=torch.int32, device="cuda")
+    ctx.table_pack16x2(want)
+    ctx.sync()
+    c2 = eng.Context(n, 32)
+    words = torch.zeros(ctx.table_tuples, dtype=torch.int32, device="cuda")
+    c2.wire_attach(words)
+    hb = c2.batch_upload(batch, with_nodes=False)
+    c2.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_WIRE16X2)
+    c2.sync()
+    assert "/clamp:" in c2.last_count_variant() and "wire_u16x2" in c2.last_count_variant()
+    assert torch.equal(words, want)
+    o = oracle_counts(ref_nw, trees)
+    assert (ctx.table_download().astype(np.uint64) == o.counts()).all()
+
+
 def test_batches_accumulate_and_are_deterministic(eng):
     ref_nw, trees = make_case(28, 90, 12)
     ref = flatten.flatten_reference(ref_nw)

@@ -401,3 +401,67 @@ def test_finish_evaluates_a_flagged_candidate_in_both_orders(golden):
     extra = np.array([[key | (1 << 32), trip[0], trip[1], trip[2]]], dtype=np.int64)
     lq, _, _, _ = engine.score_finish_host(ref, sums, cand, 0, extra=extra)
     assert (lq[np.isfinite(lq)] == min(a, b)).all()
+
+
+@pytest.mark.parametrize("n,m,clamp,seed,kw", [(16, 20, 2, 1, {}), (16, 20, 3, 2, {}), (20, 15, 2, 3, {"collapse": 0.3}),
+                                                (20, 15, 2, 4, {"dropout": 0.2}), (18, 15, 1, 5, {"dropout": 0.2, "collapse": 0.3}),
+                                                (24, 10, 3, 6, {"rooted": True})])
+def test_depth_clamp_arithmetic(n, m, clamp, seed, kw):
+    """The depth clamp of the bit-sliced count classes (qs_count.hip clamp_fix_kernel), in numpy: the four-point test on LCA
+    depths CUT at `clamp` answers like the uncut one or not at all (never a wrong topology), and adding one count of the true
+    topology for every quartet with three leaves in one run of adjacent depths >= clamp (emulate.clamp_corrections = the
+    kernel's enumeration) restores the oracle's table -- binary, multifurcating, partial and rooted evaluation trees."""
+    import copy
+    from helpers import rank4
+    ref_nw = synth.reference_tree(n, seed)
+    trees = synth.tree_set(n, m, 100 + seed, **kw)
+    ref = flatten.flatten_reference(ref_nw)
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    assert int(batch.adj_depth.max()) > clamp
+    o = Oracle(ref_nw)
+    o.count("\n".join(trees))
+    want = o.counts().astype(np.int64)
+    cut = copy.deepcopy(batch)
+    cut.adj_depth = np.minimum(cut.adj_depth, clamp).astype(cut.adj_depth.dtype)
+    T = emulate.counts_from_batch(cut, n).astype(np.int64)
+    assert ((T <= want).all()) and (T != want).any()          # the cut only loses counts
+    for t in range(batch.n_trees):
+        lo, hi = int(batch.leaf_off[t]), int(batch.leaf_off[t + 1])
+        for quad, slot in emulate.clamp_corrections(batch.leaf_ids[lo:hi], batch.adj_depth[lo:hi], clamp):
+            T[int(rank4(*quad)), slot] += 1
+    assert (T == want).all()
+
+
+def test_depth_clamp_plan_is_host_only_and_matches_the_emulation():
+    """qs_depth_clamp_plan (the class plan qs_batch_upload applies) runs without a GPU: own depth bits, the class the budget
+    allows, and a correction count equal to the emulation's run enumeration; budget 0 = no clamp; a ladder is never cut at the
+    default budget, and never where its run exceeds 64 leaves."""
+    import ctypes as C
+    from math import comb
+    from quartetscores_amd import _lib
+    L = _lib.load()
+    n = 120
+    ref = flatten.flatten_reference(synth.reference_tree(n, 70))
+    cat = "(t0,t1)"
+    for i in range(2, n):
+        cat = "(" + cat + f",t{i})"
+    trees = synth.tree_set(n, 60, 71) + [cat + ";"]
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)
+    m = batch.n_trees
+
+    def plan(ppm):
+        hb = _lib.TreeBatchC(m, batch.leaf_off.ctypes.data, batch.leaf_ids.ctypes.data, batch.adj_depth.ctypes.data, None, None, None)
+        own, cls, corr = np.zeros(m, np.uint8), np.zeros(m, np.uint8), np.zeros(m, np.uint64)
+        assert L.qs_depth_clamp_plan(n, C.byref(hb), ppm, own.ctypes.data, cls.ctypes.data, corr.ctypes.data) == 0
+        return own, cls, corr
+
+    own, cls, corr = plan(0)
+    assert (own == cls).all() and not corr.any() and own[-1] == 7 and own[:-1].max() >= 5
+    own2, cls2, corr2 = plan(1000000)
+    assert (own2 == own).all() and (cls2[:-1] == 4).all() and cls2[-1] == 6     # ladder: cut at 63 = 57 leaves; at 31 = 89 > 64
+    for t in range(m):
+        lo, hi = int(batch.leaf_off[t]), int(batch.leaf_off[t + 1])
+        runs = emulate.clamp_runs(batch.adj_depth[lo:hi], hi - lo, (1 << int(cls2[t])) - 1) if cls2[t] < own2[t] else []
+        assert sum(comb(s, 3) * (hi - lo - s) + comb(s, 4) for _, s in runs) == corr2[t]
+    own3, cls3, corr3 = plan(20)
+    assert cls3[-1] == own3[-1] and (cls3 <= own3).all() and (corr3 <= 20e-6 * comb(n, 4) * (own3 - cls3)).all()
