@@ -28,8 +28,8 @@ collective_alone_ms}; rank 0 runs the cpu_baseline leg at every N.
 roofline: the dominant kernel is the count kernel. The gather formulation keeps every counter in a
 register and writes each table cell once per panel slice, so it is bound by VALU issue, not by HBM:
     achieved = ALGORITHMIC vector lane-operations per launch (the minimal compare chain of the bit-sliced four-point
-               test per class: (2(B+1)+2)/32 per tree x quartet for full binary trees with B depth bits, 2(B+1)+6 with
-               missing taxa, 3(B+1)+4 / +8 for multifurcating trees) / the kernel's average launch duration, measured live
+               test per class: (2(B+1)+2)/32 per tree x quartet for full binary trees with B depth bits, 2(B+1)+5 with
+               missing taxa, 3(B+1)+3 / +7 for multifurcating trees: ops_of) / the kernel's average launch duration, measured live
                with HIP events on the launch stream around every launch of the LAST timed step (qs_last_count_ms);
     peak     = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles
                per SIMD = the 157.3 TFLOP/s fp32 vector peak / 2 flops).
@@ -76,7 +76,7 @@ def parse_args():
     ap.add_argument("--split-trees", type=int, default=-1, help="1: --trees are split over the ranks (strong scaling); 0: every rank counts --trees of its own")
     ap.add_argument("--algo", choices=["gather", "scatter"], default="gather")
     ap.add_argument("--count-bits", type=int, default=0)
-    ap.add_argument("--cpu-budget-s", type=float, default=8.0, help="seconds of CPU counting per thread setting of the cpu_baseline leg")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="seconds of CPU counting at -t 1 and at the best thread count of the cpu_baseline leg (the scan in between: a tenth each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the e2e legs (CLI child process; steps with the host-array upload inside)")
@@ -96,6 +96,7 @@ def parse_args():
     ap.add_argument("--table-shards", type=int, default=0, help="table-sharded mode: split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=-1, help="table-sharded mode on fewer ranks than shards: which shard this rank owns (default: its rank)")
     ap.add_argument("--slice-bytes", type=int, default=0, help="qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES); 0 = automatic")
+    ap.add_argument("--p2p-leg", type=int, default=-1, help="1: also time the C++ host's peer-access reduction (QuartetScores --gpus N --reduce p2p) in a child before rank 0 uses its GPU; 0: never; -1: at N > 1 on a split workload")
     ap.add_argument("--via-launcher", action="store_true",
                     help="go through the spawn path of --gpus N > 1 even at N = 1 (a fresh torch.distributed.run child; this process never touches the GPU)")
     ap.add_argument("--dry-launch", action="store_true", help="print the child command of the spawn path as one JSON line and exit")
@@ -105,7 +106,7 @@ def parse_args():
 
 # ---------------------------------------------------------------------------------------------------------------
 # `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only the PARENT. It never
-# makes a HIP call (no torch.cuda.* beyond device_count(), which reads the topology without creating a context); it
+# makes a HIP call and never imports torch (the GPUs are counted from the KFD topology in sysfs: visible_gpus); it
 # starts ONE fresh child `python -m torch.distributed.run ... bench.py <same arguments>`, passes the child's stderr
 # through, relays rank 0's JSON line as its own last line of stdout and exits with the child's code. No retry.
 # ---------------------------------------------------------------------------------------------------------------
@@ -127,12 +128,25 @@ def child_command(n_gpus, argv, port=None):
 
 
 def visible_gpus():
-    """GPUs this process could use, WITHOUT initialising the runtime (device_count() only reads the topology)."""
-    try:
-        import torch
-        return int(torch.cuda.device_count())
-    except Exception:
-        return 0
+    """GPUs this process could use, counted WITHOUT torch and without any HIP / HSA call: the KFD topology in sysfs (a node
+    with simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (index lists;
+    UUID entries count as one device each)."""
+    import glob
+    n = 0
+    # (no KFD topology = no amdgpu driver = no GPU: the ROCm runtime enumerates devices from these very files)
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+        except (OSError, ValueError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            listed = [x for x in val.split(",") if x.strip() != ""]
+            n = min(n, len(listed))
+    return n
 
 
 def launch(args, argv):
@@ -208,8 +222,33 @@ def host_info():
             "threads_note": "OpenMP threads are not pinned; beyond one NUMA node's cores the n^4 table's remote accesses cost more than the threads add"[:100]}
 
 
+def numa_node0_cpus():
+    """CPUs of NUMA node 0 that this process may use (sysfs cpulist), or None."""
+    try:
+        with open("/sys/devices/system/node/node0/cpulist") as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        return sorted(cpus) or None
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
 def cpu_child(spec_path):
-    """Times the oracle on a bounded sample; prints one JSON object."""
+    """Times the oracle on a bounded sample; prints one JSON object. The process is pinned to the CPUs of NUMA node 0 and the
+    OpenMP threads are bound to them (OMP_PLACES / OMP_PROC_BIND) BEFORE the oracle's library (libgomp) is loaded: the table is
+    first-touched by those threads, so table and threads share one node."""
+    pinned = numa_node0_cpus()
+    if pinned:
+        try:
+            os.sched_setaffinity(0, pinned)
+        except OSError:
+            pinned = None
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "threads")
     from oracle_api import Oracle
     with open(spec_path) as f:
         spec = json.load(f)
@@ -217,7 +256,10 @@ def cpu_child(spec_path):
         text = f.read()
     n, m, nq, budget = spec["n"], spec["m"], spec["nq"], spec["budget_s"]
     info = host_info()
-    ncpu = info["host_cpus"]
+    ncpu = len(pinned) if pinned else info["host_cpus"]
+    info["pinned"] = (f"NUMA node 0: {len(pinned)} CPUs ({pinned[0]}..{pinned[-1]}), OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES={os.environ['OMP_PLACES']}"
+                      if pinned else "not pinned (no sysfs NUMA topology)")
+    info["threads_note"] = "threads and table on one NUMA node; thread counts beyond the node's CPUs are not run"
     cint_bits = 8 if m < 256 else 16 if m < 65536 else 32               # QuartetScores.cpp:115-147
     fast_bytes = n ** 4 * cint_bits // 8
     # QuartetScoreComputer.hpp:739: the n^4 table unless it exceeds 0.9 x RAM (here: half of what is available, so
@@ -237,11 +279,16 @@ def cpu_child(spec_path):
         out["runs"].append(r)
         return r
 
-    r1 = run(1, budget)
+    r1 = run(1, budget)                                                 # -t 1 for the full budget (>= 30 s by default)
     best = r1
     if not savemem:                                                     # savemem + threads is racy in the reference
-        for th in sorted({min(t, ncpu) for t in (8, 32, 128, ncpu)} - {1}):
-            r = run(th, max(2.0, budget / 2))
+        scan = None
+        for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64, ncpu)} - {1}):   # short scan for the best thread count ...
+            r = run(th, max(2.0, budget / 10))
+            if scan is None or r["value"] > scan["value"]:
+                scan = r
+        if scan is not None:
+            r = run(scan["threads"], budget)                            # ... which then runs for the full budget
             if r["value"] > best["value"]:
                 best = r
     out["t1"] = {"value": r1["value"], "cores": 1}
@@ -270,7 +317,7 @@ def run_cpu_baseline(ref_nw, eval_text, n, m, nq, budget_s):
     env.pop("HIP_VISIBLE_DEVICES", None)
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", sp], capture_output=True, text=True,
-                           timeout=60 + 12 * budget_s, env=env)
+                           timeout=120 + 4 * budget_s, env=env)
         last = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not last:
             return {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed (rc {p.returncode}): {p.stderr[-300:]}"}
@@ -289,9 +336,36 @@ def run_cpu_baseline(ref_nw, eval_text, n, m, nq, budget_s):
             pass
 
 
-def run_cli_e2e(ref_nw, eval_text, threads=8):
+def cli_phases(stdout, stderr):
+    """Phases of one QuartetScores run from what it prints: the two "It took: <us> microseconds." lines of the reference's stdout
+    protocol (counting, scoring) and, with --trace on a multi-GPU run, when all GPUs had counted and how long the table
+    reduction behind that took. None when the protocol lines are missing."""
+    import re
+    took = [int(x) for x in re.findall(r"It took: (\d+) microseconds", stdout)]
+    if len(took) < 2:
+        return None
+    res = {"counting_phase_ms": took[0] / 1e3, "scoring_phase_ms": took[1] / 1e3}
+    stamps = {what.strip(): float(ms) for ms, what in re.findall(r"\[trace\] \+\s*([0-9.]+) ms\s+(main: [^\n]*)", stderr)}
+    if "main: all GPUs counted" in stamps and "main: tables reduced" in stamps:
+        res["all_gpus_counted_at_ms"] = stamps["main: all GPUs counted"]
+        res["table_reduction_ms"] = round(stamps["main: tables reduced"] - stamps["main: all GPUs counted"], 3)
+    return res
+
+
+def same_workload_scaling(value, world, units_per_rank_per_step, count_only_ms, ms_per_step):
+    """What an N > 1 line says about scaling by itself: the ranks' own shares counted without the table collective in the same
+    run (count_only_ms, max over ranks) against the whole-job value."""
+    rate = units_per_rank_per_step / (count_only_ms * 1e-3)
+    return {"count_only_ms_per_step": round(count_only_ms, 3), "units_per_rank_per_step": units_per_rank_per_step,
+            "rate_quartets_per_s": rate, "scaling_efficiency": value / (world * rate),
+            "collective_exposed_ms": round(ms_per_step - count_only_ms, 3),
+            "note": "same ranks, same shares, same run, no table collective (max over ranks)"}
+
+
+def run_cli_e2e(ref_nw, eval_text, threads=8, extra=()):
     """The product's own counting phase (QuartetScores CLI: Newick text on disk -> table in HBM) on the same trees, in a
-    child process, BEFORE this process touches the GPU. Returns the phases the CLI prints (Appendix A protocol)."""
+    child process, BEFORE this process touches the GPU. Returns the phases the CLI prints (Appendix A protocol). `extra`:
+    more CLI arguments (the peer-access leg: --gpus N --reduce p2p --trace; its trace stamps are parsed as well)."""
     import re
     import tempfile
     exe = os.path.join(ROOT, "quartetscores_amd", "bin", "QuartetScores")
@@ -305,13 +379,13 @@ def run_cli_e2e(ref_nw, eval_text, threads=8):
         with open(ep, "wb") as f:
             f.write(eval_text if isinstance(eval_text, bytes) else eval_text.encode())
         t0 = time.perf_counter()
-        p = subprocess.run([exe, "-r", rp, "-e", ep, "-o", op, "-t", str(threads)], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, "-r", rp, "-e", ep, "-o", op, "-t", str(threads)] + list(extra), capture_output=True, text=True, timeout=600)
         wall = time.perf_counter() - t0
-        took = [int(x) for x in re.findall(r"It took: (\d+) microseconds", p.stdout)]
-        if p.returncode != 0 or len(took) < 2:
+        res = cli_phases(p.stdout, p.stderr)
+        if p.returncode != 0 or res is None:
             return {"error": f"rc {p.returncode}: {p.stderr[-200:]}"}
-        return {"counting_phase_ms": took[0] / 1e3, "scoring_phase_ms": took[1] / 1e3, "process_wall_ms": wall * 1e3,
-                "host_threads": threads, "newick_bytes": os.path.getsize(ep)}
+        res.update({"process_wall_ms": wall * 1e3, "host_threads": threads, "newick_bytes": os.path.getsize(ep)})
+        return res
     except Exception as e:  # reported, never required for the metric
         return {"error": str(e)[:200]}
     finally:
@@ -460,6 +534,17 @@ def main():
     cli_e2e = None
     if not args.no_e2e and world == 1 and binary_full_trees and shards == 1 and args.algo == "gather":
         cli_e2e = run_cli_e2e(ref_nw, sample_text)
+    # The peer-access leg (`--p2p-leg`, default at N > 1 on a split workload): the C++ host's communicator-free reduction
+    # (QuartetScores --gpus N --reduce p2p: one process, hipDeviceEnablePeerAccess, qs_sum_words over xGMI) on the SAME trees, as
+    # a child process of rank 0 BEFORE rank 0 touches its GPU (the other ranks wait at the rendezvous with idle devices), so that
+    # one N-GPU run measures the RCCL path (`value`) and the p2p path (`config.p2p_leg`) side by side.
+    p2p_leg = None
+    want_p2p = args.p2p_leg == 1 or (args.p2p_leg < 0 and world > 1 and split)
+    if want_p2p and rank == 0 and binary_full_trees and shards == 1 and args.algo == "gather":
+        p2p_leg = run_cli_e2e(ref_nw, sample_text, threads=0, extra=["--gpus", str(world), "--reduce", "p2p", "--trace"])
+        if p2p_leg.get("counting_phase_ms"):
+            p2p_leg["counting_quartets_per_s"] = m_total * ranks.n_quartets(n) / (p2p_leg["counting_phase_ms"] * 1e-3)
+        p2p_leg["what"] = f"QuartetScores -t 0 --gpus {world} --reduce p2p: Newick on disk -> reduced table, all {m_total} trees"[:100]
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -639,6 +724,9 @@ def main():
     elapsed = t1 - t0
     region_gpu_ms = ev0.elapsed_time(ev1) / max(steps, 1)
     last_step_ms = ctx.last_count_ms() if steps > 0 else None
+    last_fix_ms = ctx.last_count_fix_ms() if steps > 0 else None     # depth-clamp corrections inside count_kernels_ms (QS_TUNE_DEPTH_CLAMP)
+    clamp_info = ctx.batch_clamp_info(hb)
+    last_events = ctx.last_count_events() if steps > 0 else []
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -660,6 +748,30 @@ def main():
         fence()
         coll_alone_ms = (time.perf_counter() - c0) * 1e3 / reps
         step()                              # restore a freshly counted + reduced buffer for the gates below
+        drain()
+        torch.cuda.synchronize(dev)
+    # the SAME ranks count the SAME shares without the table collective, inside this run: what the step costs when nothing is
+    # exchanged (max over ranks). scaling_efficiency = value / (N x one rank's count-only rate) then reads from this line alone.
+    count_only_ms = None
+    if collective and steps > 0:
+        fence()
+        collective = False
+        step()
+        ctx.sync()
+        fence()
+        k_co = max(3, min(steps, 10))
+        c0 = time.perf_counter()
+        for _ in range(k_co):
+            step()
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        count_only_ms = (time.perf_counter() - c0) * 1e3 / k_co
+        if use_dist:
+            tt = torch.tensor([count_only_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            count_only_ms = float(tt.item())
+        collective = True
+        step()                              # a freshly counted + reduced buffer for the gates below
         drain()
         torch.cuda.synchronize(dev)
     # gate on the REDUCED table of the last step: every tuple sums to the total number of trees (binary, full trees)
@@ -827,7 +939,7 @@ def main():
             ctx.batch_free(h2)
         up_step()
         ctx.sync()
-        k_up = 3 if one_ms >= 100 else max(3, min(steps, 50))
+        k_up = max(3, min(steps, 20)) if one_ms >= 100 else max(3, min(steps, 50))   # (a timed region of its own, not a 3-step aside)
         torch.cuda.synchronize(dev)
         u0 = time.perf_counter()
         for _ in range(k_up):
@@ -880,7 +992,7 @@ def main():
         "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if split else "weak",
+        "scaling": "n/a" if world == 1 else ("strong" if split else "weak"),
         "vs_baseline": None,
         "dtype": "u32" if count_bits == 32 else "u16",
         "data": "synthetic",
@@ -889,6 +1001,8 @@ def main():
                          + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
                          + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else (", mixed thirds" if args.mixed else "") + f", collapse {args.collapse} dropout {args.dropout}")
                          + f", seeds {seed_ref}/{seed_set}")[:100],
+            "baseline_config": (f"BASELINE.json configs[{cfg_no - 1}] (bench.py --config {cfg_no})" if not custom else "custom (not a BASELINE config)"),
+            "one_rank_same_workload": same_workload_scaling(value, world, m * nq_all, count_only_ms, elapsed / steps * 1e3) if count_only_ms else None,
             "quartets": nq_all,
             "quartets_this_rank": nq,
             "workload_key": workload_key,
@@ -909,6 +1023,10 @@ def main():
             "kernel_ms_source": kernel_ms_source,
             "prewarm_ms": args.prewarm_ms,
             "count_kernels_ms_last_timed_step": last_step_ms[1] if last_step_ms else None,
+            "kernels_of_last_timed_step": [[k_, round(ms_, 3)] for k_, ms_ in last_events][:24],
+            "depth_clamp": {"trees_below_own_depth_bits": clamp_info[0], "tree_quartet_corrections": clamp_info[1], "fix_workgroups": clamp_info[2],
+                            "fix_kernels_ms_last_timed_step": round(last_fix_ms, 3) if last_fix_ms is not None else None,
+                            "note": "trees counted in a class below their depth bits; clamp_fix_kernel adds the tied quartets (in count_kernels_ms)"},
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
             "score_mode": score_mode,
             "score_phase_ms": score_ms,
@@ -921,6 +1039,13 @@ def main():
             "box_issue_probe_note": "bare 24 v_bitop3 + 4 v_bcnt slot at 4 waves/SIMD on this device; 1.39-1.40 in profiles/r03_valu_yardstick.txt",
         },
     }
+    # SURVEY 8(d) defines the phase from "trees resident on host": the same step with qs_batch_upload (validation, class plan, pinned
+    # staging, H2D) inside, at top level beside `value` (which the bench contract defines with the inputs resident in HBM)
+    if upload_step_ms:
+        out["value_upload_inclusive"] = (m * nq) / (upload_step_ms * 1e-3) * (world if not shards > 1 else 1)
+        out["ms_per_step_upload_inclusive"] = upload_step_ms
+        out["config"]["resident_ms_per_step"] = elapsed / steps * 1e3
+        out["config"]["value_definition"] = "value: inputs resident in HBM (bench contract); value_upload_inclusive: host arrays -> table (SURVEY 8(d))"
     # e2e: what the product delivers when the inputs are NOT yet resident (never `value`)
     if upload_step_ms or cli_e2e:
         e2e = {"note": "inputs not resident: never `value`"}
@@ -971,6 +1096,8 @@ def main():
         roof["pmc_source"] = f"none under profiles/ for kernel source {kernel_source_sha()}"
     out["roofline"] = roof
 
+    if p2p_leg is not None:
+        out["config"]["p2p_leg"] = p2p_leg
     if cpu_baseline is not None:                     # rank 0's host, at every N
         out["cpu_baseline"] = cpu_baseline
     if comm is not None:

@@ -354,6 +354,12 @@ int qs_score_prepare(qs_ctx *ctx, const qs_ref_tree *ref, uint64_t n_trees_total
  */
 #define QS_SCORE_CAND_SLOTS 8
 uint64_t qs_score_pair_slots(const qs_ref_tree *ref);
+/* Host-only (no device call; ctx may be NULL, the message then comes from qs_last_error(NULL)): the status qs_score /
+ * qs_score_finish would return for this reference tree and these flags for reasons that depend on the TREE alone -- today
+ * QS_ERR_REFERENCE_THROWS for QS_SCORE_SAVEMEM_LOOKUPS with a rooted reference tree (same message). Lets a host know before it
+ * counts; the reference itself counts first and dies in its scoring loop (QuartetScoreComputer.hpp:393-431). */
+int qs_score_check(qs_ctx *ctx, const qs_ref_tree *ref, uint32_t flags);
+
 /* Scoring view: qs_score_pass1 / qs_score_pass2 read the tuples of ranks [rank_lo, rank_lo + n_tuples) from
  * caller-owned device memory ([tuple][3] cells of count_bits bits) instead of the context's own table -- the
  * shard a rank holds after a reduce-scatter of the count table. table_dev = NULL returns to the own table.
@@ -390,6 +396,9 @@ int qs_last_count_ms(qs_ctx *ctx, float out_ms[3]);
 int qs_last_count_launches(const qs_ctx *ctx);
 /* ... and the share of [1] spent in the depth-clamp correction kernels (QS_TUNE_DEPTH_CLAMP; 0 without clamped trees). */
 float qs_last_count_fix_ms(qs_ctx *ctx);
+/* ... and every kernel of that call in launch order: ms[k] = its duration, kind[k] = 0 panel build, 1 count kernel, 2 depth-clamp
+ * corrections; returns the number of kernels written (at most cap). */
+int qs_last_count_events(qs_ctx *ctx, float *ms, uint8_t *kind, int cap);
 /* Depth clamp of an uploaded batch: out[0] = trees counted in a class below their own depth bits, out[1] = the (tree, quartet)
  * corrections they cost, out[2] = workgroups of the correction kernel. */
 int qs_batch_clamp_info(const qs_device_batch *batch, uint64_t out[3]);

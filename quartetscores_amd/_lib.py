@@ -7,6 +7,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libquartetscores_hip.so")
+# A/B runs of the PYTHON harness against another build of the library (tools/Makefile `exp`): QS_PY_LIB=/path/to/libqs_expX.so.
+# Like QS_PY_TUNING this is the harness' switch; the library itself reads no environment variables.
+LIB_PATH = os.environ.get("QS_PY_LIB") or LIB_PATH
 
 QS_OK = 0
 QS_ERR_ARG, QS_ERR_HIP, QS_ERR_OOM, QS_ERR_STATE, QS_ERR_OVERFLOW, QS_ERR_NO_DEVICE, QS_ERR_UNSUPPORTED, QS_ERR_REFERENCE_THROWS = -1, -2, -3, -4, -5, -6, -7, -8
@@ -30,7 +33,7 @@ EXPORTS = [
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
     "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
-    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan",
+    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan", "qs_score_check", "qs_last_count_events",
 ]
 
 
@@ -168,6 +171,10 @@ def load():
     L.qs_last_count_fix_ms.argtypes = [vp]
     L.qs_batch_clamp_info.restype = i32
     L.qs_batch_clamp_info.argtypes = [vp, C.POINTER(u64 * 3)]
+    L.qs_last_count_events.restype = i32
+    L.qs_last_count_events.argtypes = [vp, vp, vp, i32]
+    L.qs_score_check.restype = i32
+    L.qs_score_check.argtypes = [vp, C.POINTER(RefTreeC), u32]
     L.qs_depth_clamp_plan.restype = i32
     L.qs_depth_clamp_plan.argtypes = [u32, C.POINTER(TreeBatchC), u32, vp, vp, vp]
     _lib = L

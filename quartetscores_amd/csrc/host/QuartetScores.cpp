@@ -29,7 +29,7 @@ namespace {
 struct Args {
     std::string ref, eval, out, raw, raw_bin;
     size_t threads = 0;
-    bool verbose = false, savemem = false, raw_rank_order = false;
+    bool verbose = false, savemem = false, raw_rank_order = false, fail_fast = false;
     int table_shards = -1;   // -1 = off (the whole table on the device); 0 = as many as the device's free memory asks for; K = K shards, one after the other (table_shards.hpp)
     int spill = 0;           // ShardedTableQuartetScoreComputer::Spill
     int gpus = 0;   // 0 = the single-GPU path; N >= 1 = trees split over N GPUs of this node + one RCCL collective (multi_gpu.hpp)
@@ -45,13 +45,14 @@ void usage(std::ostream &os) {
           "   -t, --threads  Maximum number of host threads for parsing the evaluation trees (0 = all)\n"
           "   -v, --verbose  Verbose mode\n"
           "   -s, --savemem  Consume less memory (the GPU table is always the compact one; with a ROOTED reference tree the run\n"
-          "                  ends with the reference's own std::runtime_error, see --root-as-edge)\n"
+          "                  ends with the reference's own std::runtime_error, see --root-as-edge; a note says so before the\n"
+          "                  counting starts, --fail-fast ends the run there)\n"
           "   --device N     HIP device ordinal (default 0)\n"
           "   --gpus N       split the evaluation trees over N GPUs of this node (devices --device .. --device+N-1) and\n"
           "                  combine the count tables with one reduction over xGMI\n"
           "   --reduce R     with --gpus: rccl (default: one RCCL reduce-scatter / all-reduce) | p2p (this one process maps its\n"
           "                  peers' memory and every GPU sums its chunk with plain loads: no communicator to create)\n"
-          "   --comm-overlap 0|1  with --gpus, rccl: count while the communicators are being created (default 1)\n"
+          "   --comm-overlap 0|1  with --gpus, rccl: count while the communicators are being created (default 0: the first launch waits for them)\n"
           "   --algo A       gather (default) | scatter\n"
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
           "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
@@ -119,6 +120,7 @@ int parse(int argc, char **argv, Args &a) {
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
         else if (f == "--root-as-edge") a.dev.root_as_edge = true;
+        else if (f == "--fail-fast") a.fail_fast = true;
         else if (f == "--reduce") {
             if (!(v = need(i, "--reduce"))) return 1;
             a.dev.reduce = v;
@@ -223,6 +225,22 @@ int main(int argc, char *argv[]) {
             for (size_t v = 0; v < referenceTree.node_count(); ++v)
                 if (referenceTree.is_leaf(v)) std::cout << referenceTree.name[v] << " " << v << "\n";
             std::cout << std::endl;
+        }
+
+        // What the scoring will refuse because of the reference tree alone is known before anything is counted (qs_score_check,
+        // host-only): `-s` with a rooted reference tree. The reference program counts first and dies in its scoring loop; this run
+        // says so NOW and then does the same -- or ends at once with --fail-fast.
+        if (a.savemem) {
+            const RefFlat rf0 = flatten_reference(referenceTree);
+            qs_ref_tree rt0;
+            rt0.n_nodes = (uint32_t)referenceTree.node_count(); rt0.n_taxa = (uint32_t)rf0.names.size();
+            rt0.parent = rf0.parent.data(); rt0.leaf_node = rf0.leaf_node.data();
+            if (qs_score_check(nullptr, &rt0, QS_SCORE_SAVEMEM_LOOKUPS | (a.dev.root_as_edge ? QS_SCORE_ROOT_AS_EDGE : 0u)) == QS_ERR_REFERENCE_THROWS) {
+                const std::string what = qs_last_error(nullptr);
+                if (a.fail_fast) throw std::runtime_error(what);
+                std::cerr << "Note: -s with a rooted reference tree: the reference program ends in its scoring loop with \"" << what
+                          << "\" after it has counted, and so will this run (--fail-fast ends it now).\n";
+            }
         }
 
         std::vector<double> lqic, qpic, eqpic;

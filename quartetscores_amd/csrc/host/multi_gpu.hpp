@@ -66,10 +66,11 @@ public:
         table_.assign(G_, nullptr);
         send_.assign(G_, nullptr);
         // RCCL's communicators take 1.7-5.6 s to create (ncclCommInitAll), on a helper thread that starts NOW. Nothing but the
-        // collective itself needs them: the GPUs' host threads create their contexts, allocate, parse and COUNT meanwhile
-        // (opt.comm_overlap, the default). Round 3 made the workers wait for the communicators before their first launch,
-        // because the creation's many small device operations queued behind 100 ms count kernels (5.6 s instead of 2.8 s
-        // at 512 taxa x 10000 trees); `--comm-overlap 0` restores that order. `--reduce p2p` creates no communicator at all.
+        // collective itself needs them: the GPUs' host threads create their contexts, allocate and parse meanwhile. By DEFAULT
+        // (opt.comm_overlap = false, `--comm-overlap 0`) the workers wait for the communicators before their first launch: the
+        // creation's many small device operations queue behind 100 ms count kernels (5.6 s instead of 2.8 s at 512 taxa x
+        // 10000 trees, measured in rounds 3 and 4); `--comm-overlap 1` counts beside the creation (A/B runs only).
+        // `--reduce p2p` creates no communicator at all.
         std::vector<int> devs(G_);
         for (int g = 0; g < G_; ++g) devs[g] = dev_of(g);
         comms_.assign(G_, nullptr);
@@ -161,7 +162,7 @@ private:
                 // between the count and the collective; freed again if the trees turn out not to be binary and full
                 if (!full_ && bits_ == 32 && (opt_.algo & 0xFFu) != QS_ALGO_SCATTER && G_ > 1) {
                     const size_t sb = (size_t)chunk_tuples_ * 2 * 4 * G_;
-                    if (hipMalloc(&send_[g], sb) == hipSuccess) QSM_HIP(hipMemsetAsync(send_[g], 0, sb, nullptr));   // padding tuples stay zero
+                    if (hipMalloc(&send_[g], sb) == hipSuccess) QSM_HIP(hipMemset(send_[g], 0, sb));   // padding tuples stay zero (synchronous: ordered before the pack kernel on the context's stream and the peers' reads)
                     else { send_[g] = nullptr; (void)hipGetLastError(); }
                 }
                 const size_t lo = spans.size() * g / G_, hi = spans.size() * (g + 1) / G_;

@@ -168,6 +168,9 @@ static uint32_t slice_groups(const qs_ctx *c, size_t group_bytes, uint32_t n_tot
     }
     else g = std::min<size_t>(std::max<size_t>(96ull << 20, 32 * group_bytes), 384ull << 20) / group_bytes;
     g = std::min<size_t>(std::max<size_t>(g, 1), std::max<uint32_t>(n_total, 1));
+    // (round 5: up to 1.5 slices' worth stays ONE slice -- 313 groups at configs[2] since the depth clamp put all 10000 trees in one
+    // class: 301.5 ms in one slice against 308.1 ms in two of 157, the second pass over the table costs more than the larger L2 set)
+    if (balance && !c->tune_slice_bytes && n_total <= g + g / 2) g = std::max<uint32_t>(n_total, 1);
     if (balance) { const size_t slices = (n_total + g - 1) / g; g = (n_total + slices - 1) / std::max<size_t>(slices, 1); }
     return (uint32_t)std::max<size_t>(g, 1);
 }
@@ -857,7 +860,7 @@ struct Stager {
 // (tree, quartet) corrections a tree costs when its LCA depths are cut at `cut`: the quartets with at least three leaves in one
 // maximal run of tour-adjacent LCA depths >= cut (a subtree below a node of depth `cut`): C(s,3)(L - s) + C(s,4) per run of s
 // leaves. ~0 when a run is longer than the kernel's LDS table takes. runs (optional): (first position, leaves) of every run.
-constexpr uint32_t kClampMaxRun = 64;   // = kFixMaxRun of qs_count.hip
+constexpr uint32_t kClampMaxRun = 128;  // = kFixMaxRun of qs_count.hip
 static uint64_t clamp_cost(const uint16_t *adj, uint32_t L, uint32_t cut, std::vector<std::pair<uint32_t, uint32_t>> *runs) {
     uint64_t cost = 0;
     for (uint32_t i = 0; i + 1 < L;) {
@@ -984,8 +987,8 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     d.max_depth = max_depth; d.all_full = all_full && nt > 0; d.all_binary = all_binary && nt > 0;
     // Classes = (kernel mode, depth bits) per TREE. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B
     // of the deepest LCA of the trees it is given (2(B+1)+2 instructions for full binary trees, B >= 4) and with what the
-    // trees may contain: binary trees with missing taxa 2(B+1)+6, multifurcating trees 3(B+1)+4, both 3(B+1)+8 on a tile of
-    // half the size. One deep, one multifurcating or one incomplete tree must not put the whole batch on the dearest
+    // trees may contain: binary trees with missing taxa 2(B+1)+5, multifurcating trees 3(B+1)+3, both 3(B+1)+7 (the same
+    // two-column tile). One deep, one multifurcating or one incomplete tree must not put the whole batch on the dearest
     // instance (the reference's loop is shape-independent, QuartetCounterLookup.hpp:65-106), so trees are counted class by
     // class: B = 4 .. 10 (LCA depths below 1024: ladder-like trees of up to ~2000 taxa) and "deeper" (byte-SWAR kernel,
     // 16-bit depths) within each of the four modes. Every class costs at least one more panel slice = one more pass over
@@ -1033,6 +1036,29 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
                 for (uint32_t lo = bb - 1; lo >= eff_hard[t] && lo >= 4; --lo)
                     if (cnt[mo][lo] >= small) { cnt[mo][bb]--; cnt[mo][lo]++; cls[t] = (uint8_t)lo; break; }
             }
+        // ... and a class that is still small after that costs a launch of its own = one more pass over the table (10-20 ms at
+        // 34 GB) plus the waves' fixed cost for a handful of trees: its trees go down at ANY finite price, as long as the sum stays
+        // below what the pass would cost (5 % of C(n,4) corrections ~ 1.4e8 at 512 taxa)
+        if (c->tune_clamp_ppm)
+            for (uint32_t mo = 0; mo < kModes; ++mo)
+                for (uint32_t bb = top_bits; bb > 4; --bb) {
+                    if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                    uint32_t lo = bb - 1;
+                    while (lo > 4 && cnt[mo][lo] < small) --lo;
+                    if (cnt[mo][lo] < small) continue;                  // no class below that is worth joining
+                    uint64_t total = 0;
+                    bool finite = true;
+                    std::vector<uint32_t> members;
+                    for (uint32_t t = 0; t < nt && finite; ++t) {
+                        if (final_mode(tree_mode[t]) != mo || cls[t] != bb) continue;
+                        const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
+                        const uint64_t cost = clamp_cost(hb->adj_depth + base, L, (1u << lo) - 1u, nullptr);
+                        if (cost == ~0ull) finite = false; else { total += cost; members.push_back(t); }
+                    }
+                    if (!finite || total > binom4(n) / 20) continue;
+                    for (uint32_t t : members) cls[t] = (uint8_t)lo;
+                    cnt[mo][lo] += cnt[mo][bb]; cnt[mo][bb] = 0;
+                }
         for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(tree_mode[t]); mx[mo][cls[t]] = std::max<uint32_t>(mx[mo][cls[t]], tree_depth[t]); }
         uint32_t remap[kModes][kBits];
         for (uint32_t mo = 0; mo < kModes; ++mo) {
@@ -1311,7 +1337,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                     CountGeometry g3 = g;
                     if (bin_tiles) {
                         g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3;
-                        if (mode == MODE_BINARY_FULL) { g3.perm_coop = c->perm_coop; g3.n_coop = c->n_coop; g3.perm_rest = c->perm_rest; g3.n_rest = c->n_rest; any_coop = any_coop || c->n_coop; }
+                        if (mode == MODE_BINARY_FULL) { g3.perm_coop = c->perm_coop; g3.n_coop = c->n_coop; g3.perm_rest = c->perm_rest; g3.n_rest = c->n_rest; any_coop = any_coop || (c->n_coop && depth_bits <= 7); }   // (count_bitslice4_kernel carries at most 7 planes)
                     }
                     else { g3.total_tiles = c->total_tiles1t; g3.dprefix = c->dprefix1t; g3.cprefix = c->cprefix; }
                     g3.perm = order;
@@ -1406,6 +1432,19 @@ extern "C" float qs_last_count_fix_ms(qs_ctx *c) {
         if (c->ev_kind[i] == 2 && hipEventElapsedTime(&ms, c->evs[i - 1], c->evs[i]) == hipSuccess) sum += ms;
     }
     return sum;
+}
+
+extern "C" int qs_last_count_events(qs_ctx *c, float *ms, uint8_t *kind, int cap) {
+    if (!c || !c->last_timed || c->ev_used < 2) return 0;
+    if (hipEventSynchronize(c->evs[c->ev_used - 1]) != hipSuccess) return 0;
+    int k = 0;
+    for (uint32_t i = 1; i < c->ev_used && k < cap; ++i, ++k) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, c->evs[i - 1], c->evs[i]);
+        if (ms) ms[k] = t;
+        if (kind) kind[k] = c->ev_kind[i];
+    }
+    return k;
 }
 
 extern "C" int qs_batch_clamp_info(const qs_device_batch *b, uint64_t out[3]) {
@@ -1993,6 +2032,17 @@ static int check_savemem_lookups(qs_ctx *c, const RefHost &R, uint32_t flags) {
     uint64_t id = 0;
     if (!first_compact_throw(R, nq, &id)) return QS_OK;
     return fail(c, QS_ERR_REFERENCE_THROWS, "id = " + std::to_string(id) + ", but quartet_lookup_.size() = " + std::to_string(nq));
+}
+
+// Host-only: what qs_score / qs_score_finish would refuse for this reference tree and these flags, found from the tree alone
+// (before any counting): today the QS_SCORE_SAVEMEM_LOOKUPS + rooted-reference case. ctx may be NULL.
+extern "C" int qs_score_check(qs_ctx *c, const qs_ref_tree *ref, uint32_t flags) {
+    if (!ref) return fail(c, QS_ERR_ARG, "qs_score_check: NULL");
+    RefHost local;
+    const RefHost *Rp = &local;
+    const int rc = c ? get_ref(c, ref, false, &Rp) : build_ref(nullptr, ref, local);
+    if (rc != QS_OK) return rc;
+    return check_savemem_lookups(c, *Rp, flags);
 }
 
 // Pure host: log_score of the O(#node pairs) candidates and sums with the host libm

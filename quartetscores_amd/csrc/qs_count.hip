@@ -884,6 +884,9 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 #define QS_GEN3_MAXB 6   /* general / partial instances up to this many depth bits are held to 3 waves per SIMD (168 VGPRs, a few spills) */
 #endif
 
+#ifndef QS_GEN_PREFETCH
+#define QS_GEN_PREFETCH 0   /* 1: general modes request the next d-row's R elements one row ahead; 2: ... behind a scheduling barrier */
+#endif
 #define QS_BS3_OCC __attribute__((amdgpu_waves_per_eu(QS_BS3_WAVES, QS_BS3_WAVES)))
 
 
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
     // blkB in columns 0..7 / 8..15 / 16..23 (they also compare R of (a,d)) and M[b,c] in row columns 16..23.
     // Diagonal tiles (a and b from the same block) pack two diagonal blocks per wave, one a per lane, 16 columns.
     uint32_t blk0, blk1, blkB;
-    uint32_t a1, a2, b, colA1, colA2, colB;
+    uint32_t a1, a2, b, colA1_, colA2_, colB_;
     if (offdiag) {
         uint32_t Bk = (uint32_t)(2.0f * sqrtf((float)tl + 1.0f)); // largest Bk with floor(Bk^2 / 4) <= tl
         while ((Bk * Bk) / 4 > tl) --Bk;
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         const uint32_t j = tl - (Bk * Bk) / 4;
         blk0 = 2 * j; blk1 = (2 * j + 1 < Bk) ? 2 * j + 1 : 0xFFFFFFFFu; blkB = Bk;
         const uint32_t ia = lane & (kTA - 1), ib = lane / kTA;
-        colA1 = ia; colA2 = kTA + ia; colB = GEN ? 2 * kTA + ib : ib;
+        colA1_ = ia; colA2_ = kTA + ia; colB_ = GEN ? 2 * kTA + ib : ib;
         a1 = blk0 * kTA + ia;
         a2 = blk1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : blk1 * kTA + ia;
         b = Bk * kTB + ib;
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         const uint32_t h = lane >> 5, q = lane & 31;
         uint32_t ia = 0, ib = 1;
         if (q < 28) unrank2(q, ia, ib);
-        colA1 = h * kTA + ia; colA2 = colA1; colB = h * kTA + ib;
+        colA1_ = h * kTA + ia; colA2_ = colA1_; colB_ = h * kTA + ib;
         a1 = (h ? blk1 : blk0) * kTA + ia; a2 = 0xFFFFFFFFu;
         b = q < 28 ? (h ? blk1 : blk0) * kTA + ib : 0xFFFFFFFFu;
     }
@@ -1101,6 +1104,12 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         abn1 = gload(r, ab1off);
         if (A2) abn2 = gload(r, ab2off);
 
+        // The lane's LDS columns, re-defined per step behind an empty asm: in the straight-line (FULL) instance of the general
+        // modes LLVM otherwise hoists every (d-row, column) address out of the loop as a value of its own -- ~48 address
+        // registers in an instance that lives at the 168-VGPR limit, which pushed four of the seven panel loads behind the last
+        // d-row (an exposed L2 round trip per step). With the columns opaque the rows are immediate offsets from three bases.
+        uint32_t colA1 = colA1_, colA2 = colA2_, colB = colB_;
+        if (GEN) asm volatile("" : "+v"(colA1), "+v"(colA2), "+v"(colB));
         const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1)); // M[a1 b] - M[a1 c] + 2^B
         Planes L2 = L1, G1 = L1, G2 = L1;
         if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));      // M[a2 b] - M[a2 c] + 2^B
@@ -1109,10 +1118,20 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
             G1 = sub_biased<B>(abc1, rb);
             if (A2) G2 = sub_biased<B>(abc2, rb);
         }
+        // general modes, hot instance: the three R elements of d-row j + 1 are requested before row j is compared (the LDS
+        // round trip is ~100+ cycles, a row's chains ~80, and only 3 waves per SIMD are there to cover the difference)
+        constexpr bool PFR = QS_GEN_PREFETCH && MODE == MODE_GENERAL_FULL && B <= 4 && FULL && A2;
+        Planes nRb = L1, nRa = L1, nRa2 = L1;
+        if (PFR) { nRb = lload(cur, colB); nRa = lload(cur, colA1); nRa2 = lload(cur, colA2); }
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
             if (FULL || ((uint32_t)j >= jlo && (uint32_t)j < jhi)) { // wave-uniform
-                const Planes Rb = lload(cur, j * RC + colB);         // M[bd] - M[cd] + 2^B
+                const Planes pRb = nRb, pRa = nRa, pRa2 = nRa2;
+                if (PFR && j + 1 < kDB) {
+                    nRb = lload(cur, (j + 1) * RC + colB); nRa = lload(cur, (j + 1) * RC + colA1); nRa2 = lload(cur, (j + 1) * RC + colA2);
+                    if (QS_GEN_PREFETCH == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+                const Planes Rb = PFR ? pRb : lload(cur, j * RC + colB);   // M[bd] - M[cd] + 2^B
                 uint32_t gt, lt;
                 cmp_planes<NB>(L1, Rb, gt, lt);
                 if (BIN) {
@@ -1135,7 +1154,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                         popc_acc(lt2, y1[j]);
                     }
                 } else {
-                    const Planes Ra = lload(cur, j * RC + colA1);    // M[a1 d] - M[cd] + 2^B
+                    const Planes Ra = PFR ? pRa : lload(cur, j * RC + colA1);    // M[a1 d] - M[cd] + 2^B
                     // [S3 > S1]. In a tree the two smaller of the three sums are equal (four-point condition), so S3 > S1 already
                     // implies S1 == S2: no masking with ~(gt | lt) (round 4: one instruction per quartet less)
                     uint32_t g3 = gt_planes<NB>(Ra, G1);
@@ -1147,7 +1166,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                     popc_acc(lt, x1[j]);
                     popc_acc(g3, z0[j]);
                     if (A2) {                                        // the second a-column against the same R of (b,d)
-                        const Planes Ra2 = lload(cur, j * RC + colA2);
+                        const Planes Ra2 = PFR ? pRa2 : lload(cur, j * RC + colA2);
                         uint32_t gt2, lt2;
                         cmp_planes<NB>(L2, Rb, gt2, lt2);
                         uint32_t h3 = gt_planes<NB>(Ra2, G2);
@@ -1162,11 +1181,16 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
                 }
             }
         }
+        // single-buffered image (cur == nxt): every read of this step above, every write of the next image below. LDS operations
+        // of a wave execute in program order; the scheduling barrier keeps the compiler from moving a store above a load it
+        // cannot prove disjoint (no instruction is emitted)
+        if (NBUF == 1) __builtin_amdgcn_wave_barrier();
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
         if (NR >= 2) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
         if (NR == 3) lstore(nxt, slot2, sub_biased<B>(st.x2, st.y));
         if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
         else lstore(nxt, rowslot, st.row);
+        if (NBUF == 1) __builtin_amdgcn_wave_barrier();   // ... and the next step's reads stay behind these stores
     };
 
     auto run = [&](auto a2_tag, auto full_tag, auto nr_tag) {
@@ -1645,7 +1669,7 @@ hipError_t launch_count_scatter(hipStream_t s, const DeviceBatch &b, uint32_t n,
 // the third cell (n2 = trees - n0 - n1), so that cell is decremented when the true topology is another one.
 // Workgroup = one unit = (tree, run, a stretch of the run's triples in colex order); threads = the fourth leaves.
 // Replaces nothing in the reference: its loop is shape-independent (QuartetCounterLookup.hpp:65-106).
-constexpr int kFixMaxRun = 64;      // leaves of a run (longer runs: the tree keeps its own depth class)
+constexpr int kFixMaxRun = 128;     // leaves of a run (longer runs: the tree keeps its own depth class)
 constexpr int kFixThreads = 256;
 enum FixRule { FIX_BINARY = 0, FIX_GENERAL = 1, FIX_WIRE = 2 };
 

@@ -222,6 +222,13 @@ class Context:
         """Share of last_count_ms()[1] spent in the depth-clamp correction kernels (QS_TUNE_DEPTH_CLAMP)."""
         return float(self.L.qs_last_count_fix_ms(self.h))
 
+    def last_count_events(self):
+        """[(kind, ms)] of every kernel of the last timed count_batch in launch order; kind: "panel" | "count" | "fix"."""
+        ms = (C.c_float * 256)()
+        kind = (C.c_uint8 * 256)()
+        k = int(self.L.qs_last_count_events(self.h, ms, kind, 256))
+        return [(("panel", "count", "fix")[min(int(kind[i]), 2)], float(ms[i])) for i in range(k)]
+
     def batch_clamp_info(self, hb) -> Tuple[int, int, int]:
         """(trees counted in a class below their own depth bits, their (tree, quartet) corrections, correction workgroups)."""
         out = (C.c_uint64 * 3)()
@@ -391,6 +398,18 @@ class QuartetCounterLookup:
         return self.ctx.table_download()
 
 
+def score_check(ref: flatten.RefTree, flags: int) -> None:
+    """qs_score_check without a context (host-only): raises the QSError qs_score would end with for reasons of the reference tree
+    alone -- QS_ERR_REFERENCE_THROWS for QS_SCORE_SAVEMEM_LOOKUPS with a rooted reference tree."""
+    L = _lib.load()
+    parent = np.ascontiguousarray(ref.parent, dtype=np.int32)
+    leaf_node = np.ascontiguousarray(ref.leaf_node, dtype=np.uint32)
+    s = _lib.RefTreeC(ref.n_nodes, ref.n_taxa, parent.ctypes.data, leaf_node.ctypes.data)
+    rc = L.qs_score_check(None, C.byref(s), flags)
+    if rc != 0:
+        raise QSError(rc, L.qs_last_error(None).decode())
+
+
 class QuartetScoreComputer:
     """QuartetScoreComputer<CINT>(refTree, evalTreesPath, m, verboseOutput, enforceSmallMem): does
     all the work in its constructor (QuartetScoreComputer.hpp:698-785). Scores are indexed by
@@ -401,6 +420,11 @@ class QuartetScoreComputer:
         self.ref = refTree if isinstance(refTree, flatten.RefTree) else flatten.flatten_reference(refTree)
         say = log or (lambda s: None)
         n = self.ref.n_taxa
+        score_flags = ((QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32) | (QS_SCORE_ROOT_AS_EDGE if root_as_edge else 0) |
+                       (QS_SCORE_SAVEMEM_LOOKUPS if enforceSmallMem else 0))
+        # what the scoring would refuse because of the reference tree alone (`-s` + a rooted reference: the reference program
+        # throws there, after it has counted) is known now: raise before the counting instead of after it
+        score_check(self.ref, score_flags)
         self.quartetCounterLookup = QuartetCounterLookup(self.ref, evalTreesPath, m, enforceSmallMem, **kw)
         say(f"There are {self.quartetCounterLookup.m} evaluation trees.")
         say(f"The reference tree has {n} taxa.")
@@ -410,9 +434,7 @@ class QuartetScoreComputer:
         # root_as_edge: a degree-2 root as a subdivision of one edge instead of the reference's handling (quirk Q5)
         # enforceSmallMem (`-s`): the reference's compact table behind the lookups of a degree-2 root's node pairs -- it throws
         # there (quartet_lookup_table.hpp:79-85), and so does this constructor (QSError, code QS_ERR_REFERENCE_THROWS)
-        lq, qp, eqp, bif = ctx.score(self.ref, (QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32) |
-                                     (QS_SCORE_ROOT_AS_EDGE if root_as_edge else 0) |
-                                     (QS_SCORE_SAVEMEM_LOOKUPS if enforceSmallMem else 0))
+        lq, qp, eqp, bif = ctx.score(self.ref, score_flags)
         self.bifurcating = bif
         say("The reference tree is bifurcating." if bif else "The reference tree is multifurcating.")
         self._lq, self._qp, self._eqp = lq[1:], (qp[1:] if bif else None), (eqp[1:] if bif else None)

@@ -95,3 +95,33 @@ def test_the_roofline_prices_every_class_with_its_own_mode():
     assert bench.parse_variant("gather/partial/bitslice_b4x2:1418+bitslice_b5x2:82/count_u16", 1500)[2] == (22 * 1418 + 25 * 82) / 1500
     assert bench.parse_variant("gather/partial/depth_u16/count_u32", 40)[2] is None          # byte-SWAR kernel: priced against HBM
     assert bench.parse_variant("scatter/atomic/count_u32", 40) == (None, [], None)
+
+
+def test_scaling_fields_and_cli_phase_parsing():
+    """The pieces of the N > 1 line that need no GPU: scaling efficiency from the same-workload count-only step, the phases of
+    a (multi-GPU, --trace) CLI run from its stdout protocol and trace stamps, the GPU count from the KFD topology narrowed by
+    *_VISIBLE_DEVICES, and the NUMA node the cpu_baseline child pins itself to."""
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.same_workload_scaling(value=7.2e14, world=8, units_per_rank_per_step=2.0e12, count_only_ms=20.0, ms_per_step=22.5)
+    assert abs(f["rate_quartets_per_s"] - 1.0e14) < 1 and abs(f["scaling_efficiency"] - 0.9) < 1e-12 and f["collective_exposed_ms"] == 2.5
+    out = "There are 7 evaluation trees.\nFinished counting quartets.\nIt took: 446000 microseconds.\nFinished computing scores.\nIt took: 30000 microseconds.\n"
+    err = ("[trace] +     1.0 ms  main: arguments parsed\n[trace] +   400.0 ms  main: all GPUs counted\n"
+           "[trace] +   400.1 ms  main: no communicator (peer access)\n[trace] +   416.5 ms  main: tables reduced\n")
+    ph = bench.cli_phases(out, err)
+    assert ph == {"counting_phase_ms": 446.0, "scoring_phase_ms": 30.0, "all_gpus_counted_at_ms": 400.0, "table_reduction_ms": 16.5}
+    assert bench.cli_phases("It took: 5 microseconds.\n", "") is None
+    assert bench.cli_phases(out, "")["counting_phase_ms"] == 446.0 and "table_reduction_ms" not in bench.cli_phases(out, "")
+    have = bench.visible_gpus()
+    assert have >= 0
+    old = os.environ.get("HIP_VISIBLE_DEVICES")
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        assert bench.visible_gpus() == 0
+    finally:
+        if old is None:
+            del os.environ["HIP_VISIBLE_DEVICES"]
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = old
+    cpus = bench.numa_node0_cpus()
+    assert cpus is None or (len(cpus) >= 1 and set(cpus) <= set(os.sched_getaffinity(0)))

@@ -46,3 +46,26 @@ def test_config4_through_the_launcher_takes_the_table_sharded_path():
                      "--no-cpu-baseline", "--no-e2e"])
     assert doc["config"]["table_shard"] is not None and doc["config"]["collective"] is None
     assert doc["collective"]["ranks"] == 1 and doc["dtype"] == "u16"
+
+
+def test_forced_collective_line_carries_its_own_scaling_figures_and_the_p2p_leg():
+    """The N > 1 code path on one GPU (QS_BENCH_FORCE_DIST=1: RCCL initialised, the table collective inside every step): the line
+    times the same share WITHOUT the collective in the same run (config.one_rank_same_workload: count-only ms, scaling efficiency,
+    exposed collective time) and, with --p2p-leg 1, the C++ host's peer-access reduction on the same trees in a child process."""
+    os.environ["QS_BENCH_FORCE_DIST"] = "1"
+    try:
+        doc = run_bench(["--gpus", "1", "--config", "3", "--taxa", "160", "--trees", "6000", "--steps", "10", "--warmup", "2", "--p2p-leg", "1",
+                         "--no-cpu-baseline", "--no-e2e", "--no-score"])
+    finally:
+        del os.environ["QS_BENCH_FORCE_DIST"]
+    cfg = doc["config"]
+    assert doc["scaling"] == "n/a" and cfg["baseline_config"].startswith("custom") and cfg["collective"] == "scatter"
+    same = cfg["one_rank_same_workload"]
+    assert same["count_only_ms_per_step"] > 0 and 0.3 < same["scaling_efficiency"] < 1.2, same
+    assert abs(same["collective_exposed_ms"] - (doc["ms_per_step"] - same["count_only_ms_per_step"])) < 1e-2
+    leg = cfg["p2p_leg"]
+    assert leg.get("counting_phase_ms", 0) > 0 and leg["counting_quartets_per_s"] > 0 and "table_reduction_ms" in leg, leg
+    assert cfg["parity_reduced_tuple_sums_ok"] is True
+    plain = run_bench(["--gpus", "1"] + SMALL)
+    assert plain["scaling"] == "n/a" and plain["config"]["one_rank_same_workload"] is None and "p2p_leg" not in plain["config"]
+    assert plain["config"]["baseline_config"].startswith("custom")

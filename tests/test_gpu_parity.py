@@ -375,7 +375,8 @@ def test_cooperative_count_kernel_matches_oracle(eng, monkeypatch, n, m, bits, c
     monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_COOP, 1)
     ctx, T = gpu_table(eng, ref, batch, count_bits)
     v = ctx.last_count_variant()
-    assert "binary_full" in v and "coop" in v and f"bitslice_b{bits}" in v, v
+    # (the cooperative kernel carries at most 7 planes: an 8-bit class runs count_bitslice3_kernel alone and the variant says so)
+    assert "binary_full" in v and ("coop" in v) == (bits <= 7) and f"bitslice_b{bits}" in v, v
     assert (T.astype(np.uint64) == want).all(), v
     assert (T == T_plain).all()
     # two batches accumulate (the second launch reads-modifies-writes)
@@ -512,32 +513,43 @@ def test_depth_clamp_counts_bit_exact(eng, monkeypatch, kind, count_bits):
 
 def test_depth_clamp_budget_and_long_runs(eng, monkeypatch):
     """The clamp's decisions: the default budget (20 millionths of C(n,4) per bit saved) leaves a ladder alone (its cut subtree
-    is most of the tree), a run of more than 64 leaves is never cut whatever the budget, accumulation over two uploads and
+    is most of the tree), a run of more than 128 leaves is never cut whatever the budget, accumulation over two uploads and
     several panel slices per class keep the corrections with their slice, and a table shard takes only its own quartets."""
-    n = 90
+    import ctypes as C
+    n = 150
     ref_nw = synth.reference_tree(n, 9000)
     ref = flatten.flatten_reference(ref_nw)
     trees = [_ladder(n)] * 2 + synth.tree_set(n, 30, 9001)
-    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)     # ladder: 88 levels (7 bits), cut at 15: a run of 74
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=False)     # ladder: 148 levels (8 bits)
     monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
     monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
     ctx = eng.Context(n, 32)
     ctx.table_alloc()
     hb = ctx.batch_upload(batch, with_nodes=False)
-    assert ctx.batch_clamp_info(hb)[0] == 0                                     # default budget: nothing is cut at this size
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER)
+    ctx.sync()
+    assert "bitslice_b8" in ctx.last_count_variant()                             # default budget: the ladders keep their 8-bit class
     ctx.batch_free(hb)
     monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_DEPTH_CLAMP, 1000000)
+    # the host-only plan says what to expect: cut at 31 (5 bits) the ladder's run is 119 leaves, at 15 it is 135 > 128: never
+    L = _lib.load()
+    own, cls = np.zeros(batch.n_trees, np.uint8), np.zeros(batch.n_trees, np.uint8)
+    hbs = _lib.TreeBatchC(batch.n_trees, batch.leaf_off.ctypes.data, batch.leaf_ids.ctypes.data, batch.adj_depth.ctypes.data, None, None, None)
+    assert L.qs_depth_clamp_plan(n, C.byref(hbs), 1000000, own.ctypes.data, cls.ctypes.data, None) == 0
+    assert own[0] == 8 and cls[0] == 5 and (cls[2:] == 4).all()
     ctx = eng.Context(n, 32)
     ctx.table_alloc()
     hb = ctx.batch_upload(batch, with_nodes=False)
     ctx.count_batch(hb, eng.QS_ALGO_GATHER)
     ctx.sync()
     v = ctx.last_count_variant()
-    # cut at 63 (6 bits) the ladder's run is 26 leaves, at 31 (5 bits) 58: allowed; at 15 it is 74 > 64: never
-    assert "bitslice_b5" in v and "bitslice_b7" not in v and "/clamp:2" in v, v
+    assert "bitslice_b5" in v and "bitslice_b8" not in v and f"/clamp:{int((cls < own).sum())}" in v, v
     o = oracle_counts(ref_nw, trees)
     assert (ctx.table_download().astype(np.uint64) == o.counts()).all()
     ctx.batch_free(hb)
+    n = 90
+    ref_nw = synth.reference_tree(n, 9000)
+    ref = flatten.flatten_reference(ref_nw)
     # recentred ladders + NNIs: accumulate two uploads, 3 panel slices per class, on two table shards
     trees2 = synth.nni_tree_set(_ladder(n), 70, 9002, mean_nni=4) + synth.tree_set(n, 40, 9003)
     batch2 = flatten.flatten_eval_trees(trees2, ref.name_to_id)

@@ -435,12 +435,12 @@ def test_depth_clamp_arithmetic(n, m, clamp, seed, kw):
 def test_depth_clamp_plan_is_host_only_and_matches_the_emulation():
     """qs_depth_clamp_plan (the class plan qs_batch_upload applies) runs without a GPU: own depth bits, the class the budget
     allows, and a correction count equal to the emulation's run enumeration; budget 0 = no clamp; a ladder is never cut at the
-    default budget, and never where its run exceeds 64 leaves."""
+    default budget, and never where its run exceeds 128 leaves (the correction kernel's LDS table)."""
     import ctypes as C
     from math import comb
     from quartetscores_amd import _lib
     L = _lib.load()
-    n = 120
+    n = 200
     ref = flatten.flatten_reference(synth.reference_tree(n, 70))
     cat = "(t0,t1)"
     for i in range(2, n):
@@ -456,9 +456,10 @@ def test_depth_clamp_plan_is_host_only_and_matches_the_emulation():
         return own, cls, corr
 
     own, cls, corr = plan(0)
-    assert (own == cls).all() and not corr.any() and own[-1] == 7 and own[:-1].max() >= 5
+    assert (own == cls).all() and not corr.any() and own[-1] == 8 and own[:-1].max() >= 5
     own2, cls2, corr2 = plan(1000000)
-    assert (own2 == own).all() and (cls2[:-1] == 4).all() and cls2[-1] == 6     # ladder: cut at 63 = 57 leaves; at 31 = 89 > 64
+    # ladder of 198 levels: cut at 127 its run is 73 leaves (allowed), at 63 it is 137 > 128: never, whatever the budget
+    assert (own2 == own).all() and (cls2[:-1] == 4).all() and cls2[-1] == 7
     for t in range(m):
         lo, hi = int(batch.leaf_off[t]), int(batch.leaf_off[t + 1])
         runs = emulate.clamp_runs(batch.adj_depth[lo:hi], hi - lo, (1 << int(cls2[t])) - 1) if cls2[t] < own2[t] else []

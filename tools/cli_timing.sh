@@ -33,8 +33,8 @@ def timed(label, cmd, out):
 for t in ("1", "8", "64", "0"):
     timed(f"QuartetScores -t {t}", ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out.nwk", "-t", t], d + "/out.nwk")
 base_cmd = ["quartetscores_amd/bin/QuartetScores", "-r", d + "/ref.nwk", "-e", d + "/eval.nwk", "-o", d + "/out3.nwk", "-t", "8", "--gpus", "1"]
-for label, extra in (("--gpus 1, RCCL, counting beside ncclCommInitAll (default)", []),
-                     ("--gpus 1, RCCL, first launch waits for the communicators (--comm-overlap 0: round 3)", ["--comm-overlap", "0"]),
+for label, extra in (("--gpus 1, RCCL, counting beside ncclCommInitAll (--comm-overlap 1: A/B only)", ["--comm-overlap", "1"]),
+                     ("--gpus 1, RCCL, first launch waits for the communicators (--comm-overlap 0: the default)", ["--comm-overlap", "0"]),
                      ("--gpus 1 --reduce p2p (peer access, no communicator)", ["--reduce", "p2p"]),
                      ("--gpus 3 --reduce p2p --gpus-on-one-device (3 contexts, reduce-scatter by qs_sum_words)", ["--gpus", "3", "--reduce", "p2p", "--gpus-on-one-device"])):
     for rep in range(2):
