@@ -22,7 +22,8 @@
 #include "QuartetScoreComputer.hpp"
 
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is dlopen'ed (Rccl below)
+#include <dlfcn.h>
 
 #include <atomic>
 #include <future>
@@ -35,10 +36,41 @@ namespace qsh {
         hipError_t e__ = (expr);                                                                           \
         if (e__ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
+// RCCL is loaded on first use (dlopen), not linked: librccl.so is 570 MB of code objects that every start of the CLI would map
+// and register with the HIP runtime, although only `--gpus N --reduce rccl` ever calls it (round 5: the single-GPU CLI's wall).
+struct Rccl {
+    decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclAllReduce) AllReduce = nullptr;
+    decltype(&::ncclReduceScatter) ReduceScatter = nullptr;
+    static Rccl &get() {
+        static Rccl r = load();
+        return r;
+    }
+private:
+    static Rccl load() {
+        Rccl r;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) throw std::runtime_error(std::string("--reduce rccl: cannot load librccl.so.1: ") + dlerror());
+        auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) throw std::runtime_error(std::string("librccl.so.1 lacks ") + name); return p; };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(sym("ncclReduceScatter"));
+        return r;
+    }
+};
 #define QSM_NCCL(expr)                                                                                     \
     do {                                                                                                   \
         ncclResult_t r__ = (expr);                                                                         \
-        if (r__ != ncclSuccess) throw std::runtime_error(std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+        if (r__ != ncclSuccess) throw std::runtime_error(std::string(#expr) + ": " + Rccl::get().GetErrorString(r__)); \
     } while (0)
 
 struct MultiGpuScores {
@@ -79,14 +111,15 @@ public:
         const bool use_rccl = opt_.reduce != "p2p";
         if (use_rccl && !opt_.comm_overlap) comm_ready_ = comm_done.get_future().share();
         std::thread comm_init;
+        if (use_rccl) (void)Rccl::get();   // dlopen here, on this thread: a missing library is an exception the caller sees
         if (use_rccl)
-            comm_init = std::thread([&] { trace_mark(opt_, "rccl thread: ncclCommInitAll starts"); comm_rc = ncclCommInitAll(comms_.data(), G_, devs.data()); trace_mark(opt_, "rccl thread: communicators ready"); comm_done.set_value(); });
+            comm_init = std::thread([&] { trace_mark(opt_, "rccl thread: ncclCommInitAll starts"); comm_rc = Rccl::get().CommInitAll(comms_.data(), G_, devs.data()); trace_mark(opt_, "rccl thread: communicators ready"); comm_done.set_value(); });
         try {
             try { count(evalTreesPath, m); } catch (...) { if (comm_init.joinable()) comm_init.join(); throw; }
             trace_mark(opt_, "main: all GPUs counted");
             if (comm_init.joinable()) comm_init.join();
             trace_mark(opt_, use_rccl ? "main: communicators joined" : "main: no communicator (peer access)");
-            if (comm_rc != ncclSuccess) { comms_.assign(G_, nullptr); throw std::runtime_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(comm_rc)); }
+            if (comm_rc != ncclSuccess) { comms_.assign(G_, nullptr); throw std::runtime_error(std::string("ncclCommInitAll: ") + Rccl::get().GetErrorString(comm_rc)); }
             if (use_rccl) reduce(m); else reduce_p2p(m);
             trace_mark(opt_, "main: tables reduced");
             const auto t1 = std::chrono::steady_clock::now();
@@ -126,7 +159,7 @@ private:
     int dev_of(int g) const { return opt_.gpus_on_one_device ? opt_.device : opt_.device + g; }
 
     void release() {
-        for (auto &cm : comms_) if (cm) { (void)ncclCommDestroy(cm); cm = nullptr; }
+        for (auto &cm : comms_) if (cm) { (void)Rccl::get().CommDestroy(cm); cm = nullptr; }
         for (int g = 0; g < (int)ctx_.size(); ++g) {
             if (ctx_[g]) qs_destroy(ctx_[g]);
             (void)hipSetDevice(dev_of(g));
@@ -213,20 +246,20 @@ private:
         pack_two_cell(two_cell, words2);
         bool group_open = false;
         try {
-            QSM_NCCL(ncclGroupStart());
+            QSM_NCCL(Rccl::get().GroupStart());
             group_open = true;
             for (int g = 0; g < G_; ++g) {
                 QSM_HIP(hipSetDevice(dev_of(g)));
                 uint32_t *buf = (uint32_t *)table_[g];
-                if (full_) QSM_NCCL(ncclAllReduce(buf, buf, chunk_words_ * G_, ncclUint32, ncclSum, comms_[g], nullptr));
-                else if (two_cell) { uint32_t *sb = (uint32_t *)send_[g]; QSM_NCCL(ncclReduceScatter(sb, sb + (size_t)g * words2, words2, ncclUint32, ncclSum, comms_[g], nullptr)); }
-                else QSM_NCCL(ncclReduceScatter(buf, buf + (size_t)g * chunk_words_, chunk_words_, ncclUint32, ncclSum, comms_[g], nullptr));
+                if (full_) QSM_NCCL(Rccl::get().AllReduce(buf, buf, chunk_words_ * G_, ncclUint32, ncclSum, comms_[g], nullptr));
+                else if (two_cell) { uint32_t *sb = (uint32_t *)send_[g]; QSM_NCCL(Rccl::get().ReduceScatter(sb, sb + (size_t)g * words2, words2, ncclUint32, ncclSum, comms_[g], nullptr)); }
+                else QSM_NCCL(Rccl::get().ReduceScatter(buf, buf + (size_t)g * chunk_words_, chunk_words_, ncclUint32, ncclSum, comms_[g], nullptr));
             }
             group_open = false;
-            QSM_NCCL(ncclGroupEnd());
+            QSM_NCCL(Rccl::get().GroupEnd());
             for (int g = 0; g < G_; ++g) { QSM_HIP(hipSetDevice(dev_of(g))); QSM_HIP(hipDeviceSynchronize()); }
         } catch (...) {
-            if (group_open) (void)ncclGroupEnd();     // never destroy communicators inside an open group
+            if (group_open) (void)Rccl::get().GroupEnd();     // never destroy communicators inside an open group
             throw;
         }
         unpack_two_cell(two_cell, words2, m);

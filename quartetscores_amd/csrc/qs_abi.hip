@@ -14,12 +14,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <limits>
 #include <string>
 #include <thread>
 #include <vector>
 
 using namespace qs;
+
+struct EarlyPerm { std::vector<uint32_t> perm; uint32_t chunk = 0, cblock_in = 0, cgroup = 0; bool ok = false; };
 
 struct qs_device_batch {
     DeviceBatch d;
@@ -62,6 +65,7 @@ struct qs_ctx {
     // first use; [0] binary tiling (16x8), [1] general / partial tiling (8x8). NULL = (d,c)-major (identity).
     uint32_t *perm[2] = {nullptr, nullptr};
     bool perm_built[2] = {false, false};
+    std::future<EarlyPerm> perm_early;                 // the binary tiling's launch order, started by qs_create before its first HIP call
     uint32_t tile_chunk = 2, tile_cblock = 32;         // a-block (pairs) per chunk / c values per c-block; chunk 0 = (d,c)-major (round 3: 4 | 16 -> 2 | 32, -1.5 %)
     uint32_t tile_cgroup = 0;                          // > 1: c innermost in groups of this many (the waves of a workgroup share M[ab], M[bd])
     // binary tiling, cooperative workgroups (count_bitslice4_kernel): launch slots in groups of 4 tiles of one (a-blocks,
@@ -215,22 +219,21 @@ extern "C" const char *qs_last_error(const qs_ctx *ctx) { return ctx ? ctx->err.
 // M[bd] elements of (Bk, d-block) and the M[xc] rows of the c-block, which stay in its 4 MB L2; per (c,d) a chunk still
 // writes 8 contiguous runs of the table. Diagonal tiles follow at the end. 512 taxa x 10000 trees: 568 -> 401 ms,
 // 256 taxa: -35 %. Shards with more than 2^26 tiles keep the (d,c)-major order (the slot array would be > 256 MB).
-static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
-    *out = nullptr;
-    if (c->perm_built[which]) { *out = c->perm[which]; return QS_OK; }
-    c->perm_built[which] = true;
-    const bool bin = which == 0;
-    const uint32_t total = bin ? c->total_tiles3 : c->total_tiles1t;
-    const uint32_t chunk = c->tile_chunk;
-    if (chunk == 0 || total == 0 || total > (1u << 26)) return QS_OK;
-    const uint32_t d_hi = c->d_hi, n_dblk = c->n_dblk;
-    const std::vector<uint32_t> &cp = bin ? c->h_cp3 : c->h_cp, &dp = bin ? c->h_dp3 : c->h_dp1t;
-    std::vector<uint32_t> perm;
+// Host part of the launch order: the (a,b)-major enumeration of the tiles of one tiling (bin: 16x8 tiles of count_bitslice3_kernel's
+// two-column instances; else the 8x8 tiling) as launch slot -> tile id, checked to be a bijection. Pure host code (no context, no HIP):
+// qs_create starts it on a helper thread BEFORE its first HIP call, so that in a fresh process the ~25 ms it takes at 512 taxa pass
+// while the HIP runtime comes up (round 5: the CLI's first launch 25 ms earlier).
+struct TilePermParams { uint32_t chunk, cblock_in, cgroup, d_hi, n_dblk, total; bool bin; };
+static bool build_tile_perm(const TilePermParams &P, const std::vector<uint32_t> &cp, const std::vector<uint32_t> &dp, std::vector<uint32_t> &perm,
+                            std::string &err) {
+    const bool bin = P.bin;
+    const uint32_t total = P.total, chunk = P.chunk, d_hi = P.d_hi, n_dblk = P.n_dblk;
+    perm.clear();
     perm.reserve(total);
     auto T_of = [](uint32_t cc) { return (cc + 7) / 8; };
     const uint32_t cmax = d_hi >= 2 ? d_hi - 2 : 0;          // largest c of any tile
     const uint32_t Tmax = T_of(cmax);
-    const uint32_t cblock = c->tile_cblock ? c->tile_cblock : cmax + 1;
+    const uint32_t cblock = P.cblock_in ? P.cblock_in : cmax + 1;
     // off-diagonal tiles under b-block Bk. (Building the lists of several Bk on helper threads was tried: in the CLI, where 8 host
     // threads flatten the first batch at the same time, the set-up thread then was ready after 27-30 ms instead of 24.)
     auto emit_Bk = [&](uint32_t Bk, std::vector<uint32_t> &out) {
@@ -243,7 +246,7 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
             for (uint32_t cb = c_lo; cb <= cmax; cb += cblock)
                 for (uint32_t k = 0; k < n_dblk; ++k) {
                     const uint32_t d1 = d_hi - k * kDB;
-                    if (c->tile_cgroup <= 1) {
+                    if (P.cgroup <= 1) {
                         for (uint32_t cc = cb; cc < cb + cblock && cc + 1 < d1; ++cc) {
                             const uint32_t id = dp[k] + cp[cc] + base;
                             for (uint32_t j = j0; j < j1; ++j) out.push_back(id + j);
@@ -251,9 +254,9 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
                     } else {
                         // c innermost in groups of `cgroup`: the waves of a workgroup (consecutive slots) then hold the SAME
                         // (a-blocks, b-block, d-block) and consecutive c -- their M[ab] and M[bd] elements are identical
-                        for (uint32_t c4 = cb; c4 < cb + cblock && c4 + 1 < d1; c4 += c->tile_cgroup)
+                        for (uint32_t c4 = cb; c4 < cb + cblock && c4 + 1 < d1; c4 += P.cgroup)
                             for (uint32_t j = j0; j < j1; ++j)
-                                for (uint32_t cc = c4; cc < c4 + c->tile_cgroup && cc < cb + cblock && cc + 1 < d1; ++cc)
+                                for (uint32_t cc = c4; cc < c4 + P.cgroup && cc < cb + cblock && cc + 1 < d1; ++cc)
                                     out.push_back(dp[k] + cp[cc] + base + j);
                     }
                 }
@@ -268,14 +271,43 @@ static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
                 if (kd < (T + 1) / 2) perm.push_back(dp[k] + cp[cc] + (bin ? (T * T) / 4 : T * (T - 1) / 2) + kd);
             }
         }
-    if (perm.size() != total) return fail(c, QS_ERR_STATE, "tile order: enumeration does not match the tiling");
+    if (perm.size() != total) { err = "tile order: enumeration does not match the tiling"; return false; }
     {   // every tile exactly once: a tile listed twice would be counted by two waves (a race on its tuples), one left out never
         std::vector<uint64_t> seen((total + 63) / 64, 0);   // (a bit per tile: 350 KB at 512 taxa, stays in the host's L2)
         for (uint32_t id : perm) {
-            if (id >= total || ((seen[id >> 6] >> (id & 63)) & 1ull)) return fail(c, QS_ERR_STATE, "tile order: launch permutation is not a bijection");
+            if (id >= total || ((seen[id >> 6] >> (id & 63)) & 1ull)) { err = "tile order: launch permutation is not a bijection"; return false; }
             seen[id >> 6] |= 1ull << (id & 63);
         }
     }
+    return true;
+}
+
+static int tile_order(qs_ctx *c, int which, const uint32_t **out) {
+    *out = nullptr;
+    if (c->perm_built[which]) { *out = c->perm[which]; return QS_OK; }
+    c->perm_built[which] = true;
+    const bool bin = which == 0;
+    const uint32_t total = bin ? c->total_tiles3 : c->total_tiles1t;
+    const uint32_t chunk = c->tile_chunk;
+    if (chunk == 0 || total == 0 || total > (1u << 26)) {
+        if (bin && c->perm_early.valid()) c->perm_early.wait();
+        return QS_OK;
+    }
+    const uint32_t d_hi = c->d_hi, n_dblk = c->n_dblk;
+    const std::vector<uint32_t> &cp = bin ? c->h_cp3 : c->h_cp, &dp = bin ? c->h_dp3 : c->h_dp1t;
+    const TilePermParams P{chunk, c->tile_cblock, c->tile_cgroup, d_hi, n_dblk, total, bin};
+    std::vector<uint32_t> perm;
+    std::string perr;
+    bool have = false;
+    if (bin && c->perm_early.valid()) {       // started by qs_create beside the HIP start-up
+        EarlyPerm ep = c->perm_early.get();
+        if (ep.ok && ep.chunk == P.chunk && ep.cblock_in == P.cblock_in && ep.cgroup == P.cgroup) { perm.swap(ep.perm); have = true; }
+    }
+    if (!have && !build_tile_perm(P, cp, dp, perm, perr)) return fail(c, QS_ERR_STATE, perr);
+    auto T_of = [](uint32_t cc) { return (cc + 7) / 8; };
+    const uint32_t cmax = d_hi >= 2 ? d_hi - 2 : 0;
+    const uint32_t Tmax = T_of(cmax);
+    const uint32_t cblock = c->tile_cblock ? c->tile_cblock : cmax + 1;
     // Off unless asked for (QS_TUNE_COOP = 1): measured on MI355X the real barrier per 32-tree step costs more than the
     // shared loads save (512 taxa x 10000 trees: 368 ms against 354 ms; profiles/r03_experiments.md)
     if (bin && c->tune_coop == 1) {
@@ -410,13 +442,9 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     if (count_bits != 16 && count_bits != 32) return fail(nullptr, QS_ERR_ARG, "qs_create: count_bits must be 16 or 32");
     if (d_lo == 0 && d_hi == 0) d_hi = n_taxa;
     if (d_hi > n_taxa || d_lo >= d_hi) return fail(nullptr, QS_ERR_ARG, "qs_create: bad shard [d_lo, d_hi)");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0)
-        return fail(nullptr, QS_ERR_NO_DEVICE,
-                    "qs_create: no HIP device (this library has no CPU fallback; it needs a gfx950 GPU)");
-    if (device < 0 || device >= ndev) return fail(nullptr, QS_ERR_ARG, "qs_create: bad device ordinal");
-    QS_HIP(nullptr, hipSetDevice(device));
+    // Everything that needs no device first: the tile geometry and -- for large tilings, on a helper thread -- the launch order of the
+    // binary tiling (build_tile_perm: ~25 ms at 512 taxa), so that in a fresh process it is computed while the first HIP call below
+    // waits for the runtime to come up.
     qs_ctx *c = new qs_ctx();
     c->n = n_taxa; c->count_bits = count_bits; c->flags = flags; c->device = device;
     c->stream = (hipStream_t)stream;
@@ -439,6 +467,38 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     }
     if (tiles64 >= (1ull << 31)) { delete c; return fail(nullptr, QS_ERR_UNSUPPORTED, "qs_create: shard too large for one launch; use a narrower [d_lo, d_hi)"); }
     c->total_tiles = dp[c->n_dblk];
+    // the 16x8 tiles of count_bitslice3_kernel; block k = [max(d_start, d1 - 8), d1) with d1 = d_hi - 8k
+    std::vector<uint32_t> cp3(n_taxa + 2, 0), dp3(c->n_dblk + 1, 0), dp1(c->n_dblk + 1, 0);
+    {
+        for (uint32_t cc = 2; cc <= n_taxa; ++cc) cp3[cc + 1] = cp3[cc] + bitslice3_tiles_for_c(cc);
+        uint64_t t3 = 0;
+        for (uint32_t k = 0; k < c->n_dblk; ++k) { t3 += cp3[d_hi - k * kDB - 1]; dp3[k + 1] = (uint32_t)t3; }
+        if (t3 >= (1ull << 31)) { delete c; return fail(nullptr, QS_ERR_UNSUPPORTED, "qs_create: shard too large for one launch; use a narrower [d_lo, d_hi)"); }
+        c->total_tiles3 = dp3[c->n_dblk];
+        for (uint32_t k = 0; k < c->n_dblk; ++k) dp1[k + 1] = dp1[k] + cp[d_hi - k * kDB - 1]; // total equals total_tiles (< 2^31, checked above)
+        c->h_cp3 = cp3; c->h_dp3 = dp3; c->h_cp = cp; c->h_dp1t = dp1;
+        c->total_tiles1t = dp1[c->n_dblk];
+    }
+    if (c->total_tiles3 >= (1u << 20) && c->total_tiles3 <= (1u << 26) && c->tile_chunk) {
+        const TilePermParams P{c->tile_chunk, c->tile_cblock, c->tile_cgroup, c->d_hi, c->n_dblk, c->total_tiles3, true};
+        try {
+            c->perm_early = std::async(std::launch::async, [P, cp3, dp3] {
+                EarlyPerm ep; ep.chunk = P.chunk; ep.cblock_in = P.cblock_in; ep.cgroup = P.cgroup;
+                std::string err;
+                ep.ok = build_tile_perm(P, cp3, dp3, ep.perm, err);
+                return ep;
+            });
+        } catch (...) { c->perm_early = std::future<EarlyPerm>(); }   // no thread to be had: tile_order builds it when asked
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        delete c;   // (waits for the helper thread: a std::async future blocks in its destructor)
+        return fail(nullptr, QS_ERR_NO_DEVICE,
+                    "qs_create: no HIP device (this library has no CPU fallback; it needs a gfx950 GPU)");
+    }
+    if (device < 0 || device >= ndev) { delete c; return fail(nullptr, QS_ERR_ARG, "qs_create: bad device ordinal"); }
+    if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, QS_ERR_HIP, "qs_create: hipSetDevice"); }
     // the kernels take d_lo as the first d of block 0
     c->d_lo = d_lo; // shard boundary for ranks
     auto cleanup = [&](int code, const std::string &m) { qs_destroy(c); return fail(nullptr, code, m); };
@@ -446,24 +506,12 @@ extern "C" int qs_create(qs_ctx **out, uint32_t n_taxa, uint32_t count_bits, uin
     if (hipMalloc(&c->dprefix, dp.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix");
     if (hipMemcpy(c->cprefix, cp.data(), cp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix");
     if (hipMemcpy(c->dprefix, dp.data(), dp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix");
-    {   // the 16x8 tiles of count_bitslice3_kernel; block k = [max(d_start, d1 - 8), d1) with d1 = d_hi - 8k
-        std::vector<uint32_t> cp3(n_taxa + 2, 0), dp3(c->n_dblk + 1, 0);
-        for (uint32_t cc = 2; cc <= n_taxa; ++cc) cp3[cc + 1] = cp3[cc] + bitslice3_tiles_for_c(cc);
-        uint64_t t3 = 0;
-        for (uint32_t k = 0; k < c->n_dblk; ++k) { t3 += cp3[d_hi - k * kDB - 1]; dp3[k + 1] = (uint32_t)t3; }
-        if (t3 >= (1ull << 31)) return cleanup(QS_ERR_UNSUPPORTED, "qs_create: shard too large for one launch; use a narrower [d_lo, d_hi)");
-        c->total_tiles3 = dp3[c->n_dblk];
-        std::vector<uint32_t> dp1(c->n_dblk + 1, 0);
-        for (uint32_t k = 0; k < c->n_dblk; ++k) dp1[k + 1] = dp1[k] + cp[d_hi - k * kDB - 1]; // total equals total_tiles (< 2^31, checked above)
-        c->h_cp3 = cp3; c->h_dp3 = dp3; c->h_cp = cp; c->h_dp1t = dp1;
-        c->total_tiles1t = dp1[c->n_dblk];
-        if (hipMalloc(&c->dprefix1t, dp1.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix1t");
-        if (hipMemcpy(c->dprefix1t, dp1.data(), dp1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix1t");
-        if (hipMalloc(&c->cprefix3, cp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix3");
-        if (hipMalloc(&c->dprefix3, dp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix3");
-        if (hipMemcpy(c->cprefix3, cp3.data(), cp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix3");
-        if (hipMemcpy(c->dprefix3, dp3.data(), dp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix3");
-    }
+    if (hipMalloc(&c->dprefix1t, dp1.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix1t");
+    if (hipMemcpy(c->dprefix1t, dp1.data(), dp1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix1t");
+    if (hipMalloc(&c->cprefix3, cp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc cprefix3");
+    if (hipMalloc(&c->dprefix3, dp3.size() * 4) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc dprefix3");
+    if (hipMemcpy(c->cprefix3, cp3.data(), cp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy cprefix3");
+    if (hipMemcpy(c->dprefix3, dp3.data(), dp3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(QS_ERR_HIP, "memcpy dprefix3");
     if (hipMalloc(&c->dev_flags, 16) != hipSuccess) return cleanup(QS_ERR_OOM, "hipMalloc flags");
     if (hipMemset(c->dev_flags, 0, 16) != hipSuccess) return cleanup(QS_ERR_HIP, "memset flags");
     *out = c;

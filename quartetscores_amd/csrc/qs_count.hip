@@ -884,6 +884,20 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 #define QS_GEN3_MAXB 6   /* general / partial instances up to this many depth bits are held to 3 waves per SIMD (168 VGPRs, a few spills) */
 #endif
 
+// A/B switches of the general / partial instances (profiles/r05_experiments.md 3; 512 taxa x 1500 trees, 20 % of the edges collapsed,
+// ms per step on one box): OPAQUE 0 / 1 = 81.4 / 90.6 -- the opaque columns take the hot instance from 168 VGPRs + 9 spills to 147
+// and bring all seven panel loads to the top of the step, and it is 10 % SLOWER (with the row-ahead prefetch 85.0): measured, not
+// adopted. WBAR 0 / 1 / 2 = 81.4 / 81.3 / 82.2: the wave barrier is free, the wavefront fence is not.
+#ifndef QS_GEN_OPAQUE
+#define QS_GEN_OPAQUE 0     /* 1: general modes re-define the lane's LDS columns per step behind an empty asm (see the step) */
+#endif
+#ifndef QS_GEN_WBAR
+#define QS_GEN_WBAR 1       /* single-buffered LDS image: 0 = nothing between a step's reads and its writes, 1 = wave barrier (orders every instruction), 2 = wavefront-scope fence (orders memory operations only) */
+#endif
+template <int KIND> __device__ __forceinline__ void lds_order() {
+    if (KIND == 1) __builtin_amdgcn_wave_barrier();
+    else if (KIND == 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 #ifndef QS_GEN_PREFETCH
 #define QS_GEN_PREFETCH 0   /* 1: general modes request the next d-row's R elements one row ahead; 2: ... behind a scheduling barrier */
 #endif
@@ -1104,12 +1118,13 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         abn1 = gload(r, ab1off);
         if (A2) abn2 = gload(r, ab2off);
 
-        // The lane's LDS columns, re-defined per step behind an empty asm: in the straight-line (FULL) instance of the general
-        // modes LLVM otherwise hoists every (d-row, column) address out of the loop as a value of its own -- ~48 address
-        // registers in an instance that lives at the 168-VGPR limit, which pushed four of the seven panel loads behind the last
-        // d-row (an exposed L2 round trip per step). With the columns opaque the rows are immediate offsets from three bases.
+        // QS_GEN_OPAQUE (A/B only, off): in the straight-line (FULL) instance of the general modes LLVM hoists every (d-row, column)
+        // LDS address out of the loop as a value of its own -- ~48 address registers in an instance that lives at the 168-VGPR
+        // limit, which pushes four of the seven panel loads behind the last d-row. With the columns re-defined per step behind an
+        // empty asm the rows become immediate offsets from three bases (147 VGPRs, no spills, loads at the top) -- and the kernel
+        // runs 10 % slower (table above): what looks like an exposed L2 round trip is covered by the other two waves.
         uint32_t colA1 = colA1_, colA2 = colA2_, colB = colB_;
-        if (GEN) asm volatile("" : "+v"(colA1), "+v"(colA2), "+v"(colB));
+        if (GEN && QS_GEN_OPAQUE) asm volatile("" : "+v"(colA1), "+v"(colA2), "+v"(colB));
         const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1)); // M[a1 b] - M[a1 c] + 2^B
         Planes L2 = L1, G1 = L1, G2 = L1;
         if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));      // M[a2 b] - M[a2 c] + 2^B
@@ -1184,13 +1199,13 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(b
         // single-buffered image (cur == nxt): every read of this step above, every write of the next image below. LDS operations
         // of a wave execute in program order; the scheduling barrier keeps the compiler from moving a store above a load it
         // cannot prove disjoint (no instruction is emitted)
-        if (NBUF == 1) __builtin_amdgcn_wave_barrier();
+        if (NBUF == 1) lds_order<QS_GEN_WBAR>();
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
         if (NR >= 2) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
         if (NR == 3) lstore(nxt, slot2, sub_biased<B>(st.x2, st.y));
         if (B <= 4 && !PART) nxt[rowslot] = make_uint4(st.row.w[0], st.row.w[1], st.row.w[2], st.row.w[3]);
         else lstore(nxt, rowslot, st.row);
-        if (NBUF == 1) __builtin_amdgcn_wave_barrier();   // ... and the next step's reads stay behind these stores
+        if (NBUF == 1) lds_order<QS_GEN_WBAR>();   // ... and the next step's reads stay behind these stores
     };
 
     auto run = [&](auto a2_tag, auto full_tag, auto nr_tag) {

@@ -64,6 +64,7 @@ def check_full_size(eng, cfg_no, n, m, bits, d_lo=0, d_hi=0, expect_slices=True,
     ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE | eng.QS_COUNT_TIMED)
     ctx.sync()
     variant = ctx.last_count_variant()
+    ctx.first_variant, ctx.first_launches = variant, ctx.last_count_launches()
     assert "binary_full/bitslice" in variant, variant
     if expect_slices:   # the default panel-slice size is in force: several slices, i.e. the table read-modify-write path
         assert ctx.last_count_launches() > 1
@@ -120,10 +121,12 @@ def score_steps(ctx, ref, kernel):
 
 
 def test_configs2_512_taxa_10000_trees_u32(eng):
-    """BASELINE configs[2]: 34 GB table, depth classes B=4 / B=5, two panel slices = two launches (the second read-modify-writes
-    the table). Scoring at full size: the bundle kernel (43 000 planned rounds) and the scan kernel give the same
-    per-node-pair sums bit for bit and the same LQ-/QP-/EQP-IC."""
-    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 2, 512, 10000, 32)
+    """BASELINE configs[2]: 34 GB table. Since round 5 the depth clamp puts all 10 000 trees into the 4-bit class (7572 of them need
+    5 bits: clamp_fix_kernel adds 1.4e8 tied quartets) and the class is ONE slice = one launch; the accumulate run inside
+    check_full_size keeps the read-modify-write path under the gates. Scoring at full size: the bundle kernel (43 000 planned rounds) and the scan
+    kernel give the same per-node-pair sums bit for bit and the same LQ-/QP-/EQP-IC."""
+    ctx, table, (ref_nw, ref, text, batch) = check_full_size(eng, 2, 512, 10000, 32, expect_slices=False)
+    assert "/clamp:" in ctx.first_variant and "bitslice_b5" not in ctx.first_variant and ctx.first_launches == 1, ctx.first_variant
     assert ctx.table_bytes == 33958525440
     a, b = score_steps(ctx, ref, 0), score_steps(ctx, ref, 1)
     assert (a[0] == b[0]).all()

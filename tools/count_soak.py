@@ -1,6 +1,7 @@
 """Randomised soak of the count kernels: the bit-sliced kernel (default launch plan, and random slice sizes / tile orders /
 depth-class thresholds) against the byte-SWAR kernel on the same trees -- whole tables and random shards [d_lo, d_hi), both cell
-widths, binary / multifurcating / partial / ladder-like trees, accumulate across two batches -- and against the split-based
+widths, binary / multifurcating / partial / ladder-like trees, re-centred or not, accumulate across two batches, the depth clamp forced
+on every tree it can take (round 5) -- and against the split-based
 brute force (tests/bruteforce.py) on small cases.      python tools/count_soak.py [cases] [seed]"""
 import os
 import sys
@@ -15,6 +16,7 @@ from quartetscores_amd import _lib, engine, flatten, ranks, synth
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+clamped = 0
 for case in range(cases):
     n = int(rng.choice([4, 5, 7, 9, 16, 17, 24, 33, 40, 64, 65, 97, 130, 200, 257]))
     kind = str(rng.choice(["binary", "binary", "collapsed", "partial", "mixed", "ladder", "modes", "modes"]))
@@ -35,7 +37,8 @@ for case in range(cases):
         kw = {"collapsed": dict(collapse=0.25), "partial": dict(dropout=0.2), "mixed": dict(collapse=0.2, dropout=0.15)}.get(kind, {})
         trees = synth.tree_set(n, m, seed + 2, **kw)
     ref = flatten.flatten_reference(ref_nw)
-    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    recentre = bool(rng.random() < 0.65)             # un-centred trees are deep at moderate sizes: depth classes, the depth clamp
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id, recentre=recentre)
     half = batch.slice(0, max(1, m // 2)), batch.slice(max(1, m // 2), m)
     d_lo, d_hi = 0, n
     if n >= 9 and rng.random() < 0.4:
@@ -45,7 +48,11 @@ for case in range(cases):
                          ("random plan", {_lib.QS_TUNE_PANEL_SLICE_BYTES: int(rng.choice([1 << 12, 1 << 16, 1 << 20, 1 << 24])),
                                           _lib.QS_TUNE_TILE_ORDER: int(rng.choice([0, 1 | 4 << 16, 2 | 32 << 16, 4 | 16 << 16, 3 | 7 << 16])),
                                           _lib.QS_TUNE_CLASS_PCT: int(rng.choice([0, 10, 60, 100])),
-                                          _lib.QS_TUNE_CLASS_MIN_TREES: int(rng.choice([1, 8, 64, 1024]))})):
+                                          _lib.QS_TUNE_DEPTH_CLAMP: int(rng.choice([0, 20, 5000, 1000000])),
+                                          _lib.QS_TUNE_CLASS_MIN_TREES: int(rng.choice([1, 8, 64, 1024]))}),
+                         # round 5: every tree in the lowest class any budget allows -- the correction kernel on every shape
+                         ("clamp", {_lib.QS_TUNE_DEPTH_CLAMP: 1000000, _lib.QS_TUNE_CLASS_MIN_TREES: int(rng.choice([1, 1024])),
+                                    _lib.QS_TUNE_PANEL_SLICE_BYTES: int(rng.choice([0, 1 << 14, 1 << 20]))})):
         ctx = engine.Context(n, bits, d_lo=d_lo, d_hi=d_hi)
         for k_, v_ in tuning.items():
             ctx.set_tuning(k_, v_)
@@ -55,8 +62,9 @@ for case in range(cases):
             ctx.count_trees(half[1])                 # accumulate
         tables[name] = ctx.table_download().astype(np.uint64)
         variant = ctx.last_count_variant()
+        clamped += name == "clamp" and "/clamp:" in variant
         ctx.close()
-    ok = all(np.array_equal(tables["swar"], tables[k]) for k in ("default", "random plan"))
+    ok = all(np.array_equal(tables["swar"], tables[k]) for k in ("default", "random plan", "clamp"))
     why = "" if ok else " [bit-sliced != SWAR]"
     if n <= 33 and m <= 200:                         # the split-based brute force on every quartet of the table
         want = bruteforce.count_table(list(ref.names), trees)
@@ -67,6 +75,6 @@ for case in range(cases):
         if not np.array_equal(got, want[r0:r1]):
             ok = False; why += " [!= brute force]"
     bad += not ok
-    print(f"case {case}: n={n} m={m} u{bits} {kind} d[{d_lo},{d_hi}) seed={seed} {variant}: {'ok' if ok else 'MISMATCH' + why}", flush=True)
-print("mismatches:", bad)
+    print(f"case {case}: n={n} m={m} u{bits} {kind}{'' if recentre else ' (not re-centred)'} d[{d_lo},{d_hi}) seed={seed} {variant}: {'ok' if ok else 'MISMATCH' + why}", flush=True)
+print("mismatches:", bad, "| cases with trees below their own depth bits:", clamped)
 sys.exit(1 if bad else 0)
