@@ -1091,9 +1091,16 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
             for (uint32_t mo = 0; mo < kModes; ++mo)
                 for (uint32_t bb = top_bits; bb > 4; --bb) {
                     if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                    // the class below to join: the nearest one that is large enough for a pass of its own, or -- in a batch whose
+                    // classes are ALL small -- the nearest non-empty one that is at least as large as this one (joining the larger
+                    // neighbour downwards beats the rule below, which would send the larger class up to this one's depth bits)
                     uint32_t lo = bb - 1;
                     while (lo > 4 && cnt[mo][lo] < small) --lo;
-                    if (cnt[mo][lo] < small) continue;                  // no class below that is worth joining
+                    if (cnt[mo][lo] < small) {
+                        lo = bb - 1;
+                        while (lo > 4 && cnt[mo][lo] == 0) --lo;
+                        if (cnt[mo][lo] == 0 || cnt[mo][lo] < cnt[mo][bb]) continue;   // nothing below that is worth joining
+                    }
                     uint64_t total = 0;
                     bool finite = true;
                     std::vector<uint32_t> members;

@@ -888,6 +888,10 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
 // ms per step on one box): OPAQUE 0 / 1 = 81.4 / 90.6 -- the opaque columns take the hot instance from 168 VGPRs + 9 spills to 147
 // and bring all seven panel loads to the top of the step, and it is 10 % SLOWER (with the row-ahead prefetch 85.0): measured, not
 // adopted. WBAR 0 / 1 / 2 = 81.4 / 81.3 / 82.2: the wave barrier is free, the wavefront fence is not.
+#ifndef QS_BP4_WAVES
+#define QS_BP4_WAVES 1      /* binary_partial at 4 depth bits is held to 4 waves per SIMD (128 VGPRs + 6 spilled; it would take 133): 512 taxa x
+                             * 1500 trees with 10 % of the taxa dropped 67.0 / 67.2 -> 63.7 / 63.4 ms (round 5; at 5 bits, 152 VGPRs, round 4 measured no gain) */
+#endif
 #ifndef QS_GEN_OPAQUE
 #define QS_GEN_OPAQUE 0     /* 1: general modes re-define the lane's LDS columns per step behind an empty asm (see the step) */
 #endif
@@ -928,7 +932,7 @@ template <int B, int MODE> constexpr int bs3_waves() {
     constexpr bool gen = MODE == MODE_GENERAL_FULL || MODE == MODE_PARTIAL;
     if (gen) return B <= (MODE == MODE_PARTIAL ? QS_GEN3_MAXB - 1 : QS_GEN3_MAXB) ? 3 : 2;   // two a-columns + three counters per quartet: 172-192 VGPRs unconstrained (B <= 6)
     if (B >= 10 || (B >= 7 && MODE == MODE_BINARY_PARTIAL)) return 2;
-    if (MODE == MODE_BINARY_PARTIAL) return 3;
+    if (MODE == MODE_BINARY_PARTIAL) return (B <= 4 && QS_BP4_WAVES) ? 4 : 3;
     if (B >= 8) return 3;
     if (B == 7 && MODE == MODE_BINARY_FULL) return 3;
     return QS_BS3_WAVES;

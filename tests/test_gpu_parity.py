@@ -572,6 +572,39 @@ def test_depth_clamp_budget_and_long_runs(eng, monkeypatch):
     assert lo_tuples == len(want)
 
 
+def test_a_few_deep_trees_join_the_larger_class_below_them(eng):
+    """Default tuning, a batch whose classes are ALL below the 1024-tree floor: 50 trees that fit 4 depth bits and 3 whose one deep
+    subtree (5 leaves below depth 15) needs 5. The old rule sent the larger class UP to the smaller one's depth bits; now the few
+    deep trees go down (395 tied quartets each, far below the price of a table pass) and the batch is one 4-bit class. Table = oracle."""
+    n = 44
+    ref_nw = synth.reference_tree(n, 4500)
+    ref = flatten.flatten_reference(ref_nw)
+    rng = np.random.default_rng(45)
+    deep = []
+    for _ in range(3):
+        order = [int(x) for x in rng.permutation(n)]
+        sub = f"((t{order[0]},t{order[1]}),t{order[2]})"                        # inner nodes at depths 17 and 18
+        for x in order[3:19]:                                                    # a spine of 16 single leaves above it
+            sub = f"({sub},t{x})"
+        rest = synth._to_newick(synth._join_random([f"t{x}" for x in order[19:]], rng, stop_at=2))
+        deep.append(f"({sub},{rest[1:-1]});")
+    trees = synth.tree_set(n, 50, 4501) + deep
+    batch_a = flatten.flatten_eval_trees(trees[:50], ref.name_to_id)
+    batch_b = flatten.flatten_eval_trees(deep, ref.name_to_id, recentre=False)
+    assert int(batch_a.adj_depth.max()) <= 15 and 16 <= int(batch_b.adj_depth.max()) <= 31
+    batch = _concat_batches(batch_a, batch_b)
+    ctx = eng.Context(n, 32)
+    ctx.table_alloc()
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    assert ctx.batch_clamp_info(hb)[0] == 3 and ctx.batch_clamp_info(hb)[1] == 3 * (10 * 39 + 5)   # C(5,3) (44 - 5) + C(5,4) per tree
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER)
+    ctx.sync()
+    v = ctx.last_count_variant()
+    assert "bitslice_b4x2" in v and "bitslice_b5" not in v and "/clamp:3" in v and ":" not in v.split("/clamp")[0], v
+    assert (ctx.table_download().astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all()
+    ctx.batch_free(hb)
+
+
 def test_depth_clamp_in_the_wire_format(eng, monkeypatch):
     """QS_COUNT_WIRE16X2 with clamped trees: the corrections go to the wire words (n0 | n1 << 16; n2 is implied)."""
     import torch
