@@ -904,7 +904,8 @@ struct Stager {
     }
 };
 
-// ---- depth clamp (qs_count.hip clamp_fix_kernel) -----------------------------------------------------------------------------
+// ---- depth clamp (qs_count.hip clamp_fix_kernel): the plan -- "plan_depth_clamp" in qs_count.hip's comments and DESIGN.md = clamp_cost +
+// clamp_choice below and the class rules of qs_batch_upload ------------------------------------------------------------------------
 // (tree, quartet) corrections a tree costs when its LCA depths are cut at `cut`: the quartets with at least three leaves in one
 // maximal run of tour-adjacent LCA depths >= cut (a subtree below a node of depth `cut`): C(s,3)(L - s) + C(s,4) per run of s
 // leaves. ~0 when a run is longer than the kernel's LDS table takes. runs (optional): (first position, leaves) of every run.
