@@ -425,6 +425,11 @@ def test_cli_savemem_with_a_rooted_reference_ends_like_the_reference(tmp_path, d
     assert p.returncode == 1 and not out.exists()
     assert "ERROR: " + fx["reference_throws"] in p.stderr
     assert "Finished counting quartets." in p.stdout           # the reference counts first, then dies in the scoring loop
+    assert "Note: -s with a rooted reference tree" in p.stderr  # round 5: known from the tree alone (qs_score_check), said before the counting
+    if driver == "single":                                      # --fail-fast ends the run at the note, with the same error text
+        pf = run("-r", str(r), "-e", str(e), "-o", str(out), "-s", "--fail-fast")
+        assert pf.returncode == 1 and not out.exists() and "ERROR: " + fx["reference_throws"] in pf.stderr
+        assert "Finished counting quartets." not in pf.stdout and "Counting" not in pf.stdout
     ok = tmp_path / "ok.nwk"
     p = run("-r", str(r), "-e", str(e), "-o", str(ok), *extra)
     assert p.returncode == 0 and ok.exists() and "NOT reproduced" not in p.stderr and "Note:" not in p.stderr

@@ -339,6 +339,12 @@ def test_rooted_reference_compact_mode_host_logic_matches_oracle(golden, name, n
         engine.score_finish_host(ref, sums, cand, _lib.QS_SCORE_SAVEMEM_LOOKUPS)
     assert eg.value.code == _lib.QS_ERR_REFERENCE_THROWS
     assert str(eg.value).endswith(str(eo.value)), (str(eg.value), str(eo.value))
+    # round 5: the same answer from the reference tree alone, before anything is counted (qs_score_check without a context)
+    with pytest.raises(engine.QSError) as ec:
+        engine.score_check(ref, _lib.QS_SCORE_SAVEMEM_LOOKUPS)
+    assert ec.value.code == _lib.QS_ERR_REFERENCE_THROWS and str(ec.value).endswith(str(eo.value))
+    engine.score_check(ref, 0)
+    engine.score_check(ref, _lib.QS_SCORE_SAVEMEM_LOOKUPS | _lib.QS_SCORE_ROOT_AS_EDGE)
     # no flag, or the root treated as a point on an edge: no exception (the n^4 table's behaviour / no repeated ids at all)
     engine.score_finish_host(ref, sums, cand, 0)
     engine.score_finish_host(ref, sums, cand, _lib.QS_SCORE_SAVEMEM_LOOKUPS | _lib.QS_SCORE_ROOT_AS_EDGE)

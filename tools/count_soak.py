@@ -19,7 +19,7 @@ bad = 0
 clamped = 0
 for case in range(cases):
     n = int(rng.choice([4, 5, 7, 9, 16, 17, 24, 33, 40, 64, 65, 97, 130, 200, 257]))
-    kind = str(rng.choice(["binary", "binary", "collapsed", "partial", "mixed", "ladder", "modes", "modes"]))
+    kind = str(rng.choice(["binary", "binary", "collapsed", "partial", "mixed", "ladder", "modes", "modes", "rooted"]))
     m = int(rng.choice([1, 31, 33, 200, 1500])) if n <= 130 else int(rng.choice([40, 300]))
     bits = int(rng.choice([16, 32]))
     seed = int(rng.integers(1, 1 << 30))
@@ -34,7 +34,8 @@ for case in range(cases):
         sets = [synth.tree_set(n, (m + 3) // 4, seed + 10 + i, **kw) for i, kw in enumerate(kws)]
         trees = [sets[i % 4][i // 4] for i in range(m)]
     else:
-        kw = {"collapsed": dict(collapse=0.25), "partial": dict(dropout=0.2), "mixed": dict(collapse=0.2, dropout=0.15)}.get(kind, {})
+        kw = {"collapsed": dict(collapse=0.25), "partial": dict(dropout=0.2), "mixed": dict(collapse=0.2, dropout=0.15),
+              "rooted": dict(rooted=True, dropout=float(rng.choice([0.0, 0.1])))}.get(kind, {})   # degree-2 root in the evaluation trees
         trees = synth.tree_set(n, m, seed + 2, **kw)
     ref = flatten.flatten_reference(ref_nw)
     recentre = bool(rng.random() < 0.65)             # un-centred trees are deep at moderate sizes: depth classes, the depth clamp
