@@ -1001,7 +1001,7 @@ def main():
                          + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
                          + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else (", mixed thirds" if args.mixed else "") + f", collapse {args.collapse} dropout {args.dropout}")
                          + f", seeds {seed_ref}/{seed_set}")[:100],
-            "baseline_config": (f"BASELINE.json configs[{cfg_no - 1}] (bench.py --config {cfg_no})" if not custom else "custom (not a BASELINE config)"),
+            "baseline_config": (f"BASELINE.json configs[{cfg_no}] (bench.py --config {cfg_no})" if not custom else "custom (not a BASELINE config)"),
             "one_rank_same_workload": same_workload_scaling(value, world, m * nq_all, count_only_ms, elapsed / steps * 1e3) if count_only_ms else None,
             "quartets": nq_all,
             "quartets_this_rank": nq,
