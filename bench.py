@@ -1030,7 +1030,7 @@ def main():
             "kernels_of_last_timed_step": [[k_, round(ms_, 3)] for k_, ms_ in last_events][:24],
             "depth_clamp": {"trees_below_own_depth_bits": clamp_info[0], "tree_quartet_corrections": clamp_info[1], "fix_workgroups": clamp_info[2],
                             "fix_kernels_ms_last_timed_step": round(last_fix_ms, 3) if last_fix_ms is not None else None,
-                            "note": "trees counted in a class below their depth bits; clamp_fix_kernel adds the tied quartets (in count_kernels_ms)"},
+                            "note": "trees in a class below their depth bits; clamp_fix_kernel adds the tied quartets (in count ms)"},
             "gpu_ms_per_step_events_over_timed_region": region_gpu_ms,
             "score_mode": score_mode,
             "score_phase_ms": score_ms,
@@ -1040,7 +1040,7 @@ def main():
             "score_roofline": score_roofline,
             "input_generation_s": gen_s,
             "box_issue_probe_ns_per_inst": box_probe_ns,
-            "box_issue_probe_note": "bare 24 v_bitop3 + 4 v_bcnt slot at 4 waves/SIMD on this device; 1.39-1.40 in profiles/r03_valu_yardstick.txt",
+            "box_issue_probe_note": "bare 24 v_bitop3 + 4 v_bcnt slot, 4 waves/SIMD, this device; 1.39-1.40 in r03_valu_yardstick.txt",
         },
     }
     # SURVEY 8(d) defines the phase from "trees resident on host": the same step with qs_batch_upload (validation, class plan, pinned
@@ -1049,7 +1049,7 @@ def main():
         out["value_upload_inclusive"] = (m * nq) / (upload_step_ms * 1e-3) * (world if not shards > 1 else 1)
         out["ms_per_step_upload_inclusive"] = upload_step_ms
         out["config"]["resident_ms_per_step"] = elapsed / steps * 1e3
-        out["config"]["value_definition"] = "value: inputs resident in HBM (bench contract); value_upload_inclusive: host arrays -> table (SURVEY 8(d))"
+        out["config"]["value_definition"] = "value: inputs in HBM (bench contract); value_upload_inclusive: host arrays -> table (SURVEY 8d)"
     # e2e: what the product delivers when the inputs are NOT yet resident (never `value`)
     if upload_step_ms or cli_e2e:
         e2e = {"note": "inputs not resident: never `value`"}
