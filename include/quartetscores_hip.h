@@ -408,6 +408,12 @@ int qs_batch_clamp_info(const qs_device_batch *batch, uint64_t out[3]);
  * The reference's loop is shape-independent (QuartetCounterLookup.hpp:65-106): this replaces nothing there. */
 int qs_depth_clamp_plan(uint32_t n_taxa, const qs_tree_batch *batch, uint32_t ppm, uint8_t *own_bits, uint8_t *class_bits,
                         uint64_t *corrections);
+/* Host-only: the classes qs_batch_upload forms for these trees with the floors QS_TUNE_CLASS_MIN_TREES / QS_TUNE_CLASS_PCT and the clamp
+ * budget given: per tree the kernel mode (0 binary_full, 1 general_full, 2 partial, 3 binary_partial) and depth bits of the class it is
+ * counted in (a small class joins a more general mode, goes down to a larger class where the corrections allow it, or joins the next
+ * deeper class), and the tree's slot in the class-ordered batch. Any output may be NULL. The trees are not validated here. */
+int qs_class_plan(uint32_t n_taxa, const qs_tree_batch *batch, uint32_t class_min_trees, uint32_t class_pct, uint32_t clamp_ppm,
+                  uint8_t *mode_of_tree, uint8_t *bits_of_tree, uint32_t *slot_of_tree);
 /* Phases of the most recent qs_score call in milliseconds: [0] the whole call (host clock), [1] set-up (accumulator
  * allocation, reference tree + LCA matrix, log table: near zero once cached in the context), [2] pass 1 and [3] pass 2
  * (HIP events on the context's stream; [3] = the filter over pass 1's candidate log in single-read mode), [4] host wait for the passes incl. the overflow pass and the accumulators' way

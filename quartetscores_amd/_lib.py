@@ -33,7 +33,7 @@ EXPORTS = [
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
     "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
-    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan", "qs_score_check", "qs_last_count_events",
+    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan", "qs_score_check", "qs_last_count_events", "qs_class_plan",
 ]
 
 
@@ -173,6 +173,8 @@ def load():
     L.qs_batch_clamp_info.argtypes = [vp, C.POINTER(u64 * 3)]
     L.qs_last_count_events.restype = i32
     L.qs_last_count_events.argtypes = [vp, vp, vp, i32]
+    L.qs_class_plan.restype = i32
+    L.qs_class_plan.argtypes = [u32, C.POINTER(TreeBatchC), u32, u32, u32, vp, vp, vp]
     L.qs_score_check.restype = i32
     L.qs_score_check.argtypes = [vp, C.POINTER(RefTreeC), u32]
     L.qs_depth_clamp_plan.restype = i32

@@ -946,6 +946,148 @@ static void clamp_choice(const uint16_t *adj, uint32_t L, uint32_t own_bits, uin
     }
 }
 
+// ---- classes of a batch (host-only: qs_batch_upload and qs_class_plan) --------------------------------------------------------------
+// What validation knows about every tree: its deepest LCA, the cheapest kernel mode that is exact for it, and the lowest depth class
+// the clamp budget allows it (soft: the rule for every tree; hard: 16 x, for the trees of a class too small for a pass of its own).
+struct TreeFacts { std::vector<uint16_t> depth; std::vector<uint8_t> mode, soft, hard; };
+// deepest adjacent LCA and "fully resolved" of one tree from its adjacent-LCA depth sequence
+static void tree_shape(const uint16_t *adj, uint32_t L, std::vector<uint32_t> &stack, uint32_t &depth, bool &binary) {
+    stack.clear();
+    uint32_t nodes = 0, zeros = 0;
+    depth = 0;
+    for (uint32_t i = 0; i + 1 < L; ++i) {
+        const uint32_t dd = adj[i];
+        depth = std::max(depth, dd);
+        if (dd == 0) ++zeros;
+        while (!stack.empty() && stack.back() > dd) stack.pop_back();
+        if (stack.empty() || stack.back() < dd) { stack.push_back(dd); ++nodes; }
+    }
+    binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
+}
+struct ClassPlan {
+    uint32_t n_classes = 0;
+    uint32_t class_mode[DeviceBatch::kMaxClasses] = {0}, class_bits[DeviceBatch::kMaxClasses] = {0}, class_end[DeviceBatch::kMaxClasses] = {0},
+             class_max_depth[DeviceBatch::kMaxClasses] = {0};
+    std::vector<uint32_t> order;       // slot -> tree (empty = identity: one class)
+    std::vector<uint8_t> bits, mode;   // per tree: depth bits and kernel mode of the class it is counted in
+};
+// Classes = (kernel mode, depth bits) per TREE. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B
+// of the class (2(B+1)+2 instructions for full binary trees, B >= 4) and with what the trees may contain: binary trees with
+// missing taxa 2(B+1)+5, multifurcating trees 3(B+1)+3, both 3(B+1)+7. One deep, one multifurcating or one incomplete tree
+// must not put the whole batch on the dearest instance (the reference's loop is shape-independent,
+// QuartetCounterLookup.hpp:65-106), so trees are counted class by class: B = 4 .. 10 and "deeper" (byte-SWAR kernel, 16-bit
+// depths) within each of the four modes. Every class costs at least one more panel slice = one more pass over the table, so a
+// class that holds fewer than max(class_min, class_pct %) of the trees joins one that is exact for it: first a whole mode joins
+// a more general mode that is present (binary_full -> binary_partial, general_full or partial; binary_partial, general_full
+// -> partial), then -- depth clamp -- a small deep class goes DOWN where the corrections allow it, else a depth class joins
+// the next deeper one of its mode.
+static void plan_classes(uint32_t n, uint32_t nt, const uint32_t *leaf_off, const uint16_t *adj_depth, const TreeFacts &F, uint32_t class_min,
+                         uint32_t class_pct, uint32_t clamp_ppm, ClassPlan &P) {
+    {
+        constexpr uint32_t top_bits = 10, deep = 11;   // depth class id = depth bits; `deep` = beyond the bit-sliced instances
+        constexpr uint32_t kModes = 4, kBits = 12;
+        // Depth clamp: a tree may sit in a class BELOW its own depth bits -- the panel builders cut its depths at the class's
+        // largest value and clamp_fix_kernel adds the quartets the cut ties (qs_count.hip) -- when that costs less than the
+        // instructions it saves (eff_soft: 2 of 2(B+1)+2 per bit and quartet against a few thousand atomics per tree).
+        uint32_t cnt[kModes][kBits] = {{0}}, mx[kModes][kBits] = {{0}};
+        std::vector<uint8_t> cls(nt);
+        for (uint32_t t = 0; t < nt; ++t) {
+            cls[t] = F.soft[t];
+            cnt[F.mode[t]][cls[t]]++;
+        }
+        const uint32_t small = std::max<uint32_t>(class_min, (uint32_t)((uint64_t)nt * class_pct / 100));
+        uint32_t mode_map[kModes] = {0, 1, 2, 3};
+        auto total = [&](uint32_t mo) { uint32_t s_ = 0; for (uint32_t bb = 0; bb < kBits; ++bb) s_ += cnt[mo][bb]; return s_; };
+        auto join_mode = [&](uint32_t from, std::initializer_list<uint32_t> into) {
+            const uint32_t tf = total(from);
+            if (tf == 0 || tf >= small) return;
+            for (uint32_t to : into) {
+                if (total(to) == 0) continue;
+                for (uint32_t bb = 0; bb < kBits; ++bb) { cnt[to][bb] += cnt[from][bb]; mx[to][bb] = std::max(mx[to][bb], mx[from][bb]); cnt[from][bb] = 0; }
+                mode_map[from] = to;
+                return;
+            }
+        };
+        join_mode(MODE_BINARY_FULL, {MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL});
+        join_mode(MODE_BINARY_PARTIAL, {MODE_PARTIAL});
+        join_mode(MODE_GENERAL_FULL, {MODE_PARTIAL});
+        auto final_mode = [&](uint32_t mo) { while (mode_map[mo] != mo) mo = mode_map[mo]; return mo; };
+        // a class too small for a pass of its own: its trees go DOWN to a class that is large enough where the 16-fold budget allows
+        // it (what is left joins the next deeper class below, as before)
+        if (clamp_ppm)
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t mo = final_mode(F.mode[t]), bb = cls[t];
+                if (cnt[mo][bb] >= small || F.hard[t] >= bb) continue;
+                for (uint32_t lo = bb - 1; lo >= F.hard[t] && lo >= 4; --lo)
+                    if (cnt[mo][lo] >= small) { cnt[mo][bb]--; cnt[mo][lo]++; cls[t] = (uint8_t)lo; break; }
+            }
+        // ... and a class that is still small after that costs a launch of its own = one more pass over the table (10-20 ms at
+        // 34 GB) plus the waves' fixed cost for a handful of trees: its trees go down at ANY finite price, as long as the sum stays
+        // below what the pass would cost (5 % of C(n,4) corrections ~ 1.4e8 at 512 taxa)
+        if (clamp_ppm)
+            for (uint32_t mo = 0; mo < kModes; ++mo)
+                for (uint32_t bb = top_bits; bb > 4; --bb) {
+                    if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                    // the class below to join: the nearest one that is large enough for a pass of its own, or -- in a batch whose
+                    // classes are ALL small -- the nearest non-empty one that is at least as large as this one (joining the larger
+                    // neighbour downwards beats the rule below, which would send the larger class up to this one's depth bits)
+                    uint32_t lo = bb - 1;
+                    while (lo > 4 && cnt[mo][lo] < small) --lo;
+                    if (cnt[mo][lo] < small) {
+                        lo = bb - 1;
+                        while (lo > 4 && cnt[mo][lo] == 0) --lo;
+                        if (cnt[mo][lo] == 0 || cnt[mo][lo] < cnt[mo][bb]) continue;   // nothing below that is worth joining
+                    }
+                    uint64_t total = 0;
+                    bool finite = true;
+                    std::vector<uint32_t> members;
+                    for (uint32_t t = 0; t < nt && finite; ++t) {
+                        if (final_mode(F.mode[t]) != mo || cls[t] != bb) continue;
+                        const uint32_t base = leaf_off[t], L = leaf_off[t + 1] - base;
+                        const uint64_t cost = clamp_cost(adj_depth + base, L, (1u << lo) - 1u, nullptr);
+                        if (cost == ~0ull) finite = false; else { total += cost; members.push_back(t); }
+                    }
+                    if (!finite || total > binom4(n) / 20) continue;
+                    for (uint32_t t : members) cls[t] = (uint8_t)lo;
+                    cnt[mo][lo] += cnt[mo][bb]; cnt[mo][bb] = 0;
+                }
+        for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(F.mode[t]); mx[mo][cls[t]] = std::max<uint32_t>(mx[mo][cls[t]], F.depth[t]); }
+        uint32_t remap[kModes][kBits];
+        for (uint32_t mo = 0; mo < kModes; ++mo) {
+            for (uint32_t bb = 0; bb < kBits; ++bb) remap[mo][bb] = bb;
+            for (uint32_t bb = 4; bb < top_bits; ++bb) {
+                if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                uint32_t up = bb + 1;
+                while (up <= top_bits && cnt[mo][up] == 0) ++up;
+                if (up > top_bits) continue;               // nothing above it among the bit-sliced classes of this mode
+                cnt[mo][up] += cnt[mo][bb]; mx[mo][up] = std::max(mx[mo][up], mx[mo][bb]); cnt[mo][bb] = 0; remap[mo][bb] = up;
+            }
+        }
+        auto final_cls = [&](uint32_t mo, uint32_t k) { while (remap[mo][k] != k) k = remap[mo][k]; return k; };
+        P.n_classes = 0;
+        uint32_t run = 0, start[kModes][kBits] = {{0}};
+        // launch order: the dearest instances first? No: by mode, then depth -- binary_full first (its first slice stores
+        // instead of accumulating when the caller asks for QS_COUNT_OVERWRITE; any class may be the first)
+        static const uint32_t mode_seq[kModes] = {MODE_BINARY_FULL, MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL};
+        for (uint32_t mi = 0; mi < kModes; ++mi) {
+            const uint32_t mo = mode_seq[mi];
+            for (uint32_t k = 4; k <= deep; ++k) {
+                if (cnt[mo][k] == 0) continue;
+                start[mo][k] = run; run += cnt[mo][k];
+                P.class_mode[P.n_classes] = mo; P.class_bits[P.n_classes] = k; P.class_end[P.n_classes] = run; P.class_max_depth[P.n_classes] = mx[mo][k];
+                P.n_classes++;
+            }
+        }
+        P.bits.resize(nt); P.mode.resize(nt);
+        for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(F.mode[t]); P.mode[t] = (uint8_t)mo; P.bits[t] = (uint8_t)final_cls(mo, cls[t]); }
+        P.order.clear();
+        if (P.n_classes > 1) {
+            P.order.resize(nt);
+            for (uint32_t t = 0; t < nt; ++t) P.order[start[P.mode[t]][P.bits[t]]++] = t;
+        }
+    }
+}
+
 /* Host-only (no device call): the class plan of qs_batch_upload for the trees of `hb` on n_taxa taxa with the depth-clamp budget
  * `ppm` (QS_TUNE_DEPTH_CLAMP): per tree its own depth bits, the depth bits of the cheapest class the budget allows, and the
  * (tree, quartet) corrections that class costs. For tests and tools; qs_batch_upload applies the same functions. */
@@ -963,6 +1105,39 @@ extern "C" int qs_depth_clamp_plan(uint32_t n_taxa, const qs_tree_batch *hb, uin
         if (own_bits) own_bits[t] = (uint8_t)own;
         if (class_bits) class_bits[t] = soft;
         if (corrections) corrections[t] = soft < own ? clamp_cost(hb->adj_depth + base, L, (1u << soft) - 1u, nullptr) : 0;
+    }
+    return QS_OK;
+}
+
+/* Host-only: the classes qs_batch_upload forms for the trees of `hb` (which it does not validate) with the given floors and clamp
+ * budget: per tree the kernel mode (0 binary_full, 1 general_full, 2 partial, 3 binary_partial) and depth bits of the class it is
+ * counted in, and its slot in the class-ordered batch. */
+extern "C" int qs_class_plan(uint32_t n_taxa, const qs_tree_batch *hb, uint32_t class_min_trees, uint32_t class_pct, uint32_t clamp_ppm,
+                             uint8_t *mode_of_tree, uint8_t *bits_of_tree, uint32_t *slot_of_tree) {
+    if (!hb || !hb->leaf_off || (hb->n_trees && !hb->adj_depth) || n_taxa < 4 || class_pct > 100) return QS_ERR_ARG;
+    const uint32_t nt = hb->n_trees;
+    const uint64_t budget = (uint64_t)((double)binom4(n_taxa) * (double)clamp_ppm * 1e-6);
+    TreeFacts F;
+    F.depth.resize(nt); F.mode.resize(nt); F.soft.resize(nt); F.hard.resize(nt);
+    std::vector<uint32_t> stack;
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
+        uint32_t depth = 0;
+        bool binary = false;
+        tree_shape(hb->adj_depth + base, L, stack, depth, binary);
+        F.depth[t] = (uint16_t)depth;
+        F.mode[t] = (uint8_t)(L == n_taxa ? (binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL) : (binary ? MODE_BINARY_PARTIAL : MODE_PARTIAL));
+        clamp_choice(hb->adj_depth + base, L, depth_class_of(depth), budget, F.soft[t], F.hard[t]);
+    }
+    ClassPlan P;
+    plan_classes(n_taxa, nt, hb->leaf_off, hb->adj_depth, F, class_min_trees, class_pct, clamp_ppm, P);
+    for (uint32_t t = 0; t < nt; ++t) {
+        if (mode_of_tree) mode_of_tree[t] = P.mode[t];
+        if (bits_of_tree) bits_of_tree[t] = P.bits[t];
+    }
+    if (slot_of_tree) {
+        if (P.order.empty()) for (uint32_t t = 0; t < nt; ++t) slot_of_tree[t] = t;
+        else for (uint32_t sl = 0; sl < nt; ++sl) slot_of_tree[P.order[sl]] = sl;
     }
     return QS_OK;
 }
@@ -996,17 +1171,11 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
                 stamp[id] = t;
             }
             // internal nodes from the adjacent-LCA depth sequence
-            stack.clear();
-            uint32_t nodes = 0, zeros = 0;
-            for (uint32_t i = 0; i + 1 < L; ++i) {
-                const uint32_t dd = hb->adj_depth[base + i];
-                P.max_depth = std::max(P.max_depth, dd);
-                tree_depth[t] = (uint16_t)std::max<uint32_t>(tree_depth[t], dd);
-                if (dd == 0) ++zeros;
-                while (!stack.empty() && stack.back() > dd) stack.pop_back();
-                if (stack.empty() || stack.back() < dd) { stack.push_back(dd); ++nodes; }
-            }
-            const bool binary = L >= 3 && (zeros == 1 || zeros == 2) && (L - 1 - zeros) == nodes - 1;
+            uint32_t depth = 0;
+            bool binary = false;
+            tree_shape(hb->adj_depth + base, L, stack, depth, binary);
+            P.max_depth = std::max(P.max_depth, depth);
+            tree_depth[t] = (uint16_t)depth;
             if (!binary) P.all_binary = false;
             tree_mode[t] = (uint8_t)(L == n ? (binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL) : (binary ? MODE_BINARY_PARTIAL : MODE_PARTIAL));
             clamp_choice(hb->adj_depth + base, L, depth_class_of(tree_depth[t]), clamp_budget, eff_soft[t], eff_hard[t]);
@@ -1034,124 +1203,25 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     d.n_trees = nt;
     d.total_leaves = nt ? hb->leaf_off[nt] : 0;
     d.max_depth = max_depth; d.all_full = all_full && nt > 0; d.all_binary = all_binary && nt > 0;
-    // Classes = (kernel mode, depth bits) per TREE. The bit-sliced kernel's work per (quartet, 32 trees) grows with the bits B
-    // of the deepest LCA of the trees it is given (2(B+1)+2 instructions for full binary trees, B >= 4) and with what the
-    // trees may contain: binary trees with missing taxa 2(B+1)+5, multifurcating trees 3(B+1)+3, both 3(B+1)+7 (the same
-    // two-column tile). One deep, one multifurcating or one incomplete tree must not put the whole batch on the dearest
-    // instance (the reference's loop is shape-independent, QuartetCounterLookup.hpp:65-106), so trees are counted class by
-    // class: B = 4 .. 10 (LCA depths below 1024: ladder-like trees of up to ~2000 taxa) and "deeper" (byte-SWAR kernel,
-    // 16-bit depths) within each of the four modes. Every class costs at least one more panel slice = one more pass over
-    // the table, so a class that holds fewer than max(1024, QS_TUNE_CLASS_PCT %) of the trees joins one that is exact for
-    // it: first a whole mode joins a more general mode that is present (binary_full -> binary_partial, general_full or
-    // partial; binary_partial, general_full -> partial), then a depth class joins the next deeper one of its mode.
-    // (centred random trees: 93 % of 256-taxon trees and 24 % of 512-taxon trees fit B = 4.)
+    // classes = (kernel mode, depth bits) per tree: plan_classes above
     std::vector<uint32_t> order_host;
     std::vector<FixUnit> fix_units;
+    ClassPlan plan;
     {
-        constexpr uint32_t top_bits = 10, deep = 11;   // depth class id = depth bits; `deep` = beyond the bit-sliced instances
-        constexpr uint32_t kModes = 4, kBits = 12;
-        // Depth clamp: a tree may sit in a class BELOW its own depth bits -- the panel builders cut its depths at the class's
-        // largest value and clamp_fix_kernel adds the quartets the cut ties (qs_count.hip) -- when that costs less than the
-        // instructions it saves (eff_soft: 2 of 2(B+1)+2 per bit and quartet against a few thousand atomics per tree).
-        uint32_t cnt[kModes][kBits] = {{0}}, mx[kModes][kBits] = {{0}};
-        std::vector<uint8_t> cls(nt);
-        for (uint32_t t = 0; t < nt; ++t) {
-            cls[t] = eff_soft[t];
-            cnt[tree_mode[t]][cls[t]]++;
-        }
-        const uint32_t small = std::max<uint32_t>(c->tune_class_min, (uint32_t)((uint64_t)nt * c->tune_class_pct / 100));
-        uint32_t mode_map[kModes] = {0, 1, 2, 3};
-        auto total = [&](uint32_t mo) { uint32_t s_ = 0; for (uint32_t bb = 0; bb < kBits; ++bb) s_ += cnt[mo][bb]; return s_; };
-        auto join_mode = [&](uint32_t from, std::initializer_list<uint32_t> into) {
-            const uint32_t tf = total(from);
-            if (tf == 0 || tf >= small) return;
-            for (uint32_t to : into) {
-                if (total(to) == 0) continue;
-                for (uint32_t bb = 0; bb < kBits; ++bb) { cnt[to][bb] += cnt[from][bb]; mx[to][bb] = std::max(mx[to][bb], mx[from][bb]); cnt[from][bb] = 0; }
-                mode_map[from] = to;
-                return;
-            }
-        };
-        join_mode(MODE_BINARY_FULL, {MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL});
-        join_mode(MODE_BINARY_PARTIAL, {MODE_PARTIAL});
-        join_mode(MODE_GENERAL_FULL, {MODE_PARTIAL});
-        auto final_mode = [&](uint32_t mo) { while (mode_map[mo] != mo) mo = mode_map[mo]; return mo; };
-        // a class too small for a pass of its own: its trees go DOWN to a class that is large enough where the 16-fold budget allows
-        // it (what is left joins the next deeper class below, as before)
-        if (c->tune_clamp_ppm)
-            for (uint32_t t = 0; t < nt; ++t) {
-                const uint32_t mo = final_mode(tree_mode[t]), bb = cls[t];
-                if (cnt[mo][bb] >= small || eff_hard[t] >= bb) continue;
-                for (uint32_t lo = bb - 1; lo >= eff_hard[t] && lo >= 4; --lo)
-                    if (cnt[mo][lo] >= small) { cnt[mo][bb]--; cnt[mo][lo]++; cls[t] = (uint8_t)lo; break; }
-            }
-        // ... and a class that is still small after that costs a launch of its own = one more pass over the table (10-20 ms at
-        // 34 GB) plus the waves' fixed cost for a handful of trees: its trees go down at ANY finite price, as long as the sum stays
-        // below what the pass would cost (5 % of C(n,4) corrections ~ 1.4e8 at 512 taxa)
-        if (c->tune_clamp_ppm)
-            for (uint32_t mo = 0; mo < kModes; ++mo)
-                for (uint32_t bb = top_bits; bb > 4; --bb) {
-                    if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
-                    // the class below to join: the nearest one that is large enough for a pass of its own, or -- in a batch whose
-                    // classes are ALL small -- the nearest non-empty one that is at least as large as this one (joining the larger
-                    // neighbour downwards beats the rule below, which would send the larger class up to this one's depth bits)
-                    uint32_t lo = bb - 1;
-                    while (lo > 4 && cnt[mo][lo] < small) --lo;
-                    if (cnt[mo][lo] < small) {
-                        lo = bb - 1;
-                        while (lo > 4 && cnt[mo][lo] == 0) --lo;
-                        if (cnt[mo][lo] == 0 || cnt[mo][lo] < cnt[mo][bb]) continue;   // nothing below that is worth joining
-                    }
-                    uint64_t total = 0;
-                    bool finite = true;
-                    std::vector<uint32_t> members;
-                    for (uint32_t t = 0; t < nt && finite; ++t) {
-                        if (final_mode(tree_mode[t]) != mo || cls[t] != bb) continue;
-                        const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
-                        const uint64_t cost = clamp_cost(hb->adj_depth + base, L, (1u << lo) - 1u, nullptr);
-                        if (cost == ~0ull) finite = false; else { total += cost; members.push_back(t); }
-                    }
-                    if (!finite || total > binom4(n) / 20) continue;
-                    for (uint32_t t : members) cls[t] = (uint8_t)lo;
-                    cnt[mo][lo] += cnt[mo][bb]; cnt[mo][bb] = 0;
-                }
-        for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(tree_mode[t]); mx[mo][cls[t]] = std::max<uint32_t>(mx[mo][cls[t]], tree_depth[t]); }
-        uint32_t remap[kModes][kBits];
-        for (uint32_t mo = 0; mo < kModes; ++mo) {
-            for (uint32_t bb = 0; bb < kBits; ++bb) remap[mo][bb] = bb;
-            for (uint32_t bb = 4; bb < top_bits; ++bb) {
-                if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
-                uint32_t up = bb + 1;
-                while (up <= top_bits && cnt[mo][up] == 0) ++up;
-                if (up > top_bits) continue;               // nothing above it among the bit-sliced classes of this mode
-                cnt[mo][up] += cnt[mo][bb]; mx[mo][up] = std::max(mx[mo][up], mx[mo][bb]); cnt[mo][bb] = 0; remap[mo][bb] = up;
-            }
-        }
-        auto final_cls = [&](uint32_t mo, uint32_t k) { while (remap[mo][k] != k) k = remap[mo][k]; return k; };
-        d.n_classes = 0;
-        uint32_t run = 0, start[kModes][kBits] = {{0}};
-        // launch order: the dearest instances first? No: by mode, then depth -- binary_full first (its first slice stores
-        // instead of accumulating when the caller asks for QS_COUNT_OVERWRITE; any class may be the first)
-        static const uint32_t mode_seq[kModes] = {MODE_BINARY_FULL, MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL};
-        for (uint32_t mi = 0; mi < kModes; ++mi) {
-            const uint32_t mo = mode_seq[mi];
-            for (uint32_t k = 4; k <= deep; ++k) {
-                if (cnt[mo][k] == 0) continue;
-                start[mo][k] = run; run += cnt[mo][k];
-                d.class_mode[d.n_classes] = mo; d.class_bits[d.n_classes] = k; d.class_end[d.n_classes] = run; d.class_max_depth[d.n_classes] = mx[mo][k];
-                d.n_classes++;
-            }
-        }
-        if (d.n_classes > 1) {
-            order_host.resize(nt);
-            for (uint32_t t = 0; t < nt; ++t) { const uint32_t mo = final_mode(tree_mode[t]); order_host[start[mo][final_cls(mo, cls[t])]++] = t; }
-        }
+        TreeFacts F;
+        F.depth.swap(tree_depth); F.mode.swap(tree_mode); F.soft.swap(eff_soft); F.hard.swap(eff_hard);
+        plan_classes(n, nt, hb->leaf_off, hb->adj_depth, F, c->tune_class_min, c->tune_class_pct, c->tune_clamp_ppm, plan);
+        tree_depth.swap(F.depth); tree_mode.swap(F.mode);
+        d.n_classes = plan.n_classes;
+        for (uint32_t k = 0; k < plan.n_classes; ++k) { d.class_mode[k] = plan.class_mode[k]; d.class_bits[k] = plan.class_bits[k]; d.class_end[k] = plan.class_end[k]; d.class_max_depth[k] = plan.class_max_depth[k]; }
+        order_host = plan.order;
+        constexpr uint32_t top_bits = 10;
         // correction units of the trees whose class holds fewer depth bits than they need, by slot (a slice of a class = a range of
         // slots = a range of units). One unit = one workgroup = a stretch of a run's triples worth ~32 K fourth leaves.
         if (c->tune_clamp_ppm) {
             std::vector<std::pair<uint32_t, uint32_t>> runs;
             auto emit = [&](uint32_t slot, uint32_t t) {
-                const uint32_t mo = final_mode(tree_mode[t]), fb = final_cls(mo, cls[t]);
+                const uint32_t fb = plan.bits[t];
                 if (fb > top_bits || depth_class_of(tree_depth[t]) <= fb) return;
                 const uint32_t base = hb->leaf_off[t], L = hb->leaf_off[t + 1] - base;
                 runs.clear();

@@ -472,3 +472,67 @@ def test_depth_clamp_plan_is_host_only_and_matches_the_emulation():
         assert sum(comb(s, 3) * (hi - lo - s) + comb(s, 4) for _, s in runs) == corr2[t]
     own3, cls3, corr3 = plan(20)
     assert cls3[-1] == own3[-1] and (cls3 <= own3).all() and (corr3 <= 20e-6 * comb(n, 4) * (own3 - cls3)).all()
+
+
+def test_class_plan_rules_are_host_only():
+    """qs_class_plan = the classes qs_batch_upload forms, without a GPU: (1) in a batch whose classes are all below the 1024-tree floor a
+    few deep trees go DOWN to the larger 4-bit class (395 tied quartets each) instead of dragging it up to 5 bits -- which is what
+    happens with the clamp off; (2) the same next to a class that is large enough; (3) ladders, whose cut subtree is most of the tree,
+    keep their own class; (4) a handful of full binary trees join the mode of 1100 incomplete ones; the slots are a permutation that
+    lists the classes one after the other."""
+    import ctypes as C
+    from quartetscores_amd import _lib
+    L = _lib.load()
+    n = 44
+    ref = flatten.flatten_reference(synth.reference_tree(n, 4500))
+    rng = np.random.default_rng(45)
+
+    def deep_tree():
+        order = [int(x) for x in rng.permutation(n)]
+        sub = f"((t{order[0]},t{order[1]}),t{order[2]})"
+        for x in order[3:19]:
+            sub = f"({sub},t{x})"
+        rest = synth._to_newick(synth._join_random([f"t{x}" for x in order[19:]], rng, stop_at=2))
+        return f"({sub},{rest[1:-1]});"
+
+    def ladder():
+        cat = "(t0,t1)"
+        for i in range(2, n):
+            cat = "(" + cat + f",t{i})"
+        return cat + ";"
+
+    def plan(batch, class_min=1024, pct=10, ppm=20):
+        m = batch.n_trees
+        hb = _lib.TreeBatchC(m, batch.leaf_off.ctypes.data, batch.leaf_ids.ctypes.data, batch.adj_depth.ctypes.data, None, None, None)
+        mode, bits, slot = np.zeros(m, np.uint8), np.zeros(m, np.uint8), np.zeros(m, np.uint32)
+        assert L.qs_class_plan(n, C.byref(hb), class_min, pct, ppm, mode.ctypes.data, bits.ctypes.data, slot.ctypes.data) == 0
+        assert sorted(slot) == list(range(m))
+        key = [(int(mode[t]), int(bits[t])) for t in np.argsort(slot)]
+        assert all(key[i] == key[i + 1] or key[i] not in key[i + 1:] for i in range(m - 1))   # classes are contiguous in slot order
+        return mode, bits
+
+    def cat(*parts):
+        from test_host_cpu_helpers import concat_batches
+        out = parts[0]
+        for p_ in parts[1:]:
+            out = concat_batches(out, p_)
+        return out
+
+    shallow = lambda m, seed, **kw: flatten.flatten_eval_trees(synth.tree_set(n, m, seed, **kw), ref.name_to_id)
+    deep = flatten.flatten_eval_trees([deep_tree() for _ in range(3)], ref.name_to_id, recentre=False)
+    lad = flatten.flatten_eval_trees([ladder()] * 2, ref.name_to_id, recentre=False)
+    assert int(deep.adj_depth.max()) >= 16 and int(lad.adj_depth.max()) >= 32
+    # (1) all classes small: the three deep trees go down; with the clamp off the 50 go up
+    mode, bits = plan(cat(shallow(50, 4501), deep))
+    assert (bits == 4).all() and (mode == 0).all()
+    mode, bits = plan(cat(shallow(50, 4501), deep), ppm=0)
+    assert (bits == 5).all()
+    # (2) beside a class that is large enough
+    mode, bits = plan(cat(shallow(1100, 4502), deep))
+    assert (bits == 4).all()
+    # (3) ladders keep their class
+    mode, bits = plan(cat(shallow(1100, 4502), lad))
+    assert (bits[:1100] == 4).all() and (bits[1100:] == 6).all()
+    # (4) 30 full binary trees join the mode of 1100 binary trees with missing taxa
+    mode, bits = plan(cat(shallow(30, 4503), shallow(1100, 4504, dropout=0.2)))
+    assert (mode == 3).all() and (bits == 4).all()
