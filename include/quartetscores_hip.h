@@ -203,7 +203,7 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
 #define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel, shape of the table loads: 0 (default) = every lane loads its own row in 16-byte pieces;
                                        * 2 = ... and requests the next chunk before it processes the current one; 1 = eight lanes load the
                                        * 96-byte chunk of a row together and hand it over through LDS; 3 = 1 with the next chunk requested
-                                       * ahead. All exact; 1-3 measured slower on MI355X (profiles/r03_experiments.md 12): A/B switches */
+                                       * ahead (1, 3: workgroups of 8 waves). All exact; 1-3 measured slower on MI355X (profiles/r05_experiments.md 6): A/B switches */
 #define QS_TUNE_SCORE_DEDUPE 13u      /* single-read scoring: 1 (default) = a quartet that repeats the triple logged last for its node pair is
                                        * not logged again (tables of similar trees put thousands of equal triples at a pair's bound); 0 = off */
 #define QS_TUNE_COOP 9u               /* binary full batches: 1 = run the tiles with two a-blocks through count_bitslice4_kernel, whose

@@ -404,7 +404,11 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
         case QS_TUNE_CLASS_MIN_TREES: c->tune_class_min = (uint32_t)std::min<uint64_t>(value, 0xFFFFFFFFull); return QS_OK;
         case QS_TUNE_DEPTH_CLAMP: c->tune_clamp_ppm = (uint32_t)std::min<uint64_t>(value, 1000000ull); return QS_OK;
         case QS_TUNE_CLASS_PCT: if (value > 100) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_CLASS_PCT takes 0 .. 100"); c->tune_class_pct = (uint32_t)value; return QS_OK;
-        case QS_TUNE_SCORE_LOAD: if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3"); c->tune_score_load = (uint32_t)value; return QS_OK;
+        case QS_TUNE_SCORE_LOAD:
+            if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3");
+            c->tune_score_load = (uint32_t)value;
+            c->bundle_r0[0] = c->bundle_r0[1] = c->bundle_r1[0] = c->bundle_r1[1] = ~0ull;   // the rounds are planned per wave count, which the load mode sets
+            return QS_OK;
         case QS_TUNE_SCORE_DEDUPE: c->tune_score_dedupe = value ? 1u : 0u; return QS_OK;
         case QS_TUNE_SCORE_LOG_CAP:
             if (value > (1ull << 26)) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOG_CAP takes at most 2^26 records");
@@ -1817,7 +1821,7 @@ static int ensure_bundle_plan(qs_ctx *c, ScoreDevice &sd, int pass) {
     const uint64_t r0 = sd.rank_lo, r1 = sd.rank_lo + sd.n_tuples;
     if (c->bundle_r0[w] != r0 || c->bundle_r1[w] != r1 || !c->bundle_dev[w]) {
         if (c->bundle_dev[w]) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->bundle_dev[w]); c->bundle_dev[w] = nullptr; }
-        plan_bundles(c->n, r0, r1, score_bundle_waves(pass), plan);
+        plan_bundles(c->n, r0, r1, score_bundle_waves(pass, c->tune_score_load == 1 || c->tune_score_load == 3), plan);
         const size_t words = 2 * (size_t)c->n + plan.rounds.size();
         if (hipMalloc(&c->bundle_dev[w], std::max<size_t>(words, 1) * 4) != hipSuccess) return fail(c, QS_ERR_OOM, "qs_score: round table of the bundle kernel");
         hipStream_t up = c->prep_stream ? c->prep_stream : c->stream;

@@ -154,7 +154,7 @@ uint32_t score_scan_max_lds_log(bool coop_load = false);
 // rank range, and the partial rows at its ends, which go through the scan kernel), 1 = scan kernel (lane = 8 consecutive ranks)
 struct BundlePlan { std::vector<uint32_t> plo, pcnt, rounds; uint64_t part_lo[2], part_n[2]; int n_parts; };
 void plan_bundles(uint32_t n, uint64_t r0, uint64_t r1, uint32_t waves, BundlePlan &out);
-uint32_t score_bundle_waves(int pass);   // waves per workgroup (= consecutive b per round) of the bundle kernel in pass 1 / 2
+uint32_t score_bundle_waves(int pass, bool coop_load = false);   // waves per workgroup (= consecutive b per round) of the bundle kernel in pass 1 / 2; cooperative loads: their own count
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts, double tol = 0.0);
 hipError_t launch_score_log(hipStream_t s, const ScoreDevice &sd, double tol, unsigned long long n_rec); // single-read scoring: filter pass 1's candidate log (sd.list)
 hipError_t launch_score_pass2(hipStream_t s, const ScoreDevice &sd, double tol, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts);

@@ -461,11 +461,20 @@ constexpr int kBundleWaves1 = QS_BUNDLE_W1, kBundleWaves2 = QS_BUNDLE_W2;
 // loads make one L2 request per load, this makes one per 64-byte segment. The hash shrinks to 512 slots to make room.
 constexpr int kBundleHashCoop = 512;
 constexpr int kStageRow = 96;                          // bytes per row and chunk in the staging area
+// ... which lie kStagePitch bytes apart: 28 dwords, so that the eight lanes a 16-byte LDS read serves per clock start in eight different
+// groups of four banks (a pitch of 96 bytes = 24 dwords puts lanes l and l + 4 on the same banks)
+constexpr int kStagePitch = 112;
+#ifndef QS_BUNDLE_WC
+#define QS_BUNDLE_WC 8    /* waves per workgroup with cooperative loads, both passes: 8 x 64 x 112 bytes of staging leave the k log k table 10 900 entries
+                           * (12 waves: 8 100 -- at 10 000 trees every tuple then took the range-checked slow path, which is what round 3 measured) */
+#endif
+constexpr int kBundleWavesCoop = QS_BUNDLE_WC;
 template <int PASS, int WAVES, bool COOP> constexpr size_t bundle_lds_fixed() {   // COOP = load mode 1
-    return (PASS == 1 ? (COOP ? sizeof(HashLds<kBundleHashCoop>) : sizeof(ScanLds)) : 0) + (COOP ? (size_t)WAVES * kWave * kStageRow : 0);
+    return (PASS == 1 ? (COOP ? sizeof(HashLds<kBundleHashCoop>) : sizeof(ScanLds)) : 0) + (COOP ? (size_t)WAVES * kWave * kStagePitch : 0);
 }
 typedef uint32_t qs_u32x3 __attribute__((ext_vector_type(3)));
 typedef qs_u32x3 qs_u32x3_a2 __attribute__((aligned(2)));
+typedef const qs_u32x3_a2 __attribute__((address_space(1))) *qs_u32x3_gptr;   // (global_load, not flat_load, from an address kept as an integer)
 // LM = 2 (QS_TUNE_SCORE_LOAD = 2): the per-lane loads of the NEXT chunk are issued before the current chunk is processed (two
 // chunks of every row in flight; tools/row_bw.hip: the bare access pattern reads 4.75 TB/s with one chunk in flight, 5.67 with two).
 template <typename CT, int PASS, int WAVES, int LM>
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             const CT *row = table + (rank4(0, b, c, d) - sd.rank_lo) * 3;
             // COOP: in load instruction i this lane fetches piece (lane & 7) of the chunk of row 8 i + lane / 8
             unsigned long long rb[COOP ? 8 : 1];
-            unsigned char *stg = stage_all + (size_t)wave * (kWave * kStageRow);
+            unsigned char *stg = stage_all + (size_t)wave * (kWave * kStagePitch);
             if (COOP) {
                 const unsigned long long rp = (unsigned long long)(uintptr_t)row;
 #pragma unroll
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
             const uint32_t e12 = L[(size_t)c * n + b], e23 = L[(size_t)d * n + c];
             const uint32_t *__restrict__ lrow = L + (size_t)b * n;
             const uint16_t *__restrict__ nrow = sd.ref_next + (size_t)b * n;
-            constexpr int CH = sizeof(CT) == 2 ? QS_BUNDLE_CH16 : QS_BUNDLE_CH;   // tuples a lane requests at once: 96 bytes of its row, back to back, so that
+            constexpr int CH = COOP ? (sizeof(CT) == 2 ? 16 : 8) : (sizeof(CT) == 2 ? QS_BUNDLE_CH16 : QS_BUNDLE_CH);   // tuples a lane requests at once: 96 bytes of its row, back to back, so that
             uint32_t q[CH][3];                      // the requests for one cache line meet in the L1 while it is still pending
             uint32_t key = kKeyEmpty, code = 3;
             bool first_is_n0 = true, swp = false;
@@ -574,19 +583,19 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                             for (int i = 0; i < 8; ++i) part[i] = nxp[i];
                         } else {
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) part[i] = *reinterpret_cast<const qs_u32x3_a2 *>((uintptr_t)(rb[i] + boff));
+                            for (int i = 0; i < 8; ++i) part[i] = *(qs_u32x3_gptr)(uintptr_t)(rb[i] + boff);
                         }
                         if (CPF) {
                             nx_valid = !(sampling && smask != 0xFFFFFFFFu) && a0 + 2 * CH <= b;
                             if (nx_valid) {
                                 const uint32_t boffn = boff + (uint32_t)(CH * 3 * sizeof(CT));
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) nxp[i] = *reinterpret_cast<const qs_u32x3_a2 *>((uintptr_t)(rb[i] + boffn));
+                                for (int i = 0; i < 8; ++i) nxp[i] = *(qs_u32x3_gptr)(uintptr_t)(rb[i] + boffn);
                             }
                         }
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            *reinterpret_cast<qs_u32x3 *>(stg + (8 * i + (lane >> 3)) * kStageRow + 12u * (lane & 7u)) = part[i];
+                            *reinterpret_cast<qs_u32x3 *>(stg + (8 * i + (lane >> 3)) * kStagePitch + 12u * (lane & 7u)) = part[i];
                         // the rows were written by other lanes of this wave: LDS operations of a wave complete in order, the
                         // fences only keep the compiler from moving the reads in front of the writes
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_bundle_kernel(ScoreDevice
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                         for (int j = 0; j < NV; ++j) {
-                            const qs_u32x4 v = *reinterpret_cast<const qs_u32x4 *>(stg + lane * kStageRow + 16 * j);
+                            const qs_u32x4 v = *reinterpret_cast<const qs_u32x4 *>(stg + lane * kStagePitch + 16 * j);
                             w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -847,16 +856,16 @@ template <typename CT, int PASS> static hipError_t launch_scan(hipStream_t s, co
 // bundle kernel over the planned rounds (sd.bundle_*), scan kernel over the partial rows at the ends of the range
 template <typename CT, int PASS> static hipError_t launch_bundle(hipStream_t s, const ScoreDevice &sd, double tol, int n_cu,
                                                                  const uint64_t *part_lo, const uint64_t *part_n, int n_parts) {
-    constexpr int WAVES = PASS == 1 ? kBundleWaves1 : kBundleWaves2;
+    constexpr int WAVES = PASS == 1 ? kBundleWaves1 : kBundleWaves2, WC = kBundleWavesCoop;
     if (sd.n_rounds > 0) {
         const bool coop = sd.coop_load == 1 || sd.coop_load == 3;
-        const size_t lds = (coop ? bundle_lds_fixed<PASS, WAVES, true>() : bundle_lds_fixed<PASS, WAVES, false>()) + (size_t)sd.lds_n * 8;
+        const size_t lds = (coop ? bundle_lds_fixed<PASS, WC, true>() : bundle_lds_fixed<PASS, WAVES, false>()) + (size_t)sd.lds_n * 8;
         if (lds > 160u * 1024u) return hipErrorInvalidValue;   // (lds_n is capped by score_scan_max_lds_log(coop))
-        auto k = sd.coop_load == 1 ? score_bundle_kernel<CT, PASS, WAVES, 1> : sd.coop_load == 3 ? score_bundle_kernel<CT, PASS, WAVES, 3>
+        auto k = sd.coop_load == 1 ? score_bundle_kernel<CT, PASS, WC, 1> : sd.coop_load == 3 ? score_bundle_kernel<CT, PASS, WC, 3>
                  : (sd.coop_load == 2 ? score_bundle_kernel<CT, PASS, WAVES, 2> : score_bundle_kernel<CT, PASS, WAVES, 0>);
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        dim3 block(WAVES * kWave), grid(std::min<uint32_t>(sd.n_rounds, (uint32_t)std::max(1, n_cu)));
+        dim3 block((coop ? WC : WAVES) * kWave), grid(std::min<uint32_t>(sd.n_rounds, (uint32_t)std::max(1, n_cu)));
         hipLaunchKernelGGL(k, grid, block, lds, s, sd, tol);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -870,7 +879,7 @@ template <typename CT, int PASS> static hipError_t launch_bundle(hipStream_t s, 
     }
     return hipSuccess;
 }
-uint32_t score_bundle_waves(int pass) { return pass == 1 ? kBundleWaves1 : kBundleWaves2; }
+uint32_t score_bundle_waves(int pass, bool coop_load) { return coop_load ? kBundleWavesCoop : (pass == 1 ? kBundleWaves1 : kBundleWaves2); }
 
 // tol: only read when sd.list is set (pass 1 with the candidate log of the single-read scoring; bundle kernel, whole rows only)
 hipError_t launch_score_pass1(hipStream_t s, const ScoreDevice &sd, int kernel, int n_cu, const uint64_t *part_lo, const uint64_t *part_n, int n_parts, double tol) {
@@ -1009,8 +1018,7 @@ hipError_t launch_root_pair_sums(hipStream_t s, const ScoreDevice &sd, const voi
 
 // entries of the k log k table the kernels keep in LDS; with cooperative loads the staging areas take 48-60 KB of it
 uint32_t score_scan_max_lds_log(bool coop_load) {
-    constexpr size_t fixed = bundle_lds_fixed<1, kBundleWaves1, true>() > bundle_lds_fixed<2, kBundleWaves2, true>() ? bundle_lds_fixed<1, kBundleWaves1, true>()
-                                                                                                                    : bundle_lds_fixed<2, kBundleWaves2, true>();
+    constexpr size_t fixed = bundle_lds_fixed<1, kBundleWavesCoop, true>();   // (pass 2 has no hash: less)
     return coop_load ? (uint32_t)((160u * 1024u - fixed - 256u) / 8u) : kScanMaxLdsLog;
 }
 
