@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="0 = automatic: about 6 s of timed steps, between 5 and 500")
     ap.add_argument("--warmup", type=int, default=-1, help="-1 = automatic: 2 for steps >= 100 ms, else 20")
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[k]; 0 = 2 at N=1, 3 at N>1")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[k]; 0 = 2 (the config the metric is quoted on) at every N")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed pre-conditioning before the warm-up steps (GPU clock ramp); 0 = off")
     ap.add_argument("--taxa", type=int, default=0)
     ap.add_argument("--trees", type=int, default=0, help="trees in total (split over the ranks when the config splits), else per rank")
@@ -93,6 +93,12 @@ def parse_args():
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32x2", "u32"], default="auto",
                     help="N>1: format of the table on the wire (auto: fewer than 65536 trees in total: u16x2 for binary full trees, else u16; "
                          "from 65536 trees on: u32x2 = two u32 cells per tuple for binary full trees with reduce-scatter, else u32)")
+    ap.add_argument("--mode", choices=["auto", "tree", "table"], default="auto",
+                    help="N > 1: tree = every rank counts trees/N into a full table + ONE RCCL collective on the table; table = every rank counts ALL "
+                         "trees into its shard of the table (by largest taxon id), no table collective; auto = by the model (auto_mode)")
+    ap.add_argument("--balance", choices=["auto", "c4", "cost"], default="auto",
+                    help="table mode: shard bounds balanced by the tuples held (c4) or by the count kernel's work (cost: qs_shard_bounds); auto = cost, c4 for configs[4]")
+    ap.add_argument("--other-leg", type=int, default=-1, help="N > 1: also time a few steps of the OTHER mode (tree <-> table) in the same run; -1 = on for binary full workloads")
     ap.add_argument("--table-shards", type=int, default=0, help="table-sharded mode: split the table by the largest taxon id into this many shards")
     ap.add_argument("--shard-index", type=int, default=-1, help="table-sharded mode on fewer ranks than shards: which shard this rank owns (default: its rank)")
     ap.add_argument("--slice-bytes", type=int, default=0, help="qs_set_tuning(QS_TUNE_PANEL_SLICE_BYTES); 0 = automatic")
@@ -129,7 +135,7 @@ def child_command(n_gpus, argv, port=None):
 
 def visible_gpus():
     """GPUs this process could use, counted WITHOUT torch and without any HIP / HSA call: the KFD topology in sysfs (a node
-    with simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (index lists;
+    with simd_count > 0 whose render node /dev/dri/renderD<drm_render_minor> this process may open is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (index lists;
     UUID entries count as one device each)."""
     import glob
     n = 0
@@ -138,7 +144,14 @@ def visible_gpus():
         try:
             with open(path) as f:
                 props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
-            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            # a container / cgroup may expose only some of the host's GPUs: the topology lists them all, the render nodes say
+            # which ones this process can open (drm_render_minor of the node's properties)
+            minor = int(props.get("drm_render_minor", "0"))
+            if minor > 0 and os.path.isdir("/dev/dri") and not os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK):
+                continue
+            n += 1
         except (OSError, ValueError):
             continue
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -241,25 +254,29 @@ def cpu_child(spec_path):
     """Times the oracle on a bounded sample; prints one JSON object. The process is pinned to the CPUs of NUMA node 0 and the
     OpenMP threads are bound to them (OMP_PLACES / OMP_PROC_BIND) BEFORE the oracle's library (libgomp) is loaded: the table is
     first-touched by those threads, so table and threads share one node."""
-    pinned = numa_node0_cpus()
+    with open(spec_path) as f:
+        spec = json.load(f)
+    # placement "all" (second, short child): no affinity, threads spread over every CPU of the host -- on a multi-socket box, or
+    # where spreading suits the n^4 table better, the one-node placement would understate the CPU
+    spread = spec.get("placement") == "all"
+    pinned = None if spread else numa_node0_cpus()
     if pinned:
         try:
             os.sched_setaffinity(0, pinned)
         except OSError:
             pinned = None
-    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PROC_BIND", "spread" if spread else "close")
     os.environ.setdefault("OMP_PLACES", "threads")
     from oracle_api import Oracle
-    with open(spec_path) as f:
-        spec = json.load(f)
     with open(spec["trees_path"]) as f:
         text = f.read()
     n, m, nq, budget = spec["n"], spec["m"], spec["nq"], spec["budget_s"]
     info = host_info()
     ncpu = len(pinned) if pinned else info["host_cpus"]
     info["pinned"] = (f"NUMA node 0: {len(pinned)} CPUs ({pinned[0]}..{pinned[-1]}), OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES={os.environ['OMP_PLACES']}"
-                      if pinned else "not pinned (no sysfs NUMA topology)")
-    info["threads_note"] = "threads and table on one NUMA node; thread counts beyond the node's CPUs are not run"
+                      if pinned else f"not pinned, all {ncpu} CPUs, OMP_PROC_BIND={os.environ['OMP_PROC_BIND']}" if spread else "not pinned (no sysfs NUMA topology)")
+    info["threads_note"] = ("threads spread over all CPUs of the host" if spread else
+                            "threads and table on one NUMA node; thread counts beyond the node's CPUs are not run")
     cint_bits = 8 if m < 256 else 16 if m < 65536 else 32               # QuartetScores.cpp:115-147
     fast_bytes = n ** 4 * cint_bits // 8
     # QuartetScoreComputer.hpp:739: the n^4 table unless it exceeds 0.9 x RAM (here: half of what is available, so
@@ -279,19 +296,38 @@ def cpu_child(spec_path):
         out["runs"].append(r)
         return r
 
-    r1 = run(1, budget)                                                 # -t 1 for the full budget (>= 30 s by default)
-    best = r1
-    if not savemem:                                                     # savemem + threads is racy in the reference
-        scan = None
-        for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64, ncpu)} - {1}):   # short scan for the best thread count ...
-            r = run(th, max(2.0, budget / 10))
-            if scan is None or r["value"] > scan["value"]:
-                scan = r
-        if scan is not None:
-            r = run(scan["threads"], budget)                            # ... which then runs for the full budget
-            if r["value"] > best["value"]:
-                best = r
-    out["t1"] = {"value": r1["value"], "cores": 1}
+    if spread:
+        # the short scan only; the full budget is spent here only when the scan beats the pinned placement's best (spec["beat"])
+        best = None
+        if not savemem:
+            for th in sorted({min(t, ncpu) for t in (16, 64, ncpu)} - {1}):
+                r = run(th, max(2.0, budget / 10))
+                if best is None or r["value"] > best["value"]:
+                    best = r
+            if best is not None and best["value"] > float(spec.get("beat") or 0.0):
+                r = run(best["threads"], budget)
+                best = r if r["value"] > best["value"] else best
+        if best is None:
+            out.update({"value": None, "cores": 0, "sample": "not run (the compact table with threads is racy in the reference)"})
+            o.close()
+            print(json.dumps(out))
+            return
+        r1 = None
+    else:
+        r1 = run(1, budget)                                             # -t 1 for the full budget (>= 30 s by default)
+        best = r1
+        if not savemem:                                                 # savemem + threads is racy in the reference
+            scan = None
+            for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64, ncpu)} - {1}):   # short scan for the best thread count ...
+                r = run(th, max(2.0, budget / 10))
+                if scan is None or r["value"] > scan["value"]:
+                    scan = r
+            if scan is not None:
+                r = run(scan["threads"], budget)                        # ... which then runs for the full budget
+                if r["value"] > best["value"]:
+                    best = r
+    if r1 is not None:
+        out["t1"] = {"value": r1["value"], "cores": 1}
     out["value"], out["cores"] = best["value"], best["threads"]
     # counting is linear in the number of trees: the rate measured on a prefix stands for the whole batch
     out["extrapolated_from_trees"] = round(best["trees_equiv"], 3)
@@ -311,17 +347,35 @@ def run_cpu_baseline(ref_nw, eval_text, n, m, nq, budget_s):
     keep = lines[: max(8, min(len(lines), 4096))]
     with open(tp, "wb") as f:
         f.write(b"\n".join(keep))
-    with open(sp, "w") as f:
-        json.dump({"trees_path": tp, "ref": ref_nw, "n": n, "m": m, "nq": nq, "budget_s": budget_s}, f)
+    spec = {"trees_path": tp, "ref": ref_nw, "n": n, "m": m, "nq": nq, "budget_s": budget_s}
     env = dict(os.environ)
     env.pop("HIP_VISIBLE_DEVICES", None)
-    try:
+
+    def child(extra):
+        with open(sp, "w") as f:
+            json.dump(dict(spec, **extra), f)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", sp], capture_output=True, text=True,
                            timeout=120 + 4 * budget_s, env=env)
         last = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not last:
             return {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed (rc {p.returncode}): {p.stderr[-300:]}"}
         return json.loads(last[-1])
+    try:
+        res = child({})                      # threads and table on NUMA node 0
+        if res.get("value") and res.get("numa_nodes", 1) >= 1 and os.environ.get("QS_BENCH_CPU_SPREAD", "1") != "0":
+            # one unpinned placement beside it (all CPUs, OMP_PROC_BIND=spread): a short scan, the full budget only if it wins
+            try:
+                alt = child({"placement": "all", "beat": res["value"]})
+            except Exception as e:
+                alt = {"value": None, "sample": f"failed: {e}"}
+            res["unpinned"] = {k_: alt.get(k_) for k_ in ("value", "cores", "sample", "pinned", "runs")}
+            if alt.get("value") and alt["value"] > res["value"]:
+                for k_ in ("value", "cores", "sample", "extrapolated_from_trees"):
+                    res[k_] = alt.get(k_)
+                res["placement_won"] = "unpinned, spread over all CPUs"
+            else:
+                res["placement_won"] = "pinned to NUMA node 0"
+        return res
     except Exception as e:  # the baseline is reported, never required for the metric
         return {"value": None, "unit": "quartets/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     finally:
@@ -359,7 +413,7 @@ def same_workload_scaling(value, world, units_per_rank_per_step, count_only_ms, 
     return {"count_only_ms_per_step": round(count_only_ms, 3), "units_per_rank_per_step": units_per_rank_per_step,
             "rate_quartets_per_s": rate, "scaling_efficiency": value / (world * rate),
             "collective_exposed_ms": round(ms_per_step - count_only_ms, 3),
-            "note": "same ranks, same shares, same run, no table collective (max over ranks)"}
+            "note": "same ranks, shares, run and store path (wire words / pack pass); only the dist.* call is left out (max over ranks)"[:100]}
 
 
 def run_cli_e2e(ref_nw, eval_text, threads=8, extra=()):
@@ -458,6 +512,145 @@ def pmc_for(workload_key, variant):
     return None
 
 
+XGMI_LINK_GBS = 153.0            # MI355X_MICROARCH.md: per xGMI link and direction, 7 links per GPU
+
+
+def auto_mode(n, m_total, world, binary_full=True):
+    """tree- or table-sharded for N > 1, from what one GPU could settle (tools/scaling_model.py, profiles/r06_scaling_model.json):
+    the count work per rank is the same either way (trees x owned tuples); the tree-sharded mode adds ONE collective on the table,
+    the table-sharded mode adds the replicated panel build, the shards' imbalance and the tails of its smaller launches. Returns
+    (mode, the estimate). Constants: 1.6e-9 ms per (tree, taxon pair) of panel build (measured 1.3e-9 at 512 taxa, 1.8e-9 at
+    256), 9.4e13 quartets/s per GPU, ~8 % imbalance + tails, 1 ms per launch (one per slice of >= 350 MB of panel); the
+    collective is priced at the ring bound: reduce-scatter bytes per rank / 153 GB/s (one xGMI link at a time)."""
+    nq = n * (n - 1) * (n - 2) * (n - 3) // 24
+    npairs = n * (n - 1) // 2
+    bpt = (4 if binary_full else 6) if m_total < 65536 else (8 if binary_full else 12)
+    coll_ms = nq * bpt * (world - 1) / world / (XGMI_LINK_GBS * 1e9) * 1e3
+    count_ms = m_total * nq / 9.4e13 * 1e3 / world
+    panel_ms = 1.6e-9 * m_total * npairs
+    groups = -(-m_total // 32)
+    slice_groups = max(256, int(350e6 // (npairs * 16)))
+    table_extra_ms = panel_ms * (world - 1) / world + 0.08 * count_ms + 1.0 * -(-groups // slice_groups)
+    mode = "table" if table_extra_ms < coll_ms else "tree"
+    return mode, {"tree_collective_ms_ring_bound": round(coll_ms, 3), "table_extra_ms": round(table_extra_ms, 3), "count_ms_per_rank": round(count_ms, 3),
+                  "rule": "table if replicated panel + imbalance/tails < table collective at one xGMI link", "source": "profiles/r06_scaling_model.json"}
+
+
+def run_mode_leg(mode, world, rank, local_rank, n, count_bits, batch_all, m_total, steps, use_dist, balance):
+    """A few steps of one multi-GPU mode, self-contained (own context, table, buffers; everything is released before it returns): the
+    N > 1 line carries the OTHER mode as a leg, so that one N-GPU lease measures tree- and table-sharded counting of the same trees.
+    Binary trees holding all taxa only. Every rank calls it; the result is the same on every rank (max over ranks)."""
+    import torch
+    import torch.distributed as dist
+    from quartetscores_amd import distributed, engine, ranks
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream(dev)
+    nq_all = ranks.n_quartets(n)
+    algo = engine.QS_ALGO_GATHER | engine.QS_COUNT_OVERWRITE
+    pending = [None, None]
+    info = {"mode": mode}
+    if mode == "table":
+        d_lo, d_hi = distributed.shard_of_largest_id(n, world, rank, by=balance)
+        ctx = engine.Context(n, count_bits, device=local_rank, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
+        table = torch.zeros(max((ctx.table_bytes + 3) // 4, 1), dtype=torch.int32, device=dev)
+        ctx.table_attach(table)
+        hb = ctx.batch_upload(batch_all, with_nodes=False)
+        info.update({"table_shard_rank0": None, "balance": balance, "collective": None,
+                     "step": "panel build (all trees) + count kernel on the rank's table shard; no table collective"})
+        if rank == 0:
+            info["table_shard_rank0"] = [d_lo, d_hi]
+
+        def step(i):
+            ctx.count_batch(hb, algo)
+    else:
+        lo, hi = distributed.shard_range(m_total, world, rank)
+        ctx = engine.Context(n, count_bits, device=local_rank, stream=stream.cuda_stream)
+        wire_fmt = (("u16x2" if m_total < 65536 else "u32x2") if count_bits == 32 else 16)
+        _, chunk_words = distributed.scatter_layout(ctx.table_tuples, world, wire_fmt)
+        send_words = world * chunk_words
+        recv = [torch.zeros(chunk_words, dtype=torch.int32, device=dev) for _ in range(2)]
+        wire = [torch.zeros(send_words, dtype=torch.int32, device=dev) for _ in range(2)]
+        table = None
+        if wire_fmt == "u32x2":
+            table = torch.zeros((ctx.table_bytes + 3) // 4, dtype=torch.int32, device=dev)
+            ctx.table_attach(table)
+        hb = ctx.batch_upload(batch_all.slice(lo, hi), with_nodes=False)
+        info.update({"wire": str(wire_fmt), "collective": "scatter", "collective_input_bytes_per_rank": send_words * 4,
+                     "step": "panel build (trees/N) + count kernel on the full table + RCCL reduce-scatter, async, 2 buffers"})
+
+        def step(i):
+            k = i & 1
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+            if wire_fmt == "u16x2":
+                ctx.wire_attach(wire[k])
+                ctx.count_batch(hb, algo | engine.QS_COUNT_WIRE16X2)
+            elif wire_fmt == "u32x2":
+                ctx.count_batch(hb, algo)
+                ctx.table_pack32x2(wire[k])
+            else:                                   # u16 table: counted in place into the (padded) send buffer
+                ctx.table_attach(wire[k])
+                ctx.count_batch(hb, algo)
+            if use_dist and world > 1:
+                pending[k] = dist.reduce_scatter_tensor(recv[k], wire[k][:send_words], op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                recv[k].copy_(wire[k][:chunk_words])
+
+    def fence():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    step(0)
+    step(1)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # gate: every tuple this rank holds after the step sums to the number of trees (binary trees, all taxa)
+    if mode == "table":
+        k_ = min(ctx.table_tuples, 1 << 24)
+        cells = table[: 3 * k_] if count_bits == 32 else (table.view(torch.int16)[: 3 * k_].to(torch.int32) & 0xFFFF)
+        ok_local = bool((cells.view(k_, 3).sum(dim=1) == m_total).all().item()) if k_ else True
+    else:
+        _own_lo, own_n = distributed.scatter_owned(ctx.table_tuples, world, rank, wire_fmt)
+        k_ = min(own_n, 1 << 24)
+        red = recv[(steps - 1) & 1]
+        if wire_fmt == "u16x2":
+            w_ = red[:k_]
+            ok_local = bool((((w_ & 0xFFFF) + ((w_ >> 16) & 0xFFFF)) <= m_total).all().item())
+        elif wire_fmt == "u32x2":
+            ok_local = bool((red[: 2 * k_].view(-1, 2).to(torch.int64).sum(dim=1) <= m_total).all().item())
+        else:
+            cells = red.view(torch.int16)[: 3 * k_].to(torch.int32) & 0xFFFF
+            ok_local = bool((cells.view(k_, 3).sum(dim=1) == m_total).all().item()) if k_ else True
+    if use_dist:
+        ok = torch.tensor([int(ok_local)], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ok_local = bool(ok.item())
+    info.update({"steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": m_total * nq_all * steps / elapsed,
+                 "parity_tuple_sums_ok": ok_local, "algo": ctx.last_count_variant()[:100]})
+    ctx.batch_free(hb)
+    ctx.close()                      # (fence() above has drained the stream and the collectives)
+    del table
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    return info
+
+
 def main():
     args = parse_args()
     if args.cpu_child:
@@ -481,23 +674,50 @@ def main():
     from quartetscores_amd import _lib, distributed, engine, flatten, native_ingest, ranks, synth
 
     # ---- workload -----------------------------------------------------------------------------------------
-    cfg_no = args.config or (2 if world == 1 else 3)
+    cfg_no = args.config or 2        # the config the metric is quoted on, at every N (a driver curve is ONE workload)
     cfg = dict(CONFIGS[cfg_no])
     custom = bool(args.taxa or args.trees or args.count_bits or args.table_shards or args.split_trees >= 0 or args.shape != "random")
     n = args.taxa or cfg["taxa"]
     m_total = args.trees or cfg["trees"]
     count_bits = args.count_bits or cfg["bits"]
     shards = args.table_shards or cfg["shards"]
-    split = bool(args.split_trees) if args.split_trees >= 0 else cfg["split"]
+    binary_full_trees = not (args.collapse or args.dropout or args.mixed)
+    # ---- how N > 1 ranks share the work ----
+    #   table: rank r counts ALL trees into shard r of the table (largest taxon id in [d_lo, d_hi)): no table collective;
+    #   tree:  rank r counts trees/N into a full table, one RCCL collective on the table per step;
+    #   tree-weak (--split-trees 0): every rank counts --trees of its own + the collective (weak scaling; the pre-round-6 default of configs 1/2)
+    # explicit shards (configs[4], --table-shards K): the table-sharded path with K >= N shards, as before.
+    mode, mode_why, mode_est = "single", "one rank", None
+    multi = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
     if shards > 1:
         shards = max(shards, world)
+        split = False
+        mode, mode_why = "table", ("--table-shards" if args.table_shards else "configs[4]: the table is sharded by definition")
+    elif args.split_trees == 0 and multi:
+        split = False
+        mode, mode_why = "tree-weak", "--split-trees 0"
+    elif multi:
+        if args.mode == "auto" and args.split_trees < 0 and world > 1:
+            mode, mode_est = auto_mode(n, m_total, world, binary_full_trees)
+            mode_why = "auto (model)"
+        else:
+            mode = "tree" if (args.mode == "auto" or args.split_trees == 1) else args.mode
+            mode_why = "--mode " + args.mode if args.mode != "auto" else "one rank under the launcher: the tree-sharded path with nothing to exchange"
+        split = mode == "tree"
+        if mode == "table":
+            shards = world               # (one shard per rank; world == 1: the whole table)
+    else:
+        split = False
+    balance = args.balance if args.balance != "auto" else ("c4" if cfg_no == 4 and not args.table_shards else "cost")
     t_lo, t_hi = distributed.shard_range(m_total, world, rank) if split else (0, m_total)
     m = t_hi - t_lo                                                      # trees THIS rank counts per step
     # seeded inputs: seed = 1000 * config + tree-set id. Split configs: ONE set of m_total trees, rank
     # r takes trees [t_lo, t_hi); otherwise rank r counts its own set r (tree t of a set depends only on (seed, t)).
-    seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or shards > 1) else rank)
-    binary_full_trees = not (args.collapse or args.dropout or args.mixed)
+    seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or mode == "table") else rank)
+    want_other_leg = multi and mode in ("tree", "table") and not (args.table_shards or cfg["shards"] > 1) and binary_full_trees and args.algo == "gather" \
+        and (args.other_leg == 1 or args.other_leg < 0)
     t_gen = time.perf_counter()
+    batch_all = None
     if args.shape == "ladder":
         lad = "(t0,t1)"
         for i in range(2, n - 2):
@@ -510,7 +730,13 @@ def main():
     if binary_full_trees:
         all_text = native_ingest.synth_trees(n, m_total if split else m, seed_set, kind="nni" if args.nni else "random",
                                              ref_text=ref_nw if args.nni else None)
-        batch, _ = native_ingest.ingest_text(ref_nw, all_text, t_lo if split else 0, t_hi if split else m, want_ranges=(args.algo == "scatter"))
+        if want_other_leg and split:         # the other-mode leg (table) counts ALL trees on every rank
+            batch_all, _ = native_ingest.ingest_text(ref_nw, all_text, 0, m_total, want_ranges=False)
+            batch = batch_all.slice(t_lo, t_hi)
+        else:
+            batch, _ = native_ingest.ingest_text(ref_nw, all_text, t_lo if split else 0, t_hi if split else m, want_ranges=(args.algo == "scatter"))
+            if want_other_leg:
+                batch_all = batch
         sample_text = all_text
     else:                                   # multifurcating / partial trees: the numpy generator (small sizes only)
         if args.mixed:
@@ -580,7 +806,7 @@ def main():
     shard_index = None
     if shards > 1:
         shard_index = args.shard_index if args.shard_index >= 0 else rank
-        d_lo, d_hi = distributed.shard_of_largest_id(n, shards, shard_index)
+        d_lo, d_hi = distributed.shard_of_largest_id(n, shards, shard_index, by=balance)
     nq_all = ranks.n_quartets(n)
     nq = ranks.n_quartets(d_hi) - ranks.n_quartets(d_lo)                 # quartets this rank's table holds
     ctx = engine.Context(n, count_bits, device=local_rank, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
@@ -599,7 +825,7 @@ def main():
     # the u32 table travels as u16 cells, binary full batches as ONE word per tuple; else the table's own cells.
     # (one rank under torch.distributed.run -- `--via-launcher` at N = 1 -- initialises RCCL and proves its communicator, but has
     # no peer to combine a table with: the step is the N = 1 step)
-    collective = (world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1") and shards == 1
+    collective = (world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1") and shards == 1 and mode != "table"
     total_trees_reduced = m_total if split else m * world
     tables = [table]
     wire_fmt = None
@@ -644,7 +870,9 @@ def main():
     # gather: QS_COUNT_OVERWRITE = "clear + count" in one pass (the first slice stores instead of accumulating)
     step_algo = algo | engine.QS_COUNT_OVERWRITE if args.algo == "gather" else algo
 
-    def step(timed=False):
+    def step(timed=False, exchange=True):
+        """One step. exchange=False (the count-only leg of an N > 1 line) keeps the counting path IDENTICAL -- wire words, pack
+        pass, buffers -- and leaves out nothing but the dist.* call."""
         i = step_no[0] % (2 if (wire16 or wire32x2) else len(tables))
         step_no[0] += 1
         if pending[i] is not None:       # the collective that last used this buffer must be done
@@ -671,7 +899,9 @@ def main():
                 src = wire[i]
             else:
                 src = tables[i]
-            if reduce_mode == "scatter":
+            if not exchange:
+                pass
+            elif reduce_mode == "scatter":
                 pending[i] = dist.reduce_scatter_tensor(recv[i], src[:send_words], op=dist.ReduceOp.SUM, async_op=True)
             else:
                 pending[i] = dist.all_reduce(src, op=dist.ReduceOp.SUM, async_op=True)
@@ -761,14 +991,13 @@ def main():
     count_only_ms = None
     if collective and steps > 0:
         fence()
-        collective = False
-        step()
+        step(exchange=False)
         ctx.sync()
         fence()
         k_co = max(3, min(steps, 10))
         c0 = time.perf_counter()
         for _ in range(k_co):
-            step()
+            step(exchange=False)            # same store path as the timed step (wire words / pack pass), no dist.* call
         ctx.sync()
         torch.cuda.synchronize(dev)
         count_only_ms = (time.perf_counter() - c0) * 1e3 / k_co
@@ -776,7 +1005,6 @@ def main():
             tt = torch.tensor([count_only_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             count_only_ms = float(tt.item())
-        collective = True
         step()                              # a freshly counted + reduced buffer for the gates below
         drain()
         torch.cuda.synchronize(dev)
@@ -965,6 +1193,18 @@ def main():
         except Exception:        # diagnostic only
             box_probe_ns = None
 
+    # ---- the OTHER multi-GPU mode on the same trees, a few steps, every rank (the line's `config.other_mode_leg`) ----
+    other_leg = None
+    if want_other_leg and steps > 0:
+        other = "table" if mode == "tree" else "tree"
+        k_leg = max(3, min(steps, 10))
+        try:
+            other_leg = run_mode_leg(other, world, rank, local_rank, n, count_bits, batch_all, m_total, k_leg, use_dist, balance)
+        except Exception as e:                   # a leg must never take the line down; every rank fails the same way or not at all
+            if use_dist and world > 1:
+                raise
+            other_leg = {"mode": other, "error": str(e)[:200]}
+
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -975,7 +1215,7 @@ def main():
     # the quartets of every rank's shard (with one shard per rank that is all quartets)
     if shards > 1:
         owned = [ranks.n_quartets(hi_) - ranks.n_quartets(lo_) for lo_, hi_ in
-                 (distributed.shard_of_largest_id(n, shards, (args.shard_index if args.shard_index >= 0 else r)) for r in range(world))]
+                 (distributed.shard_of_largest_id(n, shards, (args.shard_index if args.shard_index >= 0 else r), by=balance) for r in range(world))]
         units_per_step = m * sum(owned)
     else:
         units_per_step = (m_total if split else m * world) * nq_all
@@ -998,16 +1238,18 @@ def main():
         "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "n/a" if world == 1 else ("strong" if split else "weak"),
+        "scaling": "n/a" if world == 1 else ("strong" if (split or (shards > 1 and shards == world and args.shard_index < 0)) else "weak"),
         "vs_baseline": None,
         "dtype": "u32" if count_bits == 32 else "u16",
         "data": "synthetic",
         "config": {
-            "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " per rank" if world > 1 else "")
+            "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " (all on every rank)" if (world > 1 and mode == "table") else " per rank" if world > 1 else "")
                          + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
                          + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else (", mixed thirds" if args.mixed else "") + f", collapse {args.collapse} dropout {args.dropout}")
                          + f", seeds {seed_ref}/{seed_set}")[:100],
             "baseline_config": (f"BASELINE.json configs[{cfg_no}] (bench.py --config {cfg_no})" if not custom else "custom (not a BASELINE config)"),
+            "mode": mode, "mode_decided_by": mode_why, "mode_model": mode_est, "shard_balance": balance if shards > 1 else None,
+            "other_mode_leg": other_leg,
             "one_rank_same_workload": same_workload_scaling(value, world, m * nq_all, count_only_ms, elapsed / steps * 1e3) if count_only_ms else None,
             "quartets": nq_all,
             "quartets_this_rank": nq,
@@ -1048,7 +1290,7 @@ def main():
     # SURVEY 8(d) defines the phase from "trees resident on host": the same step with qs_batch_upload (validation, class plan, pinned
     # staging, H2D) inside, at top level beside `value` (which the bench contract defines with the inputs resident in HBM)
     if upload_step_ms:
-        out["value_upload_inclusive"] = (m * nq) / (upload_step_ms * 1e-3) * (world if not shards > 1 else 1)
+        out["value_upload_inclusive"] = (units_per_step if shards > 1 else (m * nq) * world) / (upload_step_ms * 1e-3)
         out["ms_per_step_upload_inclusive"] = upload_step_ms
         out["config"]["resident_ms_per_step"] = elapsed / steps * 1e3
         out["config"]["value_definition"] = "value: inputs in HBM (bench contract); value_upload_inclusive: host arrays -> table (SURVEY 8d)"

@@ -439,6 +439,15 @@ const char *qs_last_count_variant(const qs_ctx *ctx);
  * two partial rows at the ends of the range (0,0 if absent), which the scan kernel walks. first_pair / n_pairs: n_taxa
  * entries each. */
 int qs_score_plan(uint32_t n_taxa, uint64_t rank_lo, uint64_t n_tuples, uint32_t *first_pair, uint32_t *n_pairs, uint64_t parts[4]);
+/* Host-only: where to cut the table into n_shards contiguous shards by the largest taxon id (table-sharded counting on N GPUs or
+ * through one GPU: `QuartetScores --table-shards K`, bench.py --mode table). bounds[0..n_shards]: shard k owns the quartets whose largest
+ * id lies in [bounds[k], bounds[k+1]) -- contiguous rank ranges, because the rank's leading term is C(s3,4)
+ * (/root/reference/src/quartet_lookup_table.hpp:161-165; the reference itself never cuts its table). by = QS_SHARDS_BY_TUPLES balances
+ * the tuples a shard holds (memory), QS_SHARDS_BY_COST what the count kernel spends on it (tiles of its d-blocks; the cut with the
+ * smallest largest shard). Shards may be empty for tiny n. */
+#define QS_SHARDS_BY_TUPLES 0u
+#define QS_SHARDS_BY_COST 1u
+int qs_shard_bounds(uint32_t n_taxa, uint32_t n_shards, uint32_t by, uint32_t *bounds);
 
 #ifdef __cplusplus
 }

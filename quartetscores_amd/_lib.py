@@ -24,6 +24,7 @@ QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TI
 QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD, QS_TUNE_CLASS_PCT, QS_TUNE_CLASS_MIN_TREES = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
 QS_TUNE_DEPTH_CLAMP = 17
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
+QS_SHARDS_BY_TUPLES, QS_SHARDS_BY_COST = 0, 1
 
 # every symbol include/quartetscores_hip.h declares
 EXPORTS = [
@@ -33,7 +34,7 @@ EXPORTS = [
     "qs_score", "qs_score_pair_slots", "qs_score_set_view", "qs_score_pass1", "qs_score_pass2", "qs_score_finish", "qs_raw_qic", "qs_last_count_ms", "qs_last_count_variant",
     "qs_set_tuning", "qs_last_count_launches", "qs_batch_flags", "qs_score_overflow", "qs_free_host", "qs_raw_qic_lex",
     "qs_score_plan", "qs_last_score_ms", "qs_prepare", "qs_table_pack32x2", "qs_unpack32x2", "qs_last_score_log", "qs_last_score_estimate", "qs_score_prepare",
-    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan", "qs_score_check", "qs_last_count_events", "qs_class_plan",
+    "qs_sum_words", "qs_issue_probe", "qs_last_count_fix_ms", "qs_batch_clamp_info", "qs_depth_clamp_plan", "qs_score_check", "qs_last_count_events", "qs_class_plan", "qs_shard_bounds",
 ]
 
 
@@ -173,6 +174,8 @@ def load():
     L.qs_batch_clamp_info.argtypes = [vp, C.POINTER(u64 * 3)]
     L.qs_last_count_events.restype = i32
     L.qs_last_count_events.argtypes = [vp, vp, vp, i32]
+    L.qs_shard_bounds.restype = i32
+    L.qs_shard_bounds.argtypes = [u32, u32, u32, vp]
     L.qs_class_plan.restype = i32
     L.qs_class_plan.argtypes = [u32, C.POINTER(TreeBatchC), u32, u32, u32, vp, vp, vp]
     L.qs_score_check.restype = i32

@@ -15,6 +15,8 @@
 #include "table_shards.hpp"
 
 #include <cerrno>
+#include <cstdlib>
+#include <unistd.h>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -26,6 +28,20 @@
 using namespace qsh;
 
 namespace {
+
+bool fast_exit_forced = false;
+// true when something in the environment says "a tool rides along that flushes at exit"
+bool wrapped_by_tool() {
+    const char *pre = std::getenv("LD_PRELOAD");
+    if (pre && *pre) return true;
+    if (std::getenv("HSA_TOOLS_LIB")) return true;
+    for (char **e = ::environ; e && *e; ++e) {
+        const std::string kv = *e;
+        if (kv.rfind("ROCP_", 0) == 0 || kv.rfind("ROCPROFILER_", 0) == 0 || kv.rfind("ROCTRACER_", 0) == 0 || kv.rfind("ASAN_OPTIONS", 0) == 0 ||
+            kv.rfind("LLVM_PROFILE_FILE", 0) == 0 || kv.rfind("GCOV_PREFIX", 0) == 0) return true;
+    }
+    return false;
+}
 
 struct Args {
     std::string ref, eval, out, raw, raw_bin;
@@ -58,7 +74,9 @@ void usage(std::ostream &os) {
           "   --exact-qp     64-bit QP sums instead of the reference's 32-bit wrap\n"
           "   --qic-rank-order  -q lines in the order of the count table instead of the reference's loop order\n"
           "   --trace        time stamps of the counting pipeline on stderr\n"
-          "   --clean-exit   tear the HIP runtime down before exiting (default: exit right after the output is written)\n"
+          "   --clean-exit   tear the HIP runtime down before exiting (default: exit right after the output is written,\n"
+          "                  unless LD_PRELOAD or a profiler's ROCP_* / ROCPROFILER_* / HSA_TOOLS_LIB environment is set)\n"
+          "   --fast-exit    exit right after the output is written even under such a wrapper\n"
           "   --root-as-edge rooted reference tree: score the two root edges as one internode (the reference's\n"
           "                  own handling of a degree-2 root is the default)\n"
           "   --table-shards K  the count table in K shards by largest taxon id (0 = as many as the free device memory asks for):\n"
@@ -124,6 +142,7 @@ int parse(int argc, char **argv, Args &a) {
         else if (f == "--root-as-edge") a.dev.root_as_edge = true;
         else if (f == "--fail-fast") a.fail_fast = true;
         else if (f == "--clean-exit") a.clean_exit = true;
+        else if (f == "--fast-exit") fast_exit_forced = true;
         else if (f == "--reduce") {
             if (!(v = need(i, "--reduce"))) return 1;
             a.dev.reduce = v;
@@ -142,6 +161,9 @@ int parse(int argc, char **argv, Args &a) {
     }
     const char *missing = a.ref.empty() ? "-r (--ref)" : a.eval.empty() ? "-e (--eval)" : a.out.empty() ? "-o (--output)" : nullptr;
     if (missing) { std::cerr << "ERROR: Required argument missing: for arg " << missing << std::endl; return 1; }
+    // A wrapper that flushes in its exit handlers (rocprofv3, a tracer, a coverage or sanitizer runtime) would lose its output to the
+    // fast exit: with a preloaded library or a profiler's environment the ordinary return is the default (--fast-exit overrides)
+    if (!a.clean_exit && !fast_exit_forced && wrapped_by_tool()) a.clean_exit = true;
     return 0;
 }
 

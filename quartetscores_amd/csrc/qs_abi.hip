@@ -1146,6 +1146,68 @@ extern "C" int qs_class_plan(uint32_t n_taxa, const qs_tree_batch *hb, uint32_t 
     return QS_OK;
 }
 
+/* Host-only: bounds[0..n_shards] of the largest taxon id d that cut the table into n_shards contiguous shards [bounds[k], bounds[k+1])
+ * (contiguous rank ranges: the rank's leading term is C(s3,4), quartet_lookup_table.hpp:161-165).
+ *   by = QS_SHARDS_BY_TUPLES: balanced by the tuples a shard HOLDS, C(d,4) (memory: configs[4], out-of-core runs);
+ *   by = QS_SHARDS_BY_COST:   balanced by what the count kernel SPENDS on a shard -- the wave tiles of its d-blocks (blocks of 8
+ *        largest ids aligned to the shard's top, the partial block at its bottom), each tile priced at (kShardTileOverhead + live
+ *        d slots): fitted to the per-shard timings of profiles/r06_scaling_model.json within 2 %. The largest shard is minimal
+ *        over all contiguous cuts (bisection on the bound, greedy from the top). */
+constexpr double kShardTileOverhead = 4.0;
+extern "C" int qs_shard_bounds(uint32_t n_taxa, uint32_t n_shards, uint32_t by, uint32_t *bounds) {
+    if (!bounds || n_shards == 0 || n_taxa < 4 || n_taxa > 65535) return QS_ERR_ARG;
+    const uint32_t n = n_taxa, K = n_shards;
+    if (by == QS_SHARDS_BY_TUPLES) {
+        const uint64_t total = binom4(n);
+        bounds[0] = 0;
+        for (uint32_t r = 1; r < K; ++r) {
+            const uint64_t target = total / K * r;
+            uint32_t d = bounds[r - 1];
+            while (d < n && binom4(d) < target) ++d;
+            bounds[r] = d;
+        }
+        bounds[K] = n;
+        return QS_OK;
+    }
+    if (by != QS_SHARDS_BY_COST) return QS_ERR_ARG;
+    // T0[c] = sum of tiles(c') over c' < c, T1[c] = sum of tiles(c') * c'
+    std::vector<double> T0(n + 2, 0.0), T1(n + 2, 0.0);
+    for (uint32_t c = 0; c <= n; ++c) {
+        const double t = c >= 2 ? (double)bitslice3_tiles_for_c(c) : 0.0;
+        T0[c + 1] = T0[c] + t; T1[c + 1] = T1[c] + t * c;
+    }
+    auto cost = [&](uint32_t d_lo, uint32_t d_hi) {   // count-kernel cost of the shard [d_lo, d_hi)
+        d_lo = std::max(d_lo, 3u);
+        double tot = 0.0;
+        for (uint32_t d1 = d_hi; d1 > d_lo;) {
+            const uint32_t d0 = d1 > d_lo + kDB ? d1 - kDB : d_lo, p = d1 - d0;
+            // third ids below the block see all p slots; c inside the block sees the slots above it: d1 - 1 - c
+            tot += (kShardTileOverhead + p) * T0[d0] + (kShardTileOverhead + (double)(d1 - 1)) * (T0[d1 - 1] - T0[d0]) - (T1[d1 - 1] - T1[d0]);
+            d1 = d0;
+        }
+        return tot;
+    };
+    auto cut = [&](double bound, uint32_t *out) {     // greedy from the top; true if K shards suffice (shards left over stay empty: [0, 0))
+        uint32_t hi = n;
+        if (out) out[K] = n;
+        for (uint32_t k = K; k-- > 0;) {
+            uint32_t lo = hi;
+            while (lo > 0 && cost(lo - 1, hi) <= bound) --lo;   // (ids below 3 hold nothing: the cost stops growing, lo runs to 0)
+            if (k == 0 && lo > 0) return false;
+            if (out) out[k] = lo;
+            hi = lo;
+        }
+        return true;
+    };
+    double lo_b = cost(0, n) / K, hi_b = cost(0, n);
+    for (int it = 0; it < 60 && hi_b - lo_b > 1e-9 * hi_b; ++it) {
+        const double mid = 0.5 * (lo_b + hi_b);
+        if (cut(mid, nullptr)) hi_b = mid; else lo_b = mid;
+    }
+    if (!cut(hi_b, bounds)) return QS_ERR_STATE;
+    return QS_OK;
+}
+
 extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_batch **out) {
     if (!c || !hb || !out) return fail(c, QS_ERR_ARG, "qs_batch_upload: NULL argument");
     *out = nullptr;
@@ -1396,7 +1458,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
     algo &= ~(QS_COUNT_OVERWRITE | QS_COUNT_TIMED);
     if (algo == QS_ALGO_AUTO) algo = QS_ALGO_GATHER;
     if (overwrite && algo != QS_ALGO_GATHER) return fail(c, QS_ERR_ARG, "qs_count_batch: QS_COUNT_OVERWRITE needs the gather algorithm");
-    if (overwrite) c->trees_counted = 0;
+    // (an overwrite resets trees_counted only once nothing can fail any more: a refused call leaves table and count as they were)
     c->ev_used = 0;
     if (timed) QS_HIP(c, mark(c, 0));
     if (algo == QS_ALGO_GATHER) {
@@ -1502,7 +1564,7 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         return fail(c, QS_ERR_ARG, "qs_count_batch: unknown algo");
     }
     c->last_timed = timed;
-    c->trees_counted += d.n_trees;
+    c->trees_counted = (overwrite ? 0 : c->trees_counted) + d.n_trees;
     return QS_OK;
 }
 

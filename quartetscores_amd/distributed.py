@@ -63,9 +63,26 @@ def reduce_scatter_table(send, recv, group=None, async_op=False):
     return None
 
 
-def shard_of_largest_id(n: int, world: int, rank: int) -> Tuple[int, int]:
+def shard_bounds(n: int, shards: int, by: str = "c4"):
+    """bounds[0..shards] of the largest taxon id: qs_shard_bounds of the C-ABI (host-only arithmetic, no GPU needed).
+    by="c4": balanced by the tuples held; by="cost": balanced by the count kernel's work (tools/scaling_model.py)."""
+    import ctypes as C
+    from . import _lib
+    out = (C.c_uint32 * (shards + 1))()
+    rc = _lib.load().qs_shard_bounds(n, shards, _lib.QS_SHARDS_BY_COST if by == "cost" else _lib.QS_SHARDS_BY_TUPLES, out)
+    if rc != 0:
+        raise ValueError(f"qs_shard_bounds({n}, {shards}, {by}) failed: {rc}")
+    return [int(x) for x in out]
+
+
+def shard_of_largest_id(n: int, world: int, rank: int, by: str = "c4") -> Tuple[int, int]:
     """Table-sharded mode: [d_lo, d_hi) of the largest taxon id, balanced by C(d,4) (ranks are
-    contiguous in d because rank's leading term is C(s3,4), quartet_lookup_table.hpp:161-165)."""
+    contiguous in d because rank's leading term is C(s3,4), quartet_lookup_table.hpp:161-165).
+    by="cost": balanced by what the count kernel spends on a shard instead of the tuples it holds (shard_bounds)."""
+    if by == "cost":
+        b = shard_bounds(n, world, "cost")
+        return b[rank], b[rank + 1]
+
     def c4(x):
         return x * (x - 1) * (x - 2) * (x - 3) // 24
     total = c4(n)

@@ -416,15 +416,21 @@ class QuartetScoreComputer:
     edge; edge e is the edge above node e+1 of the reference tree in preorder."""
 
     def __init__(self, refTree: Union[str, flatten.RefTree], evalTreesPath, m: Optional[int] = None, verboseOutput: bool = False,
-                 enforceSmallMem: bool = False, *, qp_exact64: bool = False, root_as_edge: bool = False, log=None, **kw):
+                 enforceSmallMem: bool = False, *, qp_exact64: bool = False, root_as_edge: bool = False, fail_fast: bool = False, log=None, **kw):
         self.ref = refTree if isinstance(refTree, flatten.RefTree) else flatten.flatten_reference(refTree)
         say = log or (lambda s: None)
         n = self.ref.n_taxa
         score_flags = ((QS_SCORE_QP_EXACT64 if qp_exact64 else QS_SCORE_QP_WRAP32) | (QS_SCORE_ROOT_AS_EDGE if root_as_edge else 0) |
                        (QS_SCORE_SAVEMEM_LOOKUPS if enforceSmallMem else 0))
         # what the scoring would refuse because of the reference tree alone (`-s` + a rooted reference: the reference program
-        # throws there, after it has counted) is known now: raise before the counting instead of after it
-        score_check(self.ref, score_flags)
+        # throws there, after it has counted) is known now. Like the CLI (QuartetScores.cpp: a note, then the reference's order of
+        # events): say so, count, and let the scoring raise; fail_fast=True (the CLI's --fail-fast) raises before the counting
+        try:
+            score_check(self.ref, score_flags)
+        except QSError as e:
+            if fail_fast or e.code != _lib.QS_ERR_REFERENCE_THROWS:
+                raise
+            say("note: the scoring of this reference tree will end with the reference's exception (-s with a rooted reference tree); counting first, like the reference")
         self.quartetCounterLookup = QuartetCounterLookup(self.ref, evalTreesPath, m, enforceSmallMem, **kw)
         say(f"There are {self.quartetCounterLookup.m} evaluation trees.")
         say(f"The reference tree has {n} taxa.")

@@ -125,3 +125,27 @@ def test_scaling_fields_and_cli_phase_parsing():
             os.environ["HIP_VISIBLE_DEVICES"] = old
     cpus = bench.numa_node0_cpus()
     assert cpus is None or (len(cpus) >= 1 and set(cpus) <= set(os.sched_getaffinity(0)))
+
+
+def test_auto_mode_follows_the_one_gpu_scaling_model():
+    """bench.py --mode auto: the table-sharded mode where the table collective would cost more than table-sharding adds (configs[2]:
+    34 GB of table per rank against a replicated 1.8 ms panel build), the tree-sharded mode where it does not (configs[3]: 100 000
+    trees, a 2.1 GB table). When profiles/r06_scaling_model.json is there, the choice must agree with its measured per-rank steps."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (2, 4, 8):
+        mode, est = bench.auto_mode(512, 10000, world)
+        assert mode == "table" and est["table_extra_ms"] < est["tree_collective_ms_ring_bound"], (world, est)
+    mode, est = bench.auto_mode(256, 100000, 8)
+    assert mode == "tree", est
+    path = os.path.join(ROOT, "profiles", "r06_scaling_model.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            doc = json.load(f)
+        for cfg_no, entry in doc["configs"].items():
+            for n_ranks, tab in entry["table"].items():
+                tree = entry["tree"][n_ranks]
+                # measured per-rank steps + the ring-bound collective of the model
+                better = "table" if tab["max_ms"] < tree["count_max_ms"] + tree["collective_model"]["ring_ms"] else "tree"
+                got, _ = bench.auto_mode(entry["taxa"], entry["trees"], int(n_ranks))
+                assert got == better, (cfg_no, n_ranks, got, tab["max_ms"], tree["count_max_ms"], tree["collective_model"]["ring_ms"])

@@ -269,3 +269,88 @@ def test_score_table_shards_over_two_ranks(tmp_path, n_shards):
         assert set(got) == set(want)
         for k in got:
             assert got[k] == want[k], (r, sorted(k), got[k], want[k])
+
+
+def _both_modes_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulate
+    from quartetscores_amd import distributed, flatten, ranks, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m = 13, 46
+    ref = flatten.flatten_reference(synth.reference_tree(n, 51))
+    batch = flatten.flatten_eval_trees(synth.tree_set(n, m, 52, collapse=0.1), ref.name_to_id)
+    nq = ranks.n_quartets(n)
+    cpu = torch.device("cpu")
+    # tree mode: trees / N per rank into a full table, reduce-scatter, every rank scores the shard it received
+    lo, hi = distributed.shard_range(m, world, rank)
+    _t, words = distributed.scatter_layout(nq, world, 32)
+    send = torch.zeros(world * words, dtype=torch.int32)
+    send.numpy().view(np.uint32)[: nq * 3].reshape(nq, 3)[...] = emulate.counts_from_batch(batch.slice(lo, hi), n).astype(np.uint32)
+    recv = torch.zeros(words, dtype=torch.int32)
+    distributed.reduce_scatter_table(send, recv)
+    r_lo, n_own = distributed.scatter_owned(nq, world, rank, 32)
+    shard = recv.numpy().view(np.uint32)[: n_own * 3].reshape(n_own, 3).astype(np.uint64)
+    tree_scores = distributed.score_sharded(emulate.ScoreEmu(ref, shard, r_lo), ref, device=cpu)
+    # table mode: ALL trees per rank into the rank's shard by largest taxon id (cost-balanced bounds), no table collective
+    d_lo, d_hi = distributed.shard_of_largest_id(n, world, rank, by="cost")
+    full = emulate.counts_from_batch(batch, n)
+    q_lo, q_hi = ranks.n_quartets(d_lo), ranks.n_quartets(d_hi)
+
+    def open_shard(k):
+        return emulate.ScoreEmu(ref, full[q_lo:q_hi] if k is not None else full[:0], q_lo if k is not None else 0)
+    table_scores = distributed.score_table_shards(open_shard, [rank], ref, device=cpu)
+    for name, (lq, qp, eqp, _bif) in (("tree", tree_scores), ("table", table_scores)):
+        np.save(os.path.join(out_dir, f"{name}{rank}.npy"), np.stack([lq, qp, eqp]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tree_and_table_sharded_modes_give_identical_scores(tmp_path):
+    """bench.py --mode tree | table, `QuartetScores --gpus N --mode ...` over 2 gloo ranks on the same trees: the
+    tree-sharded route (trees / N per rank, reduce-scatter of the table, score_sharded) and the table-sharded route (all trees per
+    rank, shard by largest taxon id with the cost-balanced bounds of qs_shard_bounds, score_table_shards) end with the SAME
+    LQ/QP/EQP-IC, bit for bit, on every rank. Counting = the numpy emulation; scoring host code = the library's."""
+    world = 2
+    mp.spawn(_both_modes_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref_scores = np.load(tmp_path / "tree0.npy")
+    assert np.isfinite(ref_scores[0][1:]).any()
+    for name in ("tree", "table"):
+        for r in range(world):
+            got = np.load(tmp_path / f"{name}{r}.npy")
+            assert got.shape == ref_scores.shape and (got.view(np.int64) == ref_scores.view(np.int64)).all(), (name, r)
+
+
+def test_shard_bounds_cover_the_table_and_balance_what_they_claim():
+    """qs_shard_bounds (host-only): contiguous shards by largest taxon id (quartet_lookup_table.hpp:161-165: the rank's leading
+    term is C(s3,4)); by tuples = the Python arithmetic of shard_of_largest_id; by cost = no shard above the bound the bisection
+    found, and a smaller largest shard (in the cost model) than the tuple-balanced cut."""
+    from quartetscores_amd import distributed
+
+    def tiles(c):
+        t = (c + 7) // 8
+        return (t * t) // 4 + (t + 1) // 2 if c >= 2 else 0
+
+    def cost(d_lo, d_hi, alpha=4.0):
+        d_lo = max(d_lo, 3)
+        tot, d1 = 0.0, d_hi
+        while d1 > d_lo:
+            d0 = max(d1 - 8, d_lo)
+            for c in range(2, d1 - 1):
+                tot += tiles(c) * (alpha + ((d1 - d0) if c < d0 else (d1 - 1 - c)))
+            d1 = d0
+        return tot
+    for n, k in ((512, 8), (256, 8), (128, 4), (97, 3), (33, 2), (8, 4), (4, 2)):
+        c4 = distributed.shard_bounds(n, k, "c4")
+        by_cost = distributed.shard_bounds(n, k, "cost")
+        assert c4 == [distributed.shard_of_largest_id(n, k, r)[0] for r in range(k)] + [n]
+        for b in (c4, by_cost):
+            assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:])) and len(b) == k + 1
+        if n >= 33:
+            worst_c4 = max(cost(lo, hi) for lo, hi in zip(c4, c4[1:]))
+            worst = max(cost(lo, hi) for lo, hi in zip(by_cost, by_cost[1:]))
+            assert worst <= worst_c4 * (1 + 1e-9), (n, k, by_cost, c4)
+            assert worst <= 1.12 * cost(0, n) / k or n < 256, (n, k, worst / (cost(0, n) / k))   # (every shard pays for one partial d-block)
+    assert distributed.shard_bounds(512, 8, "cost") == [0, 303, 362, 402, 433, 457, 478, 496, 512]

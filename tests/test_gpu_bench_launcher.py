@@ -69,3 +69,26 @@ def test_forced_collective_line_carries_its_own_scaling_figures_and_the_p2p_leg(
     plain = run_bench(["--gpus", "1"] + SMALL)
     assert plain["scaling"] == "n/a" and plain["config"]["one_rank_same_workload"] is None and "p2p_leg" not in plain["config"]
     assert plain["config"]["baseline_config"].startswith("custom")
+
+
+def test_table_mode_through_the_launcher_and_the_other_mode_leg():
+    """`--gpus 1 --via-launcher --mode table` (the N > 1 default for configs[2], here with one rank = one shard = the whole table):
+    no table collective in the step, the line says which mode ran and why, and -- with the N > 1 path forced -- it carries the
+    OTHER mode (tree-sharded + RCCL reduce-scatter) as a leg measured on the same trees in the same run."""
+    os.environ["QS_BENCH_FORCE_DIST"] = "1"
+    try:
+        doc = run_bench(["--gpus", "1", "--via-launcher", "--mode", "table"] + SMALL)
+        tree = run_bench(["--gpus", "1", "--mode", "tree", "--taxa", "160", "--trees", "6000", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-e2e", "--no-score"])
+    finally:
+        del os.environ["QS_BENCH_FORCE_DIST"]
+    cfg = doc["config"]
+    assert cfg["mode"] == "table" and cfg["mode_decided_by"] == "--mode table" and cfg["collective"] is None
+    assert cfg["parity_tuple_sums_ok"] is True and doc["collective"]["table_collective"] is None
+    leg = cfg["other_mode_leg"]
+    assert leg["mode"] == "tree" and leg["collective"] == "scatter" and leg["parity_tuple_sums_ok"] is True, leg
+    assert leg["ms_per_step"] > 0 and 0.5 < leg["value"] / doc["value"] < 2.0, (leg["value"], doc["value"])
+    cfg = tree["config"]
+    assert cfg["mode"] == "tree" and cfg["collective"] == "scatter" and cfg["parity_reduced_tuple_sums_ok"] is True
+    leg = cfg["other_mode_leg"]
+    assert leg["mode"] == "table" and leg["collective"] is None and leg["parity_tuple_sums_ok"] is True and leg["table_shard_rank0"] == [0, 160], leg

@@ -922,6 +922,16 @@ def test_rooted_reference_compact_mode_matches_oracle(eng, case):
     with pytest.raises(eng.QSError) as eg:
         eng.QuartetScoreComputer(fx["ref"], fx["eval"], None, False, True)          # (..., verboseOutput, enforceSmallMem)
     assert eg.value.code == _lib.QS_ERR_REFERENCE_THROWS and str(eg.value).endswith(fx["reference_throws"])
+    # order of events = the CLI's = the reference's: a note, the counting and its log lines, then the exception from the scoring;
+    # fail_fast=True (the CLI's --fail-fast) raises before anything is counted
+    said = []
+    with pytest.raises(eng.QSError):
+        eng.QuartetScoreComputer(fx["ref"], fx["eval"], None, False, True, log=said.append)
+    assert said[0].startswith("note:") and "Finished counting quartets." in said and "Finished computing scores." not in said
+    said = []
+    with pytest.raises(eng.QSError) as ef:
+        eng.QuartetScoreComputer(fx["ref"], fx["eval"], None, False, True, fail_fast=True, log=said.append)
+    assert ef.value.code == _lib.QS_ERR_REFERENCE_THROWS and said == []
     # the same inputs without -s: the runtime-efficient table's scores, equal to the oracle's
     qsc = eng.QuartetScoreComputer(fx["ref"], fx["eval"])
     o2 = oracle_counts(fx["ref"], fx["eval"])
