@@ -687,24 +687,24 @@ def main():
     #   tree:  rank r counts trees/N into a full table, one RCCL collective on the table per step;
     #   tree-weak (--split-trees 0): every rank counts --trees of its own + the collective (weak scaling; the pre-round-6 default of configs 1/2)
     # explicit shards (configs[4], --table-shards K): the table-sharded path with K >= N shards, as before.
-    mode, mode_why, mode_est = "single", "one rank", None
+    par_mode, mode_why, mode_est = "single", "one rank", None
     multi = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
     if shards > 1:
         shards = max(shards, world)
         split = False
-        mode, mode_why = "table", ("--table-shards" if args.table_shards else "configs[4]: the table is sharded by definition")
+        par_mode, mode_why = "table", ("--table-shards" if args.table_shards else "configs[4]: the table is sharded by definition")
     elif args.split_trees == 0 and multi:
         split = False
-        mode, mode_why = "tree-weak", "--split-trees 0"
+        par_mode, mode_why = "tree-weak", "--split-trees 0"
     elif multi:
         if args.mode == "auto" and args.split_trees < 0 and world > 1:
-            mode, mode_est = auto_mode(n, m_total, world, binary_full_trees)
+            par_mode, mode_est = auto_mode(n, m_total, world, binary_full_trees)
             mode_why = "auto (model)"
         else:
-            mode = "tree" if (args.mode == "auto" or args.split_trees == 1) else args.mode
+            par_mode = "tree" if (args.mode == "auto" or args.split_trees == 1) else args.mode
             mode_why = "--mode " + args.mode if args.mode != "auto" else "one rank under the launcher: the tree-sharded path with nothing to exchange"
-        split = mode == "tree"
-        if mode == "table":
+        split = par_mode == "tree"
+        if par_mode == "table":
             shards = world               # (one shard per rank; world == 1: the whole table)
     else:
         split = False
@@ -713,8 +713,8 @@ def main():
     m = t_hi - t_lo                                                      # trees THIS rank counts per step
     # seeded inputs: seed = 1000 * config + tree-set id. Split configs: ONE set of m_total trees, rank
     # r takes trees [t_lo, t_hi); otherwise rank r counts its own set r (tree t of a set depends only on (seed, t)).
-    seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or mode == "table") else rank)
-    want_other_leg = multi and mode in ("tree", "table") and not (args.table_shards or cfg["shards"] > 1) and binary_full_trees and args.algo == "gather" \
+    seed_ref, seed_set = 1000 * cfg_no, 1000 * cfg_no + 1 + (0 if (split or par_mode == "table") else rank)
+    want_other_leg = multi and par_mode in ("tree", "table") and not (args.table_shards or cfg["shards"] > 1) and binary_full_trees and args.algo == "gather" \
         and (args.other_leg == 1 or args.other_leg < 0)
     t_gen = time.perf_counter()
     batch_all = None
@@ -825,7 +825,7 @@ def main():
     # the u32 table travels as u16 cells, binary full batches as ONE word per tuple; else the table's own cells.
     # (one rank under torch.distributed.run -- `--via-launcher` at N = 1 -- initialises RCCL and proves its communicator, but has
     # no peer to combine a table with: the step is the N = 1 step)
-    collective = (world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1") and shards == 1 and mode != "table"
+    collective = (world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1") and shards == 1 and par_mode != "table"
     total_trees_reduced = m_total if split else m * world
     tables = [table]
     wire_fmt = None
@@ -1196,7 +1196,7 @@ def main():
     # ---- the OTHER multi-GPU mode on the same trees, a few steps, every rank (the line's `config.other_mode_leg`) ----
     other_leg = None
     if want_other_leg and steps > 0:
-        other = "table" if mode == "tree" else "tree"
+        other = "table" if par_mode == "tree" else "tree"
         k_leg = max(3, min(steps, 10))
         try:
             other_leg = run_mode_leg(other, world, rank, local_rank, n, count_bits, batch_all, m_total, k_leg, use_dist, balance)
@@ -1243,12 +1243,12 @@ def main():
         "dtype": "u32" if count_bits == 32 else "u16",
         "data": "synthetic",
         "config": {
-            "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " (all on every rank)" if (world > 1 and mode == "table") else " per rank" if world > 1 else "")
+            "workload": (f"{wl_name}: {n} taxa x {m_total} trees" + (f" split over {world} ranks" if split else " (all on every rank)" if (world > 1 and par_mode == "table") else " per rank" if world > 1 else "")
                          + f", u{count_bits} table" + (f" shard d[{d_lo},{d_hi}) of {shards}" if shards > 1 else "")
                          + (", ladder+NNI trees" if args.shape == "ladder" else ", ref+NNI trees" if args.nni else ", random binary trees" if binary_full_trees else (", mixed thirds" if args.mixed else "") + f", collapse {args.collapse} dropout {args.dropout}")
                          + f", seeds {seed_ref}/{seed_set}")[:100],
             "baseline_config": (f"BASELINE.json configs[{cfg_no}] (bench.py --config {cfg_no})" if not custom else "custom (not a BASELINE config)"),
-            "mode": mode, "mode_decided_by": mode_why, "mode_model": mode_est, "shard_balance": balance if shards > 1 else None,
+            "mode": par_mode, "mode_decided_by": mode_why, "mode_model": mode_est, "shard_balance": balance if shards > 1 else None,
             "other_mode_leg": other_leg,
             "one_rank_same_workload": same_workload_scaling(value, world, m * nq_all, count_only_ms, elapsed / steps * 1e3) if count_only_ms else None,
             "quartets": nq_all,

@@ -199,6 +199,10 @@ const char *qs_last_error(const qs_ctx *ctx); /* ctx may be NULL: message of the
                                        * correction kernel with atomics) when that costs at most `value` millionths of C(n,4) (tree, quartet)
                                        * corrections per depth bit saved (default 20; 16 x that for the trees of a class too small for a pass of
                                        * its own); 0 = every tree in the class of its own depth bits. Read by qs_batch_upload. */
+#define QS_TUNE_FUSE_CLASSES 18u      /* 1 (default): the classes of a batch that share their depth bits (up to 7) are counted in ONE launch of the count
+                                       * kernel -- one pass over the table whatever the mix of tree shapes, like the reference's shape-independent loop
+                                       * (QuartetCounterLookup.hpp:65-106,166-188); no mode joins a dearer one any more. 0: one launch per class (round 5).
+                                       * Read by qs_batch_upload (class plan) and qs_count_batch (launches). */
 #define QS_TUNE_CLASS_MIN_TREES 16u   /* ... and the absolute floor of a class (default 1024 trees; tests lower it to split small batches) */
 #define QS_TUNE_SCORE_LOAD 14u        /* bundle score kernel, shape of the table loads: 0 (default) = every lane loads its own row in 16-byte pieces;
                                        * 2 = ... and requests the next chunk before it processes the current one; 1 = eight lanes load the
@@ -412,6 +416,7 @@ int qs_depth_clamp_plan(uint32_t n_taxa, const qs_tree_batch *batch, uint32_t pp
  * budget given: per tree the kernel mode (0 binary_full, 1 general_full, 2 partial, 3 binary_partial) and depth bits of the class it is
  * counted in (a small class joins a more general mode, goes down to a larger class where the corrections allow it, or joins the next
  * deeper class), and the tree's slot in the class-ordered batch. Any output may be NULL. The trees are not validated here. */
+#define QS_CLASS_PLAN_FUSED 0x100u   /* or-ed into class_pct: the plan of QS_TUNE_FUSE_CLASSES = 1 (classes of equal depth bits share a launch) */
 int qs_class_plan(uint32_t n_taxa, const qs_tree_batch *batch, uint32_t class_min_trees, uint32_t class_pct, uint32_t clamp_ppm,
                   uint8_t *mode_of_tree, uint8_t *bits_of_tree, uint32_t *slot_of_tree);
 /* Phases of the most recent qs_score call in milliseconds: [0] the whole call (host clock), [1] set-up (accumulator

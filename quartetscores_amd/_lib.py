@@ -23,6 +23,8 @@ QS_BATCH_ALL_TAXA, QS_BATCH_BINARY = 1, 2
 QS_TUNE_PANEL_SLICE_BYTES, QS_TUNE_GATHER_IMPL, QS_TUNE_PANEL_KERNEL, QS_TUNE_TILE_ORDER = 1, 2, 3, 4
 QS_TUNE_SCORE_CAND_SLOTS, QS_TUNE_SCORE_TOL_EXP, QS_TUNE_SCORE_KERNEL, QS_TUNE_TABLE_TREES, QS_TUNE_COOP, QS_TUNE_SCORE_PASSES, QS_TUNE_SCORE_LOG_CAP, QS_TUNE_SCORE_SAMPLE, QS_TUNE_SCORE_DEDUPE, QS_TUNE_SCORE_LOAD, QS_TUNE_CLASS_PCT, QS_TUNE_CLASS_MIN_TREES = 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
 QS_TUNE_DEPTH_CLAMP = 17
+QS_TUNE_FUSE_CLASSES = 18
+QS_CLASS_PLAN_FUSED = 0x100
 QS_IMPL_AUTO, QS_IMPL_SWAR, QS_IMPL_BITSLICE = 0, 1, 2
 QS_SHARDS_BY_TUPLES, QS_SHARDS_BY_COST = 0, 1
 

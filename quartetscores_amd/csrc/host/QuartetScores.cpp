@@ -49,7 +49,8 @@ struct Args {
     bool verbose = false, savemem = false, raw_rank_order = false, fail_fast = false, clean_exit = false;
     int table_shards = -1;   // -1 = off (the whole table on the device); 0 = as many as the device's free memory asks for; K = K shards, one after the other (table_shards.hpp)
     int spill = 0;           // ShardedTableQuartetScoreComputer::Spill
-    int gpus = 0;   // 0 = the single-GPU path; N >= 1 = trees split over N GPUs of this node + one RCCL collective (multi_gpu.hpp)
+    int gpus = 0;   // 0 = the single-GPU path; N >= 1 = N GPUs of this node: tree-sharded + one table collective (multi_gpu.hpp) or table-sharded (table_shards.hpp)
+    std::string mode = "auto";   // --mode with --gpus N: tree | table | auto (the model of table_shards.hpp prefer_table_shards)
     DeviceOptions dev;
 };
 
@@ -65,8 +66,11 @@ void usage(std::ostream &os) {
           "                  ends with the reference's own std::runtime_error, see --root-as-edge; a note says so before the\n"
           "                  counting starts, --fail-fast ends the run there)\n"
           "   --device N     HIP device ordinal (default 0)\n"
-          "   --gpus N       split the evaluation trees over N GPUs of this node (devices --device .. --device+N-1) and\n"
-          "                  combine the count tables with one reduction over xGMI\n"
+          "   --gpus N       count on N GPUs of this node (devices --device .. --device+N-1)\n"
+          "   --mode M       with --gpus: tree = the evaluation trees are split over the GPUs and the count tables combined with one\n"
+          "                  reduction over xGMI; table = every GPU counts ALL trees into its shard of the table (by largest taxon\n"
+          "                  id): no table collective, no communicator; auto (default) = table unless -q / --qic-binary need the\n"
+          "                  whole table on one device or the table collective is the cheaper of the two (many trees, small table)\n"
           "   --reduce R     with --gpus: rccl (default: one RCCL reduce-scatter / all-reduce) | p2p (this one process maps its\n"
           "                  peers' memory and every GPU sums its chunk with plain loads: no communicator to create)\n"
           "   --comm-overlap 0|1  with --gpus, rccl: count while the communicators are being created (default 0: the first launch waits for them)\n"
@@ -140,6 +144,11 @@ int parse(int argc, char **argv, Args &a) {
             a.dev.algo = std::string(v) == "scatter" ? QS_ALGO_SCATTER : QS_ALGO_GATHER;
         } else if (f == "--exact-qp") a.dev.qp_exact64 = true;
         else if (f == "--root-as-edge") a.dev.root_as_edge = true;
+        else if (f == "--mode") {
+            if (!(v = need(i, "--mode"))) return 1;
+            a.mode = v;
+            if (a.mode != "auto" && a.mode != "tree" && a.mode != "table") { std::cerr << "ERROR: --mode takes auto, tree or table" << std::endl; return 1; }
+        }
         else if (f == "--fail-fast") a.fail_fast = true;
         else if (f == "--clean-exit") a.clean_exit = true;
         else if (f == "--fast-exit") fast_exit_forced = true;
@@ -206,6 +215,22 @@ void run(const Tree &referenceTree, const Args &a, size_t m, std::vector<double>
             return run_sharded(referenceTree, a, m, bits, std::max(needed, gpus), gpus, lqic, qpic, eqpic);
         }
         if (a.gpus > 0 && a.table_shards == 0) return run_sharded(referenceTree, a, m, bits, gpus, gpus, lqic, qpic, eqpic);
+    }
+    if (a.gpus > 1 && a.table_shards < 0) {
+        // N GPUs, the table fits one of them: tree- or table-sharded. The count work per GPU is the same either way;
+        // the table-sharded mode needs no collective and no communicator, the tree-sharded one keeps the whole table on GPU 0
+        // (which -q / --qic-binary / --save-table walk).
+        const bool need_whole = !a.raw.empty() || !a.raw_bin.empty() || !a.dev.save_table.empty() || !a.dev.load_table.empty();
+        double coll_ms = 0.0, extra_ms = 0.0;
+        const bool model_table = ShardedTableQuartetScoreComputer::prefer_table_shards((uint32_t)n, m, gpus, a.dev.reduce == "rccl", coll_ms, extra_ms);
+        // (--gpus-on-one-device without --mode stays the test hook of the tree-sharded reductions it was written for)
+        const bool table = !need_whole && (a.mode == "table" || (a.mode == "auto" && model_table && !a.dev.gpus_on_one_device));
+        if (a.mode == "table" && need_whole) std::cout << "--mode table: -q / --qic-binary / --save-table / --load-table need the whole table on one device; tree-sharded mode instead.\n";
+        if (table) {
+            std::cout << "Table-sharded counting on " << gpus << " GPUs (" << (a.mode == "table" ? "--mode table" : "auto")
+                      << ": table collective ~" << coll_ms << " ms against ~" << extra_ms << " ms of replicated panel build and imbalance).\n";
+            return run_sharded(referenceTree, a, m, bits, gpus, gpus, lqic, qpic, eqpic);
+        }
     }
     if (a.gpus > 0) return run_multi(referenceTree, a, m, bits, lqic, qpic, eqpic);
     // (without --clean-exit the computer is never destroyed: freeing a 17-34 GB table and the context is work the exiting process

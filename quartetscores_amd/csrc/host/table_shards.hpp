@@ -56,6 +56,21 @@ public:
         return table_bytes <= (uint64_t)(0.85 * (double)freeb) ? 1 : (int)std::ceil((double)table_bytes / room);
     }
 
+    // Tree- or table-sharded on N GPUs when the table fits each of them (bench.py auto_mode holds the same arithmetic; measured basis:
+    // profiles/r06_scaling_model.json). The count work per GPU is equal; the tree-sharded mode adds ONE collective on the table --
+    // priced at the ring bound, reduce-scatter bytes per GPU over one 153 GB/s xGMI link, plus ~1.7 s when RCCL communicators have to
+    // be created first --, the table-sharded mode the replicated panel build (1.6e-9 ms per tree and taxon pair), ~8 % of imbalance
+    // and launch tails, and 1 ms per launch. true = table-sharded is the cheaper one.
+    static bool prefer_table_shards(uint32_t n, size_t m, int gpus, bool rccl, double &coll_ms, double &extra_ms) {
+        const double nq = (double)n * (n - 1) * (n - 2) * (n - 3) / 24.0, npairs = (double)n * (n - 1) / 2.0, G = (double)std::max(gpus, 1);
+        const double bpt = m < 65536 ? 4.0 : 8.0;                     // two-cell wire formats of binary trees holding all taxa
+        coll_ms = nq * bpt * (G - 1.0) / G / 153e9 * 1e3 + (rccl ? 1700.0 : 0.0);
+        const double count_ms = (double)m * nq / 9.4e13 * 1e3 / G, panel_ms = 1.6e-9 * (double)m * npairs;
+        const double groups = std::ceil((double)m / 32.0), slice_groups = std::max(256.0, std::floor(350e6 / (npairs * 16.0)));
+        extra_ms = panel_ms * (G - 1.0) / G + 0.08 * count_ms + std::ceil(groups / slice_groups);
+        return extra_ms < coll_ms;
+    }
+
     // n_gpus devices opt.device .. opt.device + n_gpus - 1; n_shards >= 1 (fewer shards than GPUs leave GPUs idle)
     ShardedTableQuartetScoreComputer(Tree const &refTree, const std::string &evalTreesPath, size_t m, uint32_t count_bits, int n_shards,
                                      Spill spill, DeviceOptions opt, int n_gpus = 1)
@@ -64,22 +79,20 @@ public:
         if (n_shards < 1) throw std::runtime_error("--table-shards needs a positive number");
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device (this program has no CPU fallback)");
-        if (G_ < 1 || opt_.device < 0 || opt_.device + G_ > ndev)
+        // (--gpus-on-one-device, a test hook: the N "GPUs" are N host threads with their own contexts on device opt.device)
+        if (G_ < 1 || opt_.device < 0 || opt_.device + (opt_.gpus_on_one_device ? 1 : G_) > ndev)
             throw std::runtime_error("--gpus " + std::to_string(G_) + " from --device " + std::to_string(opt_.device) + ": " + std::to_string(ndev) + " device(s) visible");
         std::cout << "There are " << m << " evaluation trees.\n";
         std::cout << "The reference tree has " << n << " taxa.\n";
         const auto t0 = std::chrono::steady_clock::now();
-        // shard bounds in the largest id d, balanced by C(d,4); empty shards (small n) are dropped
+        // shard bounds in the largest id d (qs_shard_bounds): one resident shard per GPU -> balanced by the count kernel's work;
+        // more shards than GPUs (a table that passes through the devices shard by shard) -> by the tuples held, C(d,4): memory
+        // decides there. Empty shards (small n) are dropped
         auto c4 = [](uint64_t x) { return x < 4 ? (uint64_t)0 : x * (x - 1) * (x - 2) * (x - 3) / 24; };
         const uint64_t total = c4(n);
-        std::vector<uint32_t> bounds(1, 0);
-        for (int r = 1; r < n_shards; ++r) {
-            const uint64_t target = total / (uint64_t)n_shards * (uint64_t)r;
-            uint32_t d = bounds.back();
-            while (d < n && c4(d) < target) ++d;
-            bounds.push_back(d);
-        }
-        bounds.push_back(n);
+        std::vector<uint32_t> bounds((size_t)n_shards + 1, 0);
+        const uint32_t by = (n_shards > 1 && n_shards <= n_gpus) ? QS_SHARDS_BY_COST : QS_SHARDS_BY_TUPLES;
+        if (qs_shard_bounds(n, (uint32_t)n_shards, by, bounds.data()) != QS_OK) throw std::runtime_error("qs_shard_bounds failed");
         for (size_t k = 0; k + 1 < bounds.size(); ++k)
             if (c4(bounds[k + 1]) > c4(bounds[k])) shards_.push_back({bounds[k], bounds[k + 1]});
         const size_t K = shards_.size();
@@ -120,7 +133,7 @@ public:
         std::vector<int64_t> sums(P * 3, 0), mins(P, INT64_MAX), cand(K * P * QS_SCORE_CAND_SLOTS), extra;
         gpu_.assign((size_t)G_, PerGpu());
         for (int g = 0; g < G_; ++g) {
-            gpu_[g].dev = opt_.device + g;
+            gpu_[g].dev = opt_.gpus_on_one_device ? opt_.device : opt_.device + g;
             for (size_t s = (size_t)g; s < K; s += (size_t)G_) gpu_[g].shards.push_back(s);
             gpu_[g].sums.assign(P * 3, 0); gpu_[g].mins.assign(P, INT64_MAX);
             gpu_[g].spilled.resize(gpu_[g].shards.size());

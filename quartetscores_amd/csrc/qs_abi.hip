@@ -137,6 +137,7 @@ struct qs_ctx {
     uint64_t last_score_log = 0;                 // records the last single-read qs_score logged (0 = two passes were used)
     uint32_t tune_class_min = 1024;              // QS_TUNE_CLASS_MIN_TREES
     uint32_t tune_class_pct = 10;                // QS_TUNE_CLASS_PCT: a depth class below this share of the batch's trees is merged into the next one
+    uint32_t tune_fuse = 1;                      // QS_TUNE_FUSE_CLASSES: classes of equal depth bits share ONE launch of the count kernel (qs_count_fused.hip)
     uint32_t tune_clamp_ppm = 20;                // QS_TUNE_DEPTH_CLAMP: corrections a tree may cost per depth bit it saves, in millionths of C(n,4); 0 = no clamp
     uint32_t tune_score_load = 0;                // QS_TUNE_SCORE_LOAD: 0 = a lane loads its row in 16-byte pieces, 1 = eight lanes load a row's chunk (LDS hand-over)
     uint32_t tune_score_dedupe = 1;              // QS_TUNE_SCORE_DEDUPE: the logging pass skips a quartet that repeats its node pair's last logged triple
@@ -403,6 +404,7 @@ extern "C" int qs_set_tuning(qs_ctx *c, uint32_t key, uint64_t value) {
         }
         case QS_TUNE_CLASS_MIN_TREES: c->tune_class_min = (uint32_t)std::min<uint64_t>(value, 0xFFFFFFFFull); return QS_OK;
         case QS_TUNE_DEPTH_CLAMP: c->tune_clamp_ppm = (uint32_t)std::min<uint64_t>(value, 1000000ull); return QS_OK;
+        case QS_TUNE_FUSE_CLASSES: c->tune_fuse = value ? 1u : 0u; return QS_OK;
         case QS_TUNE_CLASS_PCT: if (value > 100) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_CLASS_PCT takes 0 .. 100"); c->tune_class_pct = (uint32_t)value; return QS_OK;
         case QS_TUNE_SCORE_LOAD:
             if (value > 3) return fail(c, QS_ERR_ARG, "qs_set_tuning: QS_TUNE_SCORE_LOAD takes 0 .. 3");
@@ -985,8 +987,11 @@ struct ClassPlan {
 // a more general mode that is present (binary_full -> binary_partial, general_full or partial; binary_partial, general_full
 // -> partial), then -- depth clamp -- a small deep class goes DOWN where the corrections allow it, else a depth class joins
 // the next deeper one of its mode.
+// fuse (QS_TUNE_FUSE_CLASSES, round 6): classes of equal depth bits (up to kFusedMaxBits) run as segments of ONE launch (qs_count_fused.hip),
+// so what costs a table pass is a depth-bits GROUP over all modes, not a class: no mode joins a dearer mode any more, and "too small
+// for a pass of its own" is asked of the group.
 static void plan_classes(uint32_t n, uint32_t nt, const uint32_t *leaf_off, const uint16_t *adj_depth, const TreeFacts &F, uint32_t class_min,
-                         uint32_t class_pct, uint32_t clamp_ppm, ClassPlan &P) {
+                         uint32_t class_pct, uint32_t clamp_ppm, ClassPlan &P, bool fuse = false) {
     {
         constexpr uint32_t top_bits = 10, deep = 11;   // depth class id = depth bits; `deep` = beyond the bit-sliced instances
         constexpr uint32_t kModes = 4, kBits = 12;
@@ -1012,18 +1017,27 @@ static void plan_classes(uint32_t n, uint32_t nt, const uint32_t *leaf_off, cons
                 return;
             }
         };
-        join_mode(MODE_BINARY_FULL, {MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL});
-        join_mode(MODE_BINARY_PARTIAL, {MODE_PARTIAL});
-        join_mode(MODE_GENERAL_FULL, {MODE_PARTIAL});
+        if (!fuse) {
+            join_mode(MODE_BINARY_FULL, {MODE_BINARY_PARTIAL, MODE_GENERAL_FULL, MODE_PARTIAL});
+            join_mode(MODE_BINARY_PARTIAL, {MODE_PARTIAL});
+            join_mode(MODE_GENERAL_FULL, {MODE_PARTIAL});
+        }
         auto final_mode = [&](uint32_t mo) { while (mode_map[mo] != mo) mo = mode_map[mo]; return mo; };
+        // trees that share the launch of class (mo, bb): the class itself, or -- fused launches -- every class with these depth bits
+        auto size_at = [&](uint32_t mo, uint32_t bb) {
+            if (!fuse || bb > (uint32_t)kFusedMaxBits) return cnt[mo][bb];
+            uint32_t s_ = 0;
+            for (uint32_t m2 = 0; m2 < kModes; ++m2) s_ += cnt[m2][bb];
+            return s_;
+        };
         // a class too small for a pass of its own: its trees go DOWN to a class that is large enough where the 16-fold budget allows
         // it (what is left joins the next deeper class below, as before)
         if (clamp_ppm)
             for (uint32_t t = 0; t < nt; ++t) {
                 const uint32_t mo = final_mode(F.mode[t]), bb = cls[t];
-                if (cnt[mo][bb] >= small || F.hard[t] >= bb) continue;
+                if (size_at(mo, bb) >= small || F.hard[t] >= bb) continue;
                 for (uint32_t lo = bb - 1; lo >= F.hard[t] && lo >= 4; --lo)
-                    if (cnt[mo][lo] >= small) { cnt[mo][bb]--; cnt[mo][lo]++; cls[t] = (uint8_t)lo; break; }
+                    if (size_at(mo, lo) >= small) { cnt[mo][bb]--; cnt[mo][lo]++; cls[t] = (uint8_t)lo; break; }
             }
         // ... and a class that is still small after that costs a launch of its own = one more pass over the table (10-20 ms at
         // 34 GB) plus the waves' fixed cost for a handful of trees: its trees go down at ANY finite price, as long as the sum stays
@@ -1031,16 +1045,16 @@ static void plan_classes(uint32_t n, uint32_t nt, const uint32_t *leaf_off, cons
         if (clamp_ppm)
             for (uint32_t mo = 0; mo < kModes; ++mo)
                 for (uint32_t bb = top_bits; bb > 4; --bb) {
-                    if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                    if (cnt[mo][bb] == 0 || size_at(mo, bb) >= small) continue;
                     // the class below to join: the nearest one that is large enough for a pass of its own, or -- in a batch whose
                     // classes are ALL small -- the nearest non-empty one that is at least as large as this one (joining the larger
                     // neighbour downwards beats the rule below, which would send the larger class up to this one's depth bits)
                     uint32_t lo = bb - 1;
-                    while (lo > 4 && cnt[mo][lo] < small) --lo;
-                    if (cnt[mo][lo] < small) {
+                    while (lo > 4 && size_at(mo, lo) < small) --lo;
+                    if (size_at(mo, lo) < small) {
                         lo = bb - 1;
-                        while (lo > 4 && cnt[mo][lo] == 0) --lo;
-                        if (cnt[mo][lo] == 0 || cnt[mo][lo] < cnt[mo][bb]) continue;   // nothing below that is worth joining
+                        while (lo > 4 && size_at(mo, lo) == 0) --lo;
+                        if (size_at(mo, lo) == 0 || size_at(mo, lo) < size_at(mo, bb)) continue;   // nothing below that is worth joining
                     }
                     uint64_t total = 0;
                     bool finite = true;
@@ -1060,10 +1074,10 @@ static void plan_classes(uint32_t n, uint32_t nt, const uint32_t *leaf_off, cons
         for (uint32_t mo = 0; mo < kModes; ++mo) {
             for (uint32_t bb = 0; bb < kBits; ++bb) remap[mo][bb] = bb;
             for (uint32_t bb = 4; bb < top_bits; ++bb) {
-                if (cnt[mo][bb] == 0 || cnt[mo][bb] >= small) continue;
+                if (cnt[mo][bb] == 0 || size_at(mo, bb) >= small) continue;
                 uint32_t up = bb + 1;
-                while (up <= top_bits && cnt[mo][up] == 0) ++up;
-                if (up > top_bits) continue;               // nothing above it among the bit-sliced classes of this mode
+                while (up <= top_bits && size_at(mo, up) == 0) ++up;
+                if (up > top_bits) continue;               // nothing above it among the bit-sliced classes of this mode (fused: of any mode)
                 cnt[mo][up] += cnt[mo][bb]; mx[mo][up] = std::max(mx[mo][up], mx[mo][bb]); cnt[mo][bb] = 0; remap[mo][bb] = up;
             }
         }
@@ -1118,7 +1132,7 @@ extern "C" int qs_depth_clamp_plan(uint32_t n_taxa, const qs_tree_batch *hb, uin
  * counted in, and its slot in the class-ordered batch. */
 extern "C" int qs_class_plan(uint32_t n_taxa, const qs_tree_batch *hb, uint32_t class_min_trees, uint32_t class_pct, uint32_t clamp_ppm,
                              uint8_t *mode_of_tree, uint8_t *bits_of_tree, uint32_t *slot_of_tree) {
-    if (!hb || !hb->leaf_off || (hb->n_trees && !hb->adj_depth) || n_taxa < 4 || class_pct > 100) return QS_ERR_ARG;
+    if (!hb || !hb->leaf_off || (hb->n_trees && !hb->adj_depth) || n_taxa < 4 || (class_pct & 0xFFu) > 100 || (class_pct & ~(0xFFu | QS_CLASS_PLAN_FUSED))) return QS_ERR_ARG;
     const uint32_t nt = hb->n_trees;
     const uint64_t budget = (uint64_t)((double)binom4(n_taxa) * (double)clamp_ppm * 1e-6);
     TreeFacts F;
@@ -1134,7 +1148,7 @@ extern "C" int qs_class_plan(uint32_t n_taxa, const qs_tree_batch *hb, uint32_t 
         clamp_choice(hb->adj_depth + base, L, depth_class_of(depth), budget, F.soft[t], F.hard[t]);
     }
     ClassPlan P;
-    plan_classes(n_taxa, nt, hb->leaf_off, hb->adj_depth, F, class_min_trees, class_pct, clamp_ppm, P);
+    plan_classes(n_taxa, nt, hb->leaf_off, hb->adj_depth, F, class_min_trees, class_pct & 0xFFu, clamp_ppm, P, (class_pct & QS_CLASS_PLAN_FUSED) != 0);
     for (uint32_t t = 0; t < nt; ++t) {
         if (mode_of_tree) mode_of_tree[t] = P.mode[t];
         if (bits_of_tree) bits_of_tree[t] = P.bits[t];
@@ -1276,7 +1290,8 @@ extern "C" int qs_batch_upload(qs_ctx *c, const qs_tree_batch *hb, qs_device_bat
     {
         TreeFacts F;
         F.depth.swap(tree_depth); F.mode.swap(tree_mode); F.soft.swap(eff_soft); F.hard.swap(eff_hard);
-        plan_classes(n, nt, hb->leaf_off, hb->adj_depth, F, c->tune_class_min, c->tune_class_pct, c->tune_clamp_ppm, plan);
+        plan_classes(n, nt, hb->leaf_off, hb->adj_depth, F, c->tune_class_min, c->tune_class_pct, c->tune_clamp_ppm, plan,
+                     c->tune_fuse && c->tune_gather_impl != QS_IMPL_SWAR);
         tree_depth.swap(F.depth); tree_mode.swap(F.mode);
         d.n_classes = plan.n_classes;
         for (uint32_t k = 0; k < plan.n_classes; ++k) { d.class_mode[k] = plan.class_mode[k]; d.class_bits[k] = plan.class_bits[k]; d.class_end[k] = plan.class_end[k]; d.class_max_depth[k] = plan.class_max_depth[k]; }
@@ -1480,7 +1495,83 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         const int batch_mode = !d.all_full ? MODE_PARTIAL : (d.all_binary ? MODE_BINARY_FULL : MODE_GENERAL_FULL);
         std::string names;
         bool any_coop = false;
+        // ---- fused launches (QS_TUNE_FUSE_CLASSES): the bit-sliced classes that share their depth bits run as segments of ONE launch
+        // of count_bitslice3_fused_kernel -- one pass over the table, one wave prologue / epilogue, whatever the mix of modes ----
+        std::vector<bool> done(n_cls, false);
+        uint32_t fused_launch_groups = 0;
+        if (c->tune_fuse && !all_swar && n_cls > 1) {
+            const uint32_t *order = nullptr;
+            for (uint32_t bb = 4; bb <= (uint32_t)kFusedMaxBits; ++bb) {
+                std::vector<uint32_t> ks;
+                for (uint32_t k = 0; k < n_cls; ++k) if (std::max(d.class_bits[k], 4u) == bb) ks.push_back(k);
+                if (ks.size() < 2) continue;
+                if (!order) { int rc_o = tile_order(c, 0, &order); if (rc_o != QS_OK) return rc_o; }
+                struct Seg { uint32_t k, s_lo, trees, groups, mode, nw; bool part; size_t chunk_bytes; };
+                std::vector<Seg> segs;
+                uint32_t g_total = 0;
+                size_t max_chunk = 0;
+                for (uint32_t k : ks) {
+                    Seg sg;
+                    sg.k = k; sg.s_lo = k ? d.class_end[k - 1] : 0u; sg.trees = d.class_end[k] - sg.s_lo; sg.groups = (sg.trees + 31) / 32;
+                    sg.mode = d.class_mode[k]; sg.part = sg.mode == MODE_PARTIAL || sg.mode == MODE_BINARY_PARTIAL;
+                    sg.nw = bb + (sg.part ? 1u : 0u); sg.chunk_bytes = (size_t)binom2(c->n) * sg.nw * 4;
+                    g_total += sg.groups; max_chunk = std::max(max_chunk, sg.chunk_bytes);
+                    segs.push_back(sg);
+                }
+                const uint32_t per_slice = slice_groups(c, max_chunk, g_total, order != nullptr);
+                const size_t need = (size_t)per_slice * max_chunk + 256 * segs.size();
+                if (need > c->panel_bytes) {
+                    if (c->panel) { QS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->panel); c->panel = nullptr; c->panel_bytes = 0; }
+                    if (hipMalloc(&c->panel, need) != hipSuccess) return fail(c, QS_ERR_OOM, "Insufficient memory! (pair-depth panel)");
+                    c->panel_bytes = need;
+                }
+                CountGeometry g3 = g;
+                g3.total_tiles = c->total_tiles3; g3.dprefix = c->dprefix3; g3.cprefix = c->cprefix3; g3.perm = order;
+                // slices of the concatenated group list [0, g_total): slice [g0, g1) takes from every class the groups that fall into it
+                for (uint32_t g0 = 0; g0 < g_total; g0 += per_slice) {
+                    const uint32_t g1 = std::min(g_total, g0 + per_slice);
+                    const void *seg_panel[4] = {nullptr, nullptr, nullptr, nullptr};
+                    uint32_t seg_groups[4] = {0, 0, 0, 0}, seg_trees[4] = {0, 0, 0, 0}, seg_slot[4] = {0, 0, 0, 0};
+                    size_t off = 0;
+                    uint32_t base = 0;
+                    for (const Seg &sg : segs) {
+                        const uint32_t a = std::max(g0, base), e_ = std::min(g1, base + sg.groups);
+                        base += sg.groups;
+                        if (a >= e_) continue;
+                        const uint32_t ga = a - (base - sg.groups), nch = e_ - a;
+                        const uint32_t t0 = ga * 32, nt = std::min(nch * 32, sg.trees - t0);
+                        DeviceBatch sub = d;
+                        sub.slot0 = sg.s_lo + t0;
+                        sub.n_trees = nt;
+                        void *pp = (char *)c->panel + off;
+                        QS_HIP(c, launch_build_bitpanel(c->stream, sub, c->n, sg.part, pp, nch, sg.nw, c->tune_panel_kernel == 1));
+                        seg_panel[sg.mode] = pp; seg_groups[sg.mode] = nch; seg_trees[sg.mode] = nt; seg_slot[sg.mode] = sub.slot0;
+                        off += ((size_t)nch * sg.chunk_bytes + 255) & ~(size_t)255;
+                    }
+                    if (timed) QS_HIP(c, mark(c, 0));
+                    QS_HIP(c, launch_count_bitslice3_fused(c->stream, g3, seg_panel, seg_groups, seg_trees, (int)bb, c->table, (int)c->count_bits, c->dev_flags, overwrite && first));
+                    first = false;
+                    if (timed) QS_HIP(c, mark(c, 1));
+                    if (d.n_fix) {
+                        bool any_fix = false;
+                        for (int mo = 0; mo < 4; ++mo)
+                            if (seg_groups[mo]) {   // (the rule of the correction depends on the mode: a tied quartet sits in the third cell of a binary tree)
+                                QS_HIP(c, clamp_fix_slots(c, b, seg_slot[mo], seg_slot[mo] + seg_trees[mo], mo, nullptr));
+                                any_fix = true;
+                            }
+                        if (timed && any_fix) QS_HIP(c, mark(c, 2));
+                    }
+                }
+                for (const Seg &sg : segs) {
+                    done[sg.k] = true;
+                    std::string nm = std::string(mode_names[sg.mode]) + ".bitslice_b" + std::to_string(bb) + "x2:" + std::to_string(sg.trees);
+                    names += (names.empty() ? "" : "+") + nm;
+                }
+                ++fused_launch_groups;
+            }
+        }
         for (uint32_t k = 0; k < n_cls; ++k) {
+            if (done[k]) continue;
             const uint32_t s_lo = (all_swar || k == 0) ? 0u : d.class_end[k - 1], s_hi = all_swar ? d.n_trees : d.class_end[k];
             const uint32_t depth_bits = all_swar ? 11u : d.class_bits[k];   // 11 = beyond the bit-sliced instances
             const uint32_t cls_max_depth = all_swar ? d.max_depth : d.class_max_depth[k];
@@ -1548,10 +1639,11 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                                           : "depth_u" + std::to_string(bits);
             if (mixed) nm = std::string(mode_names[mode]) + "." + nm;
             if (n_cls > 1) nm += ":" + std::to_string(s_hi - s_lo);
-            names += (k ? "+" : "") + nm;
+            names += (names.empty() ? "" : "+") + nm;
         }
         const int one_mode = all_swar ? batch_mode : (int)d.class_mode[0];
         c->variant = std::string("gather/") + (mixed ? "mixed" : mode_names[(!all_swar && d.class_bits[0] > top_bits && one_mode == MODE_BINARY_PARTIAL) ? (int)MODE_PARTIAL : one_mode]) + "/" + names + "/count_u" + std::to_string(c->count_bits);
+        if (fused_launch_groups) c->variant += "/fused:" + std::to_string(fused_launch_groups);   // depth-bits groups whose classes shared a launch (count_bitslice3_fused_kernel)
         if (any_coop) c->variant += "/coop4";   // tiles with two a-blocks of binary_full classes: count_bitslice4_kernel
         if (!all_swar && d.n_fix) c->variant += "/clamp:" + std::to_string(d.clamped_trees);   // trees counted below their own depth bits + clamp_fix_kernel
     } else if (algo == QS_ALGO_SCATTER) {

@@ -93,6 +93,12 @@ hipError_t launch_build_bitpanel(hipStream_t s, const DeviceBatch &b, uint32_t n
 hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g, const void *panel, int depth_bits, int mode,
                                   uint32_t n_groups, uint32_t m_trees, void *table, int count_bits, uint32_t *overflow_flag,
                                   bool overwrite, uint32_t *wire); // wire != NULL (binary_full only): one word n0 | n1 << 16 per tuple instead of the table
+// the classes of a mixed batch that share their depth bits in ONE launch (qs_count_fused.hip); seg_* are indexed by CountMode, a mode
+// without trees in this launch has seg_groups = 0
+constexpr int kFusedMaxBits = 7;
+hipError_t launch_count_bitslice3_fused(hipStream_t s, const CountGeometry &g, const void *const seg_panel[4], const uint32_t seg_groups[4],
+                                        const uint32_t seg_trees[4], int depth_bits, void *table, int count_bits, uint32_t *overflow_flag,
+                                        bool overwrite);
 hipError_t launch_clamp_fix(hipStream_t s, const DeviceBatch &b, const FixUnit *units, uint32_t n_units, uint32_t d_lo, uint32_t d_hi,
                             uint64_t rank_lo, void *table, int count_bits, int mode, uint32_t *wire); // corrections of the depth clamp (after the class's count kernel)
 uint32_t bitslice3_tiles_for_c(uint32_t c); // wave tiles per (d-block, c) of count_bitslice3_kernel

@@ -580,3 +580,38 @@ def test_cpp_cli_table_shards_on_gpus_match_the_oracle(tmp_path, ref_kind):
     # more GPUs than the box has: a clean error before any counting
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "z.nwk"), "--gpus", "64", "--table-shards", "64")
     assert p.returncode == 1 and "device(s) visible" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_cli_gpus_mode_tree_and_table_agree_with_the_oracle(tmp_path):
+    """`QuartetScores --gpus 3 --mode tree | table | auto` (the 3 "GPUs" are 3 host threads with their own contexts on
+    the one device of the box: --gpus-on-one-device): the tree-sharded route (trees / 3 per GPU, peer-access reduce-scatter,
+    sharded scoring) and the table-sharded route (all trees per GPU into its cost-balanced shard by largest taxon id, no table
+    collective) write the SAME annotated tree = the oracle's scores; -q needs the whole table on one device, so `--mode table`
+    with -q says so and runs tree-sharded."""
+    import numpy as np
+    from quartetscores_amd import synth
+    n = 37
+    ref_nw = synth.random_tree(n, np.random.default_rng(6100))
+    trees = synth.tree_set(n, 90, 6101) + synth.tree_set(n, 60, 6102, collapse=0.2, dropout=0.1)
+    r, e = tmp_path / "r.nwk", tmp_path / "e.nwk"
+    r.write_text(ref_nw + "\n")
+    e.write_text("\n".join(trees) + "\n")
+    want = oracle_comments(ref_nw, e.read_text())
+    assert len(want) >= 10
+    common = ["--gpus", "3", "--reduce", "p2p", "--gpus-on-one-device"]
+    outs = {}
+    for mode in ("tree", "table"):
+        o = tmp_path / f"{mode}.nwk"
+        p = run("-r", str(r), "-e", str(e), "-o", str(o), *common, "--mode", mode)
+        assert p.returncode == 0, (mode, p.stderr)
+        assert ("no table collective" in p.stdout) == (mode == "table") and ("peer-access reduce-scatter" in p.stdout) == (mode == "tree"), p.stdout
+        assert cli_comments(o) == want, mode
+        outs[mode] = o.read_text()
+    assert outs["tree"] == outs["table"]
+    q = tmp_path / "q.txt"
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "q.nwk"), *common, "--mode", "table", "-q", str(q))
+    assert p.returncode == 0 and "tree-sharded mode instead" in p.stdout and "peer-access all-reduce" in p.stdout, p.stdout
+    assert (tmp_path / "q.nwk").read_text() == outs["tree"] and q.stat().st_size > 0
+    p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "bad.nwk"), "--gpus", "2", "--mode", "sideways")
+    assert p.returncode == 1 and "--mode takes" in p.stderr

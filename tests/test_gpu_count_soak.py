@@ -1,7 +1,8 @@
 """Seeded count soak inside the -m gpu suite: every seed draws a taxon count, a tree count, a mix of tree
 shapes (binary / missing taxa / collapsed edges / both / all four kernel modes interleaved / rooted / deep, not re-centred /
 ladder + NNIs),
-the cell width, the launch plan (depth-clamp budget: off, default, forced so that most trees are cut; class floors; panel slice
+the cell width, the launch plan (depth-clamp budget: off, default, forced so that most trees are cut; class floors; fused launches
+on / off; panel slice
 size: several slices; tile order), a table shard [d_lo, d_hi) and overwrite-vs-accumulate, and compares the WHOLE table (or
 shard) the HIP path produces with the oracle's (QuartetCounterLookup.hpp:196-238 restated in oracle/qs_oracle.c). A second set
 of seeds does the same for the one-word-per-tuple wire format (QS_COUNT_WIRE16X2) with clamped trees. Sized for <= 60 s in all:
@@ -67,6 +68,8 @@ def draw_case(seed, binary_full_only=False):
     sl = int(rng.choice([0, 1 << 12, 1 << 16, 1 << 20]))
     if sl:
         tuning[_lib.QS_TUNE_PANEL_SLICE_BYTES] = sl
+    if rng.random() < 0.3:
+        tuning[_lib.QS_TUNE_FUSE_CLASSES] = 0                 # one launch per class (round 5) instead of one per depth-bits group
     if rng.random() < 0.5:
         tuning[_lib.QS_TUNE_TILE_ORDER] = int(rng.choice([0, 1 | 4 << 16, 2 | 32 << 16, 4 | 16 << 16, 3 | 7 << 16]))
     d_lo, d_hi = 0, n

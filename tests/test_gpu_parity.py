@@ -239,14 +239,19 @@ def test_depth_classes_are_counted_separately(eng, kind):
         assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all(), (kind, algo_split)
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("count_bits", [32, 16])
-def test_mixed_batches_are_counted_mode_by_mode(eng, monkeypatch, count_bits):
+def test_mixed_batches_are_counted_mode_by_mode(eng, monkeypatch, count_bits, fuse):
     """The kernel mode is a property of the TREE, not of the batch: a batch of one third full binary trees,
     one third binary trees with missing taxa and one third trees with collapsed edges (some of those with missing taxa too),
     interleaved, with two deep ladders among them, is counted class by class -- binary_full, binary_partial, general_full,
     partial, each with its own depth classes -- and the table equals the oracle's; with the default class floor (1024
     trees) the small classes join the most general mode present and the table is the same. The reference's loop is
-    shape-independent (QuartetCounterLookup.hpp:65-106, partial trees :214-221)."""
+    shape-independent (QuartetCounterLookup.hpp:65-106, partial trees :214-221).
+    fuse = 1 (QS_TUNE_FUSE_CLASSES, the default since round 6): the four classes that share 4 depth bits run as segments of ONE
+    launch of count_bitslice3_fused_kernel (the two ladders keep a launch of their own at 5 bits), and with the default floors no
+    mode joins a dearer one any more -- the small 4-bit classes go up to the ladders' 5 bits instead and everything is one launch."""
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_FUSE_CLASSES, fuse)
     n = 30
     ref_nw = synth.reference_tree(n, 430)
     ref = flatten.flatten_reference(ref_nw)
@@ -273,6 +278,7 @@ def test_mixed_batches_are_counted_mode_by_mode(eng, monkeypatch, count_bits):
     assert "gather/mixed/" in v, v
     for piece in ("binary_full.bitslice_b4x2:", "binary_full.bitslice_b5x2:2", "binary_partial.bitslice_b4x2:", "general_full.bitslice_b4x2:", "partial.bitslice_b4x2:"):
         assert piece in v, (piece, v)
+    assert ("/fused:1" in v) == bool(fuse), v
     assert (T.astype(np.uint64) == want).all(), v
     # accumulation over two uploads of the same mixed batch, split at an odd place
     ctx2, T2 = gpu_table(eng, ref, batch, count_bits, split=37)
@@ -281,7 +287,11 @@ def test_mixed_batches_are_counted_mode_by_mode(eng, monkeypatch, count_bits):
     monkeypatch.delitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES)
     monkeypatch.delitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT)
     ctx3, T3 = gpu_table(eng, ref, batch, count_bits)
-    assert "gather/partial/" in ctx3.last_count_variant(), ctx3.last_count_variant()
+    v3 = ctx3.last_count_variant()
+    if fuse:   # every tree keeps its own mode; one depth-bits group, one launch
+        assert "gather/mixed/" in v3 and "/fused:1" in v3 and v3.count("bitslice_b") == 4 and "binary_full.bitslice_b" in v3, v3
+    else:
+        assert "gather/partial/" in v3, v3
     assert (T3 == T).all()
     # the byte-SWAR implementation takes the batch as a whole in the mode it needs
     monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
@@ -1775,9 +1785,10 @@ def test_issue_probe_reports_a_plausible_rate(eng):
     ctx.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("case", ["F2", "four_modes"])
 @pytest.mark.parametrize("split_classes", [False, True])
-def test_modes_fixture_on_the_gpu(eng, monkeypatch, case, split_classes):
+def test_modes_fixture_on_the_gpu(eng, monkeypatch, case, split_classes, fuse):
     """The committed fixtures of tests/golden/modes.json (F2 of SURVEY 8(c): taxon dropout + collapsed edges; all four kernel
     modes interleaved in one batch): table hash in canonical taxon order and every internal edge's LQ/QP/EQP-IC as hex doubles --
     with the default class floors (the small classes join the most general mode) and with every mode in a class of its own."""
@@ -1793,12 +1804,16 @@ def test_modes_fixture_on_the_gpu(eng, monkeypatch, case, split_classes):
     spec.loader.exec_module(mod)
     trees = mod.trees_of(fx)
     assert synth.reference_tree(fx["n"], fx["ref_seed"]) == fx["ref"] and trees[0] == fx["first_tree"] and trees[-1] == fx["last_tree"]
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_FUSE_CLASSES, fuse)
     if split_classes:
         monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
         monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
     qsc = eng.QuartetScoreComputer(fx["ref"], trees, device=0)
     v = qsc.quartetCounterLookup.ctx.last_count_variant()
-    assert ("gather/mixed/" in v) == split_classes, v
+    if fuse:     # no mode joins a dearer one: a batch of several modes is "mixed" with any floors, its classes of equal depth bits share a launch
+        assert "bitslice_b" in v and (case != "four_modes" or "/fused:" in v), v
+    else:
+        assert ("gather/mixed/" in v) == split_classes, v
     names = list(qsc.ref.names)
     perm = [names.index(f"t{i}") for i in range(fx["n"])]
     table = remap_table(qsc.quartetCounterLookup.table(), perm).astype("<u4")
@@ -1807,3 +1822,61 @@ def test_modes_fixture_on_the_gpu(eng, monkeypatch, case, split_classes):
     got = {",".join(sorted(k, key=lambda s: int(s[1:]))): [float(x).hex() for x in v_]
            for k, v_ in qsc.scores_by_bipartition().items()}
     assert got == fx["scores_lq_qp_eqp_hex"]
+
+
+@pytest.mark.parametrize("count_bits", [32, 16])
+@pytest.mark.parametrize("n,bits_wanted", [(24, 4), (40, 5), (68, 6), (132, 7)])
+def test_fused_launch_equals_class_by_class_and_the_oracle(eng, monkeypatch, n, bits_wanted, count_bits):
+    """count_bitslice3_fused_kernel (qs_count_fused.hip): the classes of a batch that share their depth bits as segments of ONE
+    launch -- all four kernel modes interleaved, at 4, 5, 6 and 7 depth bits (ladder + NNI trees set the depth), both cell widths,
+    cut into several panel slices (a slice boundary falls inside a class and between classes), on a table shard, accumulated over
+    two uploads and with overwrite: the table equals the class-by-class table of round 5 (QS_TUNE_FUSE_CLASSES = 0) and the
+    oracle's. The reference's loop is shape-independent (QuartetCounterLookup.hpp:65-106,166-188)."""
+    import sys
+    sys.setrecursionlimit(100000)
+    ref_nw = synth.reference_tree(n, 900 + n)
+    ref = flatten.flatten_reference(ref_nw)
+    kws = [dict(), dict(dropout=0.15), dict(collapse=0.2), dict(collapse=0.2, dropout=0.1)]
+    per = 70 if n <= 64 else 12
+    sets = [synth.tree_set(n, per, 910 + n + i, **kw) for i, kw in enumerate(kws)]
+    trees = [sets[i % 4][i // 4] for i in range(4 * per)]
+    parts = [flatten.flatten_eval_trees(trees, ref.name_to_id)]
+    if bits_wanted > 4:   # deep trees of every mode: a caterpillar cut to 2^bits - 2 levels, whole / with a taxon missing / with a collapsed edge
+        depth = (1 << bits_wanted) - 2
+        lad = f"(t{n - 2},t{n - 1})"
+        for i in range(n - 3, n - 3 - (depth - 1), -1):
+            lad = f"(t{i},{lad})"
+        rest = ",".join(f"t{i}" for i in range(0, n - 3 - (depth - 1) + 1))
+        deep_full = f"({rest},{lad});"
+        deep = [deep_full, deep_full.replace("t0,", "", 1), deep_full.replace(f"(t{n - 2},t{n - 1})", f"t{n - 2},t{n - 1}", 1)]
+        trees += deep
+        parts.append(flatten.flatten_eval_trees(deep, ref.name_to_id, recentre=False))
+    batch = parts[0]
+    for p_ in parts[1:]:
+        batch = _concat_batches(batch, p_)
+    want = oracle_counts(ref_nw, trees).counts()
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_MIN_TREES, 1)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_CLASS_PCT, 0)
+    if bits_wanted > 4:
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_DEPTH_CLAMP, 0)          # the deep trees keep their own depth bits
+    tables = {}
+    for fuse in (1, 0):
+        monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_FUSE_CLASSES, fuse)
+        ctx, T = gpu_table(eng, ref, batch, count_bits)
+        v = ctx.last_count_variant()
+        assert ("/fused:" in v) == bool(fuse) and f"bitslice_b{bits_wanted}x2" in v, v
+        tables[fuse] = T
+        assert (T.astype(np.uint64) == want).all(), (fuse, v)
+    # several slices (the panel of a slice holds pieces of up to four classes), accumulate over two uploads, a shard, overwrite
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_FUSE_CLASSES, 1)
+    monkeypatch.setitem(eng.DEFAULT_TUNING, _lib.QS_TUNE_PANEL_SLICE_BYTES, 1 << 12)
+    ctx, T = gpu_table(eng, ref, batch, count_bits, split=batch.n_trees // 2 + 3)
+    assert "/fused:" in ctx.last_count_variant() and (T == tables[1]).all()
+    d_lo, d_hi = n // 3, n - 2
+    c2 = eng.Context(n, count_bits, d_lo=d_lo, d_hi=d_hi)
+    c2.table_alloc()
+    c2.count_trees(flatten.flatten_eval_trees(sets[0][:5], ref.name_to_id))           # overwritten below
+    c2.count_trees(batch, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    assert "/fused:" in c2.last_count_variant() and c2.trees_counted == batch.n_trees
+    assert (c2.table_download().astype(np.uint64) == want[ranks.n_quartets(d_lo): ranks.n_quartets(d_hi)]).all()
+    c2.close()

@@ -536,3 +536,14 @@ def test_class_plan_rules_are_host_only():
     # (4) 30 full binary trees join the mode of 1100 binary trees with missing taxa
     mode, bits = plan(cat(shallow(30, 4503), shallow(1100, 4504, dropout=0.2)))
     assert (mode == 3).all() and (bits == 4).all()
+    # (5) QS_CLASS_PLAN_FUSED (QS_TUNE_FUSE_CLASSES = 1, the default since round 6): classes of equal depth bits share a launch, so no tree
+    # joins a dearer mode any more -- the 30 full trees keep binary_full next to the 1100 incomplete ones -- and a deep tree of one mode
+    # goes down to the depth bits at which OTHER modes have enough trees (the group is asked, not the class)
+    fused = pct_fused = 10 | _lib.QS_CLASS_PLAN_FUSED
+    mode, bits = plan(cat(shallow(30, 4503), shallow(1100, 4504, dropout=0.2)), pct=pct_fused)
+    assert (mode[:30] == 0).all() and (mode[30:] == 3).all() and (bits == 4).all()
+    mode, bits = plan(cat(shallow(1100, 4504, dropout=0.2), deep), pct=fused)
+    assert (mode[:1100] == 3).all() and (mode[1100:] == 0).all() and (bits == 4).all()
+    # four modes, all small: every tree keeps its mode, one depth-bits group
+    mode, bits = plan(cat(shallow(40, 4505), shallow(40, 4506, dropout=0.2), shallow(40, 4507, collapse=0.2), shallow(40, 4508, collapse=0.2, dropout=0.1), deep), pct=fused)
+    assert sorted(set(mode.tolist())) == [0, 1, 2, 3] and len(set(bits.tolist())) == 1
