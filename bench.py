@@ -106,7 +106,11 @@ def parse_args():
     ap.add_argument("--via-launcher", action="store_true",
                     help="go through the spawn path of --gpus N > 1 even at N = 1 (a fresh torch.distributed.run child; this process never touches the GPU)")
     ap.add_argument("--dry-launch", action="store_true", help="print the child command of the spawn path as one JSON line and exit")
+    ap.add_argument("--secondary", type=int, default=-1,
+                    help="after the timed region also measure 3 steps each of 512 taxa x 1500 trees with --collapse 0.2 / --dropout 0.1 / --mixed on the resident "
+                         "table, and configs[1] (config.secondary); -1 = on for the default N = 1 line")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--gen-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -488,7 +492,7 @@ def parse_variant(variant, m):
 # ---------------------------------------------------------------------------------------------------------------
 def kernel_source_sha():
     h = hashlib.sha256()
-    for fn in ("qs_count.hip", "qs_common.hpp"):
+    for fn in ("qs_count.hip", "qs_bitslice3.hpp", "qs_count_fused.hip", "qs_common.hpp"):
         with open(os.path.join(ROOT, "quartetscores_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -510,6 +514,59 @@ def pmc_for(workload_key, variant):
                 ent["file"] = os.path.relpath(path, ROOT)
                 return ent
     return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# secondary workloads of the default line (config.secondary): multifurcating / incomplete / mixed trees come from the numpy
+# generator (11 s per 1500 trees at 512 taxa), so they are generated and flattened in CHILD processes started before anything
+# else -- beside the cpu_baseline leg -- and only loaded when the timed region is over.
+SECONDARY = [
+    {"name": "collapse0.2", "label": "512 taxa x 1500 trees, 20 % of the inner edges collapsed", "kw": {"collapse": 0.2}},
+    {"name": "dropout0.1", "label": "512 taxa x 1500 trees, 10 % of the taxa dropped per tree", "kw": {"dropout": 0.1}},
+    {"name": "mixed", "label": "512 taxa x 1500 trees, a third each full / dropout 0.1 / collapse 0.2", "kw": {"mixed": True}},
+]
+
+
+def gen_child(spec_path):
+    """Generates one secondary workload exactly as `bench.py --taxa n --trees m --collapse/--dropout/--mixed` does (same generator,
+    same seeds) and writes its flattened arrays to spec["out"] (npz)."""
+    import numpy as np
+    from quartetscores_amd import flatten, synth
+    with open(spec_path) as f:
+        spec = json.load(f)
+    n, m, seed, kw = spec["n"], spec["m"], spec["seed"], spec["kw"]
+    ref = flatten.flatten_reference(spec["ref"])
+    if kw.get("mixed"):
+        k3 = m // 3
+        sets = [synth.tree_set(n, m - 2 * k3, seed), synth.tree_set(n, k3, seed + 1, dropout=0.1), synth.tree_set(n, k3, seed + 2, collapse=0.2)]
+        trees = [sets[i % 3][i // 3] if i // 3 < len(sets[i % 3]) else None for i in range(3 * len(sets[0]))]
+        trees = [t_ for t_ in trees if t_ is not None]
+    else:
+        trees = synth.tree_set(n, m, seed, collapse=kw.get("collapse", 0.0), dropout=kw.get("dropout", 0.0))
+    b = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    np.savez(spec["out"], leaf_off=b.leaf_off, leaf_ids=b.leaf_ids, adj_depth=b.adj_depth, n_trees=np.array([b.n_trees]))
+
+
+def start_secondary_generators(ref_nw, n, m, seed):
+    import tempfile
+    d = tempfile.mkdtemp(prefix="qsbench_sec_")
+    jobs = []
+    for w in SECONDARY:
+        sp, out = os.path.join(d, w["name"] + ".json"), os.path.join(d, w["name"] + ".npz")
+        with open(sp, "w") as f:
+            json.dump({"ref": ref_nw, "n": n, "m": m, "seed": seed, "kw": w["kw"], "out": out}, f)
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gen-child", sp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        jobs.append((w, p, sp, out))
+    return d, jobs
+
+
+def valu_frac(variant, m, units, count_ms):
+    """(roofline.frac, minimal instructions per (quartet, 32 trees)) of a count step: algorithmic lane-ops of the classes that ran /
+    the step's count-kernel time / the VALU peak; (None, None) for variants the issue model does not price (byte-SWAR, scatter)."""
+    _mode, _classes, ops32 = parse_variant(variant, m)
+    if not ops32 or not count_ms:
+        return None, None
+    return units * ops32 / 32.0 / (count_ms * 1e-3) / 1e12 / VALU_PEAK_TLOPS, ops32
 
 
 XGMI_LINK_GBS = 153.0            # MI355X_MICROARCH.md: per xGMI link and direction, 7 links per GPU
@@ -655,6 +712,8 @@ def main():
     args = parse_args()
     if args.cpu_child:
         return cpu_child(args.cpu_child)
+    if args.gen_child:
+        return gen_child(args.gen_child)
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.via_launcher or args.dry_launch):
         sys.exit(launch(args, sys.argv[1:]))     # parent only: BEFORE torch is imported, never after a GPU call
     import numpy as np
@@ -751,6 +810,13 @@ def main():
         sample_text = "\n".join(trees).encode()
     assert batch.n_trees == m
     gen_s = time.perf_counter() - t_gen
+
+    # the secondary workloads' trees: generated beside the cpu_baseline leg, loaded after the timed region
+    want_secondary = args.secondary == 1 or (args.secondary < 0 and world == 1 and not custom and cfg_no == 2 and binary_full_trees
+                                             and args.algo == "gather" and shards == 1 and not args.nni and not multi)
+    sec_dir, sec_jobs = (None, [])
+    if want_secondary and rank == 0:
+        sec_dir, sec_jobs = start_secondary_generators(ref_nw, n, 1500, seed_set)
 
     # cpu_baseline leg first, in a child process, BEFORE this process touches the GPU (N = 1 only)
     cpu_baseline = None
@@ -1184,6 +1250,73 @@ def main():
         step()                           # the gates / scoring below read the table of a plain step
         ctx.sync()
 
+    # ---- secondary workloads on the resident table (config.secondary): multifurcating / incomplete / mixed gene-tree batches at the
+    # taxon count of the default line, and configs[1]; 1 warm + 3 timed steps each, kernels bracketed by the library's own events ----
+    secondary = None
+    if want_secondary and rank == 0:
+        secondary = []
+
+        def measure(ctx_, hb_, m_, label, k_steps=3):
+            ctx_.count_batch(hb_, step_algo)
+            ctx_.sync()
+            torch.cuda.synchronize(dev)
+            c0_ = time.perf_counter()
+            for i_ in range(k_steps):
+                ctx_.count_batch(hb_, step_algo | (engine.QS_COUNT_TIMED if i_ == k_steps - 1 else 0))
+            ctx_.sync()
+            torch.cuda.synchronize(dev)
+            ms_ = (time.perf_counter() - c0_) * 1e3 / k_steps
+            _p, cnt_ms, _t = ctx_.last_count_ms()
+            v_ = ctx_.last_count_variant()
+            nq_ = ranks.n_quartets(ctx_.n)
+            # frac: the same definition as roofline.frac (count kernels incl. corrections of the last step, event-timed); for steps below
+            # a millisecond the wall-clock mean over the steps stands in for one event sample
+            fr, ops_ = valu_frac(v_, m_, m_ * nq_, cnt_ms if ms_ >= 5 else ms_)
+            return {"workload": label[:100], "algo": v_[:100], "value": m_ * nq_ / (ms_ * 1e-3), "ms_per_step": round(ms_, 4), "steps": k_steps,
+                    "count_kernels_ms_last_step": round(cnt_ms, 4), "launches": ctx_.last_count_launches(),
+                    "frac": round(fr, 4) if fr else None, "ops_per_unit32": ops_}
+        for w, p_, sp_, out_ in sec_jobs:
+            try:
+                _o, err_ = p_.communicate(timeout=600)
+                if p_.returncode != 0:
+                    raise RuntimeError(err_[-200:])
+                z = np.load(out_)
+                empty = np.zeros(0, dtype=np.uint32)
+                mt = int(z["n_trees"][0])
+                b_ = flatten.TreeBatch(mt, z["leaf_off"], z["leaf_ids"], z["adj_depth"], np.zeros(mt + 1, dtype=np.uint32), np.zeros(1, dtype=np.uint32), empty.astype(np.uint16))
+                hb_ = ctx.batch_upload(b_, with_nodes=False)
+                secondary.append(measure(ctx, hb_, mt, w["label"]))
+                ctx.batch_free(hb_)
+            except Exception as e:           # reported, never required for the metric
+                secondary.append({"workload": w["label"][:100], "error": str(e)[:100]})
+            finally:
+                for q in (sp_, out_):
+                    try:
+                        os.remove(q)
+                    except OSError:
+                        pass
+        try:
+            os.rmdir(sec_dir)
+        except OSError:
+            pass
+        try:                                 # configs[1]: its own 128 MB table
+            c1 = CONFIGS[1]
+            ref1 = native_ingest.synth_trees(c1["taxa"], 1, 1000).decode().strip()
+            text1 = native_ingest.synth_trees(c1["taxa"], c1["trees"], 1001)
+            b1, _ = native_ingest.ingest_text(ref1, text1, 0, c1["trees"], want_ranges=False)
+            ctx1 = engine.Context(c1["taxa"], c1["bits"], device=local_rank, stream=stream.cuda_stream)
+            ctx1.table_alloc()
+            hb1 = ctx1.batch_upload(b1, with_nodes=False)
+            for _ in range(300):             # clock ramp: a 0.17 ms step from idle measures the ramp, not the kernel
+                ctx1.count_batch(hb1, step_algo)
+            secondary.append(measure(ctx1, hb1, c1["trees"], "configs[1]: 128 taxa x 1000 trees, u32 table, seeds 1000/1001", k_steps=500))
+            ctx1.batch_free(hb1)
+            ctx1.close()
+        except Exception as e:
+            secondary.append({"workload": "configs[1]", "error": str(e)[:100]})
+        step()                               # the resident table holds the default workload's counts again
+        ctx.sync()
+
     # how fast THIS device runs the count kernel's bare instruction slot (qs_issue_probe: 24 v_bitop3 + 4 v_bcnt in registers, 4
     # waves per SIMD): boxes of one pool differ by several per cent; the figure makes lines from different boxes comparable
     box_probe_ns = None
@@ -1250,6 +1383,7 @@ def main():
             "baseline_config": (f"BASELINE.json configs[{cfg_no}] (bench.py --config {cfg_no})" if not custom else "custom (not a BASELINE config)"),
             "mode": par_mode, "mode_decided_by": mode_why, "mode_model": mode_est, "shard_balance": balance if shards > 1 else None,
             "other_mode_leg": other_leg,
+            "secondary": secondary,
             "one_rank_same_workload": same_workload_scaling(value, world, m * nq_all, count_only_ms, elapsed / steps * 1e3) if count_only_ms else None,
             "quartets": nq_all,
             "quartets_this_rank": nq,
@@ -1306,7 +1440,7 @@ def main():
             if cli_e2e.get("counting_phase_ms"):
                 e2e["cli_counting_quartets_per_s"] = m * nq_all / (cli_e2e["counting_phase_ms"] * 1e-3)
         out["e2e"] = e2e
-    kname = ("count_bitslice3_kernel" if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel"
+    kname = (("count_bitslice3_fused_kernel" if "/fused:" in variant else "count_bitslice3_kernel") if "bitslice" in variant else "count_gather_kernel") if args.algo == "gather" else "count_scatter_kernel"
     hbm_ratio = (units_per_launch * bytes_per_unit) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     table_bytes = ctx.table_bytes
     panel_bytes = ((m + 31) // 32) * (n * (n - 1) // 2) * (max(depth_bits or 4, 4) * 4) if depth_bits else None
@@ -1340,6 +1474,15 @@ def main():
                               "frac_of_2_cycle_issue": 2.0 * per_simd / (launch_ms * 1e-3 * 2.4e9),
                               "minimal_share": units_per_launch * ops32 / 32.0 / 64.0 / pmc["valu_insts_per_launch"] if ops32 else None}
         roof["pmc_source"] = {k_: pmc.get(k_) for k_ in ("file", "collected", "kernel_source_sha", "fetch_size_kb", "write_size_kb", "l2_hit")}
+        if roof["traffic"]:
+            # the axis BASELINE.json north_star names: achieved HBM GB/s of the dominant kernel against the 8 TB/s roofline. traffic = the
+            # PMC bytes of one launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/<pmc file>) / THIS run's event-timed launch duration;
+            # over_model = traffic / the bytes the gather formulation has to move (table once, panel written + read once)
+            gbps = roof["traffic"] / (launch_ms * 1e-3) / 1e9
+            model_b = roof.get("hbm_model_bytes_per_step")
+            roof["hbm"] = {"achieved_gbps": round(gbps, 1), "frac_of_8tbps": round(gbps / HBM_PEAK_GBS, 4),
+                           "over_model": round(roof["traffic"] * launches / model_b, 2) if model_b else None,
+                           "note": "fabric traffic of the count kernel (PMC, builder-collected, same kernel source); the kernel is VALU-bound"}
     else:
         roof["pmc_source"] = f"none under profiles/ for kernel source {kernel_source_sha()}"
     out["roofline"] = roof

@@ -149,3 +149,37 @@ def test_auto_mode_follows_the_one_gpu_scaling_model():
                 better = "table" if tab["max_ms"] < tree["count_max_ms"] + tree["collective_model"]["ring_ms"] else "tree"
                 got, _ = bench.auto_mode(entry["taxa"], entry["trees"], int(n_ranks))
                 assert got == better, (cfg_no, n_ranks, got, tab["max_ms"], tree["count_max_ms"], tree["collective_model"]["ring_ms"])
+
+
+def test_secondary_workload_children_and_the_fraction_helper(tmp_path):
+    """config.secondary of the default line: the generator children write exactly the batch `bench.py --taxa n --trees m --collapse /
+    --dropout / --mixed` would count (same generator, same seeds), and valu_frac prices a step like roofline.frac does."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from quartetscores_amd import flatten, synth
+    n, m, seed = 16, 9, 2001
+    ref_nw = synth.reference_tree(n, 2000)
+    d, jobs = bench.start_secondary_generators(ref_nw, n, m, seed)
+    ref = flatten.flatten_reference(ref_nw)
+    assert [w["name"] for w, *_ in jobs] == ["collapse0.2", "dropout0.1", "mixed"]
+    for w, p, sp, out in jobs:
+        _o, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err
+        z = np.load(out)
+        if w["name"] == "mixed":
+            sets = [synth.tree_set(n, 3, seed), synth.tree_set(n, 3, seed + 1, dropout=0.1), synth.tree_set(n, 3, seed + 2, collapse=0.2)]
+            trees = [sets[i % 3][i // 3] for i in range(9)]
+        else:
+            trees = synth.tree_set(n, m, seed, **w["kw"])
+        want = flatten.flatten_eval_trees(trees, ref.name_to_id)
+        assert int(z["n_trees"][0]) == want.n_trees == m
+        assert (z["leaf_off"] == want.leaf_off).all() and (z["leaf_ids"] == want.leaf_ids).all() and (z["adj_depth"] == want.adj_depth).all()
+        assert len(w["label"]) <= 100
+    # 1500 trees x C(512,4) quartets in 60 ms of general_full at 4 bits: 18 instructions per (quartet, 32 trees)
+    units = 1500 * 2829877120
+    frac, ops = bench.valu_frac("gather/general_full/bitslice_b4x2/count_u32/clamp:150", 1500, units, 60.0)
+    assert ops == 18 and abs(frac - units * 18 / 32 / 0.060 / 1e12 / bench.VALU_PEAK_TLOPS) < 1e-12
+    frac, ops = bench.valu_frac("gather/mixed/binary_partial.bitslice_b4x2:1000+general_full.bitslice_b4x2:500/count_u32/fused:1", 1500, units, 60.0)
+    assert abs(ops - (15 * 1000 + 18 * 500) / 1500) < 1e-12 and frac > 0
+    assert bench.valu_frac("gather/partial/depth_u8/count_u32", 10, 10, 1.0) == (None, None)

@@ -51,7 +51,7 @@ except (OSError, ValueError):
     pass
 if bench:
     h = hashlib.sha256()
-    for fn in ("qs_count.hip", "qs_common.hpp"):
+    for fn in ("qs_count.hip", "qs_bitslice3.hpp", "qs_count_fused.hip", "qs_common.hpp"):   # = bench.py kernel_source_sha
         with open(os.path.join(root, "quartetscores_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     kname = bench["roofline"]["kernel"]
