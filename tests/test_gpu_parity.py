@@ -236,7 +236,9 @@ def test_depth_classes_are_counted_separately(eng, kind):
         ctx, T = gpu_table(eng, ref, batch, 32, split=algo_split)
         if algo_split is None:
             v = ctx.last_count_variant()
-            assert "bitslice_b4" in v and ":1100+" in v and "bitslice_b6" in v and v.count(":40") == 1, v
+            # (round 6: the ladders keep the binary_full step whatever the shallow trees need -- no tree joins a dearer mode -- and
+            # the handful of complete trees among the incomplete ones does too)
+            assert "bitslice_b4" in v and "bitslice_b6x2:40" in v and v.count(":40") == 1 and (kind != "binary_full" or ":1100+" in v), v
         assert (T.astype(np.uint64) == oracle_counts(ref_nw, trees).counts()).all(), (kind, algo_split)
 
 

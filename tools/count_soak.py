@@ -50,6 +50,7 @@ for case in range(cases):
                                           _lib.QS_TUNE_TILE_ORDER: int(rng.choice([0, 1 | 4 << 16, 2 | 32 << 16, 4 | 16 << 16, 3 | 7 << 16])),
                                           _lib.QS_TUNE_CLASS_PCT: int(rng.choice([0, 10, 60, 100])),
                                           _lib.QS_TUNE_DEPTH_CLAMP: int(rng.choice([0, 20, 5000, 1000000])),
+                                          _lib.QS_TUNE_FUSE_CLASSES: int(rng.choice([0, 1])),      # round 6: one launch per class / per depth-bits group
                                           _lib.QS_TUNE_CLASS_MIN_TREES: int(rng.choice([1, 8, 64, 1024]))}),
                          # round 5: every tree in the lowest class any budget allows -- the correction kernel on every shape
                          ("clamp", {_lib.QS_TUNE_DEPTH_CLAMP: 1000000, _lib.QS_TUNE_CLASS_MIN_TREES: int(rng.choice([1, 1024])),
