@@ -179,6 +179,12 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
     return p;
 }
 
+#ifndef QS_PROBE_ROWS
+#define QS_PROBE_ROWS kDB
+#endif
+#ifndef QS_PROBE_GEN_WAVES
+#define QS_PROBE_GEN_WAVES 0   /* probe builds: waves per SIMD of the general / partial instances up to QS_GEN3_MAXB bits */
+#endif
 #ifndef QS_BS3_WAVES
 #define QS_BS3_WAVES 4
 #endif
@@ -232,6 +238,7 @@ template <typename CT> __device__ __forceinline__ void store_tuple(CT *p, uint32
 // (8 and 9 bits in the binary / general modes: 3 waves -- <= 168 VGPRs and 42-46 KB of LDS per workgroup.)
 template <int B, int MODE> constexpr int bs3_waves() {
     constexpr bool gen = MODE == MODE_GENERAL_FULL || MODE == MODE_PARTIAL;
+    if (gen && QS_PROBE_GEN_WAVES && B <= (MODE == MODE_PARTIAL ? QS_GEN3_MAXB - 1 : QS_GEN3_MAXB)) return QS_PROBE_GEN_WAVES;
     if (gen) return B <= (MODE == MODE_PARTIAL ? QS_GEN3_MAXB - 1 : QS_GEN3_MAXB) ? 3 : 2;   // two a-columns + three counters per quartet: 172-192 VGPRs unconstrained (B <= 6)
     if (B >= 10 || (B >= 7 && MODE == MODE_BINARY_PARTIAL)) return 2;
     if (MODE == MODE_BINARY_PARTIAL) return (B <= 4 && QS_BP4_WAVES) ? 4 : 3;
@@ -484,7 +491,7 @@ __device__ __forceinline__ void bs3_segment(const Bs3Tile &t, const uint4 *__res
         Planes nRb = L1, nRa = L1, nRa2 = L1;
         if (PFR) { nRb = lload(cur, colB); nRa = lload(cur, colA1); nRa2 = lload(cur, colA2); }
 #pragma unroll
-        for (int j = 0; j < kDB; ++j) {
+        for (int j = 0; j < QS_PROBE_ROWS; ++j) {   // (QS_PROBE_ROWS < 8: timing probe of a narrower d-block, profiles/r06_experiments.md 4 -- NOT a product build)
             if (FULL || ((uint32_t)j >= jlo && (uint32_t)j < jhi)) { // wave-uniform
                 const Planes pRb = nRb, pRa = nRa, pRa2 = nRa2;
                 if (PFR && j + 1 < kDB) {

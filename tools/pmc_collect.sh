@@ -11,7 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-score --no-impl-check --no-e2e --prewarm-ms 0 ${PMC_STEPS:---steps 4 --warmup 1} $*"
+ARGS="--no-cpu-baseline --no-score --no-impl-check --no-e2e --secondary 0 --prewarm-ms 0 ${PMC_STEPS:---steps 4 --warmup 1} $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES" \
