@@ -108,7 +108,7 @@ def parse_args():
     ap.add_argument("--dry-launch", action="store_true", help="print the child command of the spawn path as one JSON line and exit")
     ap.add_argument("--secondary", type=int, default=-1,
                     help="after the timed region also measure 3 steps each of 512 taxa x 1500 trees with --collapse 0.2 / --dropout 0.1 / --mixed on the resident "
-                         "table, and configs[1] (config.secondary); -1 = on for the default N = 1 line")
+                         "table, and configs[1], one rank's share of configs[3], one shard of configs[4] (config.secondary); -1 = on for the default N = 1 line")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--gen-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -1255,7 +1255,7 @@ def main():
     if want_secondary and rank == 0:
         secondary = []
 
-        def measure(ctx_, hb_, m_, label, k_steps=3):
+        def measure(ctx_, hb_, m_, label, k_steps=3, nq_=None):
             ctx_.count_batch(hb_, step_algo)
             ctx_.sync()
             torch.cuda.synchronize(dev)
@@ -1267,7 +1267,7 @@ def main():
             ms_ = (time.perf_counter() - c0_) * 1e3 / k_steps
             _p, cnt_ms, _t = ctx_.last_count_ms()
             v_ = ctx_.last_count_variant()
-            nq_ = ranks.n_quartets(ctx_.n)
+            nq_ = nq_ or ranks.n_quartets(ctx_.n)     # (a table shard: the quartets it owns)
             # frac: the same definition as roofline.frac (count kernels incl. corrections of the last step, event-timed); for steps below
             # a millisecond the wall-clock mean over the steps stands in for one event sample
             fr, ops_ = valu_frac(v_, m_, m_ * nq_, cnt_ms if ms_ >= 5 else ms_)
@@ -1313,6 +1313,37 @@ def main():
             ctx1.close()
         except Exception as e:
             secondary.append({"workload": "configs[1]", "error": str(e)[:100]})
+        try:                                 # configs[3]: one GPU's share of 8 (12 500 of the 100 000 trees into the full 2.1 GB table)
+            c3 = CONFIGS[3]
+            ref3 = native_ingest.synth_trees(c3["taxa"], 1, 3000).decode().strip()
+            text3 = native_ingest.synth_trees(c3["taxa"], c3["trees"] // 8, 3001)
+            b3, _ = native_ingest.ingest_text(ref3, text3, 0, c3["trees"] // 8, want_ranges=False)
+            ctx3 = engine.Context(c3["taxa"], c3["bits"], device=local_rank, stream=stream.cuda_stream)
+            ctx3.table_alloc()
+            hb3 = ctx3.batch_upload(b3, with_nodes=False)
+            secondary.append(measure(ctx3, hb3, c3["trees"] // 8, "configs[3]: one rank's share of 8: 256 taxa x 12500 of the 100000 trees, u32 table, seeds 3000/3001", k_steps=10))
+            ctx3.batch_free(hb3)
+            ctx3.close()
+            del b3, text3
+        except Exception as e:
+            secondary.append({"workload": "configs[3] share", "error": str(e)[:100]})
+        try:                                 # configs[4]: one of its 8 table shards (34 GB of u16 cells), all 5000 trees
+            c4 = CONFIGS[4]
+            lo4, hi4 = distributed.shard_of_largest_id(c4["taxa"], c4["shards"], 0, by="c4")
+            if torch.cuda.mem_get_info(dev)[0] > (ranks.n_quartets(hi4) - ranks.n_quartets(lo4)) * 6 + (8 << 30):
+                ref4 = native_ingest.synth_trees(c4["taxa"], 1, 4000).decode().strip()
+                text4 = native_ingest.synth_trees(c4["taxa"], c4["trees"], 4001)
+                b4, _ = native_ingest.ingest_text(ref4, text4, 0, c4["trees"], want_ranges=False)
+                ctx4 = engine.Context(c4["taxa"], c4["bits"], device=local_rank, stream=stream.cuda_stream, d_lo=lo4, d_hi=hi4)
+                ctx4.table_alloc()
+                hb4 = ctx4.batch_upload(b4, with_nodes=False)
+                secondary.append(measure(ctx4, hb4, c4["trees"], f"configs[4]: shard d[{lo4},{hi4}) of 8: 1024 taxa x 5000 trees, u16 table, seeds 4000/4001", k_steps=3,
+                                         nq_=ranks.n_quartets(hi4) - ranks.n_quartets(lo4)))
+                ctx4.batch_free(hb4)
+                ctx4.close()
+                del b4, text4
+        except Exception as e:
+            secondary.append({"workload": "configs[4] shard", "error": str(e)[:100]})
         step()                               # the resident table holds the default workload's counts again
         ctx.sync()
 
