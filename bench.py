@@ -53,6 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+BACKEND = os.environ.get("QS_BENCH_BACKEND", "nccl")   # "gloo": several ranks share one GPU, collectives staged through the host (tests only)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 T lane-ops/s: one wave64 VALU op per 2 cycles per SIMD-32
 
@@ -172,7 +173,7 @@ def launch(args, argv):
         print(json.dumps({"launch": cmd, "n_ranks": args.gpus, "visible_gpus": visible_gpus()}))
         return 0
     have = visible_gpus()
-    if have < args.gpus:
+    if have < args.gpus and not (BACKEND == "gloo" and have >= 1):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, {have} visible "
                          "(no CPU fallback in quartetscores_amd); nothing was launched\n")
         return 2
@@ -598,6 +599,7 @@ def run_mode_leg(mode, world, rank, local_rank, n, count_bits, batch_all, m_tota
     Binary trees holding all taxa only. Every rank calls it; the result is the same on every rank (max over ranks)."""
     import torch
     import torch.distributed as dist
+    from quartetscores_amd import collectives as coll
     from quartetscores_amd import distributed, engine, ranks
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream(dev)
@@ -649,7 +651,7 @@ def run_mode_leg(mode, world, rank, local_rank, n, count_bits, batch_all, m_tota
                 ctx.table_attach(wire[k])
                 ctx.count_batch(hb, algo)
             if use_dist and world > 1:
-                pending[k] = dist.reduce_scatter_tensor(recv[k], wire[k][:send_words], op=dist.ReduceOp.SUM, async_op=True)
+                pending[k] = coll.reduce_scatter_tensor(recv[k], wire[k][:send_words], op=dist.ReduceOp.SUM, async_op=True)
             else:
                 recv[k].copy_(wire[k][:chunk_words])
 
@@ -674,7 +676,7 @@ def run_mode_leg(mode, world, rank, local_rank, n, count_bits, batch_all, m_tota
     elapsed = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # gate: every tuple this rank holds after the step sums to the number of trees (binary trees, all taxa)
     if mode == "table":
@@ -695,7 +697,7 @@ def run_mode_leg(mode, world, rank, local_rank, n, count_bits, batch_all, m_tota
             ok_local = bool((cells.view(k_, 3).sum(dim=1) == m_total).all().item()) if k_ else True
     if use_dist:
         ok = torch.tensor([int(ok_local)], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        coll.all_reduce(ok, op=dist.ReduceOp.MIN)
         ok_local = bool(ok.item())
     info.update({"steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": m_total * nq_all * steps / elapsed,
                  "parity_tuple_sums_ok": ok_local, "algo": ctx.last_count_variant()[:100]})
@@ -722,6 +724,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if BACKEND == "gloo":                # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: the ranks share the devices
+        local_rank %= max(1, torch.cuda.device_count())
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if torch.cuda.device_count() <= local_rank:   # (counting devices does not initialise the GPU)
@@ -730,6 +734,7 @@ def main():
     use_dist = "WORLD_SIZE" in os.environ or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
 
     from quartetscores_amd import _lib, distributed, engine, flatten, native_ingest, ranks, synth
+    from quartetscores_amd import collectives as coll
 
     # ---- workload -----------------------------------------------------------------------------------------
     cfg_no = args.config or 2        # the config the metric is quoted on, at every N (a driver curve is ONE workload)
@@ -853,11 +858,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         c0_ = time.perf_counter()
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if BACKEND == "gloo":          # rehearsal: the ranks share one GPU (collectives.py)
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
         # proof that RCCL's communicator spans the ranks the line claims: an all-reduce of ones must give the world size
         # on every rank (the first collective also completes the lazy parts of the communicator set-up)
         ones = torch.ones(1, dtype=torch.int32, device=dev)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        coll.all_reduce(ones, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
         comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "proof": int(ones.item()),
                 "proof_ok": int(ones.item()) == world == dist.get_world_size(),
@@ -967,9 +975,9 @@ def main():
             if not exchange:
                 pass
             elif reduce_mode == "scatter":
-                pending[i] = dist.reduce_scatter_tensor(recv[i], src[:send_words], op=dist.ReduceOp.SUM, async_op=True)
+                pending[i] = coll.reduce_scatter_tensor(recv[i], src[:send_words], op=dist.ReduceOp.SUM, async_op=True)
             else:
-                pending[i] = dist.all_reduce(src, op=dist.ReduceOp.SUM, async_op=True)
+                pending[i] = coll.all_reduce(src, op=dist.ReduceOp.SUM, async_op=True)
         last_buf[0] = i
 
     def drain():
@@ -996,7 +1004,7 @@ def main():
     one_ms = max((time.perf_counter() - t_pre) * 1e3, 1e-3)
     if use_dist:
         tt = torch.tensor([one_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         one_ms = float(tt.item())
     steps = args.steps or int(min(500, max(5, 6000.0 / one_ms)))
     warmup = args.warmup if args.warmup >= 0 else (2 if one_ms >= 100 else 20)
@@ -1030,7 +1038,7 @@ def main():
     last_events = ctx.last_count_events() if steps > 0 else []
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     drain()
@@ -1043,9 +1051,9 @@ def main():
         reps = 3
         for _ in range(reps):
             if reduce_mode == "scatter":
-                dist.reduce_scatter_tensor(recv[last_buf[0]], src[:send_words], op=dist.ReduceOp.SUM)
+                coll.reduce_scatter_tensor(recv[last_buf[0]], src[:send_words], op=dist.ReduceOp.SUM)
             else:
-                dist.all_reduce(src, op=dist.ReduceOp.SUM)
+                coll.all_reduce(src, op=dist.ReduceOp.SUM)
         fence()
         coll_alone_ms = (time.perf_counter() - c0) * 1e3 / reps
         step()                              # restore a freshly counted + reduced buffer for the gates below
@@ -1068,7 +1076,7 @@ def main():
         count_only_ms = (time.perf_counter() - c0) * 1e3 / k_co
         if use_dist:
             tt = torch.tensor([count_only_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            coll.all_reduce(tt, op=dist.ReduceOp.MAX)
             count_only_ms = float(tt.item())
         step()                              # a freshly counted + reduced buffer for the gates below
         drain()
@@ -1106,7 +1114,7 @@ def main():
             ok_local = None
         if ok_local is not None:
             ok = torch.tensor([int(ok_local)], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank's shard must pass
+            coll.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank's shard must pass
             reduced_ok = bool(ok.item())
     if len(tables) > 1:                  # measurements below run on one table without collectives
         ctx.table_attach(table)

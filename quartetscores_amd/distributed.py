@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import Callable, Tuple
 
+from . import collectives as coll
+
 
 def shard_range(m: int, world: int, rank: int) -> Tuple[int, int]:
     """Trees [lo, hi) of rank `rank`: contiguous, sizes differ by at most one, covers [0, m)."""
@@ -58,7 +60,7 @@ def reduce_scatter_table(send, recv, group=None, async_op=False):
     tree-sharded mode -- and the LQ/QP/EQP reduction works on shards anyway (score_sharded with a view)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        return dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return coll.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     recv.copy_(send[: recv.numel()])
     return None
 
@@ -101,7 +103,7 @@ def all_reduce_table(table, group=None):
     """In-place sum of the count table over all ranks (RCCL on GPU tensors, gloo on CPU tensors)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+        coll.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     return table
 
 
@@ -204,7 +206,7 @@ def reduce_scatter_counts(ref, local_batch, total_trees: int, algo: int = 0, dev
             ok = 1 if (hb is None or (ctx.batch_flags(hb) & both) == both) and algo != engine.QS_ALGO_SCATTER else 0
             if multi and world > 1:
                 flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                coll.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 ok = int(flag.item())
             if total_trees >= (1 << 16):
                 wire = "u32x2" if ok else "u32"     # binary full trees: two cells (n0, n1) instead of three
@@ -274,13 +276,13 @@ def score_sharded(ctx, ref, flags: int = 0, group=None, device=None):
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     ctx.score_pass1(ref, sums, mins)
     if multi:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
+        coll.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        coll.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
     ctx.score_pass2(ref, mins, cand)
     extra = ctx.score_overflow(ref, mins, cand)     # (k, 4) near-minimal quartets of overflowed node pairs; k = 0 almost always
     if multi:
         parts = [torch.empty_like(cand) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(parts, cand, group=group)
+        coll.all_gather(parts, cand, group=group)
         cand_host = np.stack([p.cpu().numpy() for p in parts])
         lists = [None] * dist.get_world_size(group)
         dist.all_gather_object(lists, extra, group=group)
@@ -316,7 +318,7 @@ def score_table_shards(open_shard: Callable, my_shards, ref, flags: int = 0, gro
     per_rank = len(my_shards)
     if multi:   # ranks may own different numbers of shards: pad the gathers to the maximum
         cnt = torch.tensor([per_rank], dtype=torch.int64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=group)
+        coll.all_reduce(cnt, op=dist.ReduceOp.MAX, group=group)
         per_rank = int(cnt.item())
     P = None
     kept = None
@@ -347,8 +349,8 @@ def score_table_shards(open_shard: Callable, my_shards, ref, flags: int = 0, gro
         sums = torch.zeros(3 * P, dtype=torch.int64, device=dev)
         mins = torch.full((P,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
     if multi:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
+        coll.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        coll.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
     slots = _lib.QS_SCORE_CAND_SLOTS
     cand_all = torch.full((max(per_rank, 1), slots * P), -1, dtype=torch.int64, device=dev)   # -1 = empty slot
     extras = []
@@ -365,7 +367,7 @@ def score_table_shards(open_shard: Callable, my_shards, ref, flags: int = 0, gro
     extra = np.concatenate(extras) if extras else np.zeros((0, 4), dtype=np.int64)
     if multi:
         parts = [torch.empty_like(cand_all) for _ in range(world)]
-        dist.all_gather(parts, cand_all, group=group)
+        coll.all_gather(parts, cand_all, group=group)
         cand_host = np.concatenate([p_.cpu().numpy() for p_ in parts])
         lists = [None] * world
         dist.all_gather_object(lists, extra, group=group)

@@ -92,3 +92,33 @@ def test_table_mode_through_the_launcher_and_the_other_mode_leg():
     assert cfg["mode"] == "tree" and cfg["collective"] == "scatter" and cfg["parity_reduced_tuple_sums_ok"] is True
     leg = cfg["other_mode_leg"]
     assert leg["mode"] == "table" and leg["collective"] is None and leg["parity_tuple_sums_ok"] is True and leg["table_shard_rank0"] == [0, 160], leg
+
+
+def test_two_ranks_share_the_gpu_over_gloo_both_modes():
+    """The N > 1 control flow with a REAL world size on the one-GPU box: `QS_BENCH_BACKEND=gloo python bench.py --gpus 2` -- two ranks
+    started by bench.py's own launcher share cuda:0 (RCCL refuses two ranks on one device, so the collectives are staged through the
+    host: quartetscores_amd/collectives.py). Table-sharded: every rank counts all trees into its cost-balanced shard, no table collective,
+    sharded scoring over SUM / MIN / all-gather. Tree-sharded: 3000 trees per rank, the reduce-scatter of the one-word-per-tuple wire
+    format, every rank scores the shard it received. Each line carries the other mode as a leg; all tuple-sum gates hold on every rank."""
+    os.environ["QS_BENCH_BACKEND"] = "gloo"
+    common = ["--gpus", "2", "--taxa", "160", "--trees", "6000", "--steps", "6", "--warmup", "1", "--p2p-leg", "0", "--no-cpu-baseline", "--no-e2e"]
+    try:
+        table = run_bench(common + ["--mode", "table"])
+        tree = run_bench(common + ["--mode", "tree"])
+    finally:
+        del os.environ["QS_BENCH_BACKEND"]
+    for doc in (table, tree):
+        assert doc["n_gpus"] == 2 and doc["scaling"] == "strong" and doc["collective"]["backend"] == "gloo" and doc["collective"]["proof"] == 2
+        assert doc["config"]["launcher"]["ranks"] == 2 and doc["config"]["parity_lookup_equals_bruteforce"] is True
+    cfg = table["config"]
+    assert cfg["mode"] == "table" and cfg["collective"] is None and cfg["parity_tuple_sums_ok"] is True and cfg["shard_balance"] == "cost"
+    assert cfg["table_shard"][0] == 0 and 0 < cfg["table_shard"][1] < 160 and "table shards" in cfg["score_mode"]
+    leg = cfg["other_mode_leg"]
+    assert leg["mode"] == "tree" and leg["wire"] == "u16x2" and leg["parity_tuple_sums_ok"] is True, leg
+    cfg = tree["config"]
+    assert cfg["mode"] == "tree" and cfg["collective"] == "scatter" and cfg["parity_reduced_tuple_sums_ok"] is True
+    assert "1 word/tuple wire" in cfg["step"] and cfg["one_rank_same_workload"]["count_only_ms_per_step"] > 0
+    leg = cfg["other_mode_leg"]
+    assert leg["mode"] == "table" and leg["collective"] is None and leg["parity_tuple_sums_ok"] is True, leg
+    # the same units of work in both lines: all trees x all quartets per step
+    assert abs(table["value"] * table["ms_per_step"] / (tree["value"] * tree["ms_per_step"]) - 1.0) < 1e-9
