@@ -573,24 +573,10 @@ XGMI_LINK_GBS = 153.0            # MI355X_MICROARCH.md: per xGMI link and direct
 
 
 def auto_mode(n, m_total, world, binary_full=True):
-    """tree- or table-sharded for N > 1, from what one GPU could settle (tools/scaling_model.py, profiles/r06_scaling_model.json):
-    the count work per rank is the same either way (trees x owned tuples); the tree-sharded mode adds ONE collective on the table,
-    the table-sharded mode adds the replicated panel build, the shards' imbalance and the tails of its smaller launches. Returns
-    (mode, the estimate). Constants: 1.6e-9 ms per (tree, taxon pair) of panel build (measured 1.3e-9 at 512 taxa, 1.8e-9 at
-    256), 9.4e13 quartets/s per GPU, ~8 % imbalance + tails, 1 ms per launch (one per slice of >= 350 MB of panel); the
-    collective is priced at the ring bound: reduce-scatter bytes per rank / 153 GB/s (one xGMI link at a time)."""
-    nq = n * (n - 1) * (n - 2) * (n - 3) // 24
-    npairs = n * (n - 1) // 2
-    bpt = (4 if binary_full else 6) if m_total < 65536 else (8 if binary_full else 12)
-    coll_ms = nq * bpt * (world - 1) / world / (XGMI_LINK_GBS * 1e9) * 1e3
-    count_ms = m_total * nq / 9.4e13 * 1e3 / world
-    panel_ms = 1.6e-9 * m_total * npairs
-    groups = -(-m_total // 32)
-    slice_groups = max(256, int(350e6 // (npairs * 16)))
-    table_extra_ms = panel_ms * (world - 1) / world + 0.08 * count_ms + 1.0 * -(-groups // slice_groups)
-    mode = "table" if table_extra_ms < coll_ms else "tree"
-    return mode, {"tree_collective_ms_ring_bound": round(coll_ms, 3), "table_extra_ms": round(table_extra_ms, 3), "count_ms_per_rank": round(count_ms, 3),
-                  "rule": "table if replicated panel + imbalance/tails < table collective at one xGMI link", "source": "profiles/r06_scaling_model.json"}
+    """tree- or table-sharded for N > 1: quartetscores_amd.distributed.auto_mode (the Python multi-GPU driver and the C++ CLI hold the same
+    arithmetic: table_shards.hpp prefer_table_shards)."""
+    from quartetscores_amd import distributed
+    return distributed.auto_mode(n, m_total, world, binary_full)
 
 
 def run_mode_leg(mode, world, rank, local_rank, n, count_bits, batch_all, m_total, steps, use_dist, balance):

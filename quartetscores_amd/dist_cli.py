@@ -2,7 +2,7 @@
 one node, one process per GPU:
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        -m quartetscores_amd.dist_cli -r ref.nwk -e eval.nwk -o out.nwk [-v] [--exact-qp] [--wire auto|u16x2|u16|u32]
+        -m quartetscores_amd.dist_cli -r ref.nwk -e eval.nwk -o out.nwk [-v] [--exact-qp] [--mode auto|tree|table] [--wire auto|u16x2|u16|u32]
 
 Every rank parses the evaluation file, flattens and counts its own contiguous share of the trees
 (distributed.shard_range), the tables are combined with one RCCL reduce-scatter, every rank scores the shard it
@@ -74,7 +74,8 @@ def _table_sharded(args, ref, world, rank, dev, say, t_begin):
     def open_shard(k):
         if k is None:      # a rank without a shard: a context only for the host-side parts
             return engine.Context(ref.n_taxa, bits, device=dev.index or 0, stream=stream.cuda_stream)
-        d_lo, d_hi = distributed.shard_of_largest_id(ref.n_taxa, n_shards, k)
+        # one resident shard per rank: balanced by the count kernel's work; more shards than ranks: by the tuples held (memory decides)
+        d_lo, d_hi = distributed.shard_of_largest_id(ref.n_taxa, n_shards, k, by="cost" if n_shards == world and world > 1 else "c4")
         ctx = engine.Context(ref.n_taxa, bits, device=dev.index or 0, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
         ctx.table_alloc()
         ctx.count_trees(batch, engine.QS_ALGO_GATHER)
@@ -113,6 +114,10 @@ def main(argv=None):
                          "(quartet_lookup_table.hpp:79-85) and so does this run (QS_SCORE_SAVEMEM_LOOKUPS)")
     ap.add_argument("--root-as-edge", action="store_true", help="a degree-2 reference root as a point on one edge (QS_SCORE_ROOT_AS_EDGE)")
     ap.add_argument("--wire", choices=["auto", "u16x2", "u16", "u32"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "tree", "table"], default="auto",
+                    help="how N ranks share the job (DESIGN.md 5): tree = trees / N per rank + ONE reduce-scatter of the table; table = every rank "
+                         "counts ALL trees into its shard of the table (by largest taxon id, cost-balanced), no table collective; auto = by the model "
+                         "(distributed.auto_mode; a one-shot run also pays for RCCL's communicators on the tree route)")
     ap.add_argument("--table-shards", type=int, default=-1,
                     help="table-sharded mode (1024 taxa x u16 = 273 GB: 8 ranks, 8 shards): the count table in K shards by largest taxon "
                          "id, shard s on rank s mod N, every rank counts ALL trees into its shard(s), no table collective; 0 = one per rank")
@@ -142,6 +147,16 @@ def main(argv=None):
         ref = flatten.flatten_reference(open(args.ref).read())
         if args.table_shards >= 0:
             return _table_sharded(args, ref, world, rank, dev, say, t_begin)
+        if world > 1 and args.mode != "tree":
+            # one cheap scan for the number of trees decides (every rank arrives at the same answer)
+            m_scan = native_ingest.ingest(args.ref, args.eval, 0, 0, args.threads, want_ranges=False)[1] if native_ingest.available() \
+                else sum(1 for _ in newick.parse_trees(open(args.eval).read()))
+            choice, est = distributed.auto_mode(ref.n_taxa, m_scan, world, rccl_init_ms=1700.0)
+            if args.mode == "table" or choice == "table":
+                say(f"Table-sharded counting on {world} GPUs ({'--mode table' if args.mode == 'table' else 'auto'}: table collective ~"
+                    f"{est['tree_collective_ms_ring_bound']} ms against ~{est['table_extra_ms']} ms of replicated panel build and imbalance).")
+                args.table_shards = world
+                return _table_sharded(args, ref, world, rank, dev, say, t_begin)
         if native_ingest.available():
             # the C++ host's multi-threaded ingest: one scan for the tree spans (= m), then only this rank's share is
             # parsed and flattened (the reference parses the whole file twice on one thread, QuartetScores.cpp:23-32)
