@@ -53,7 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-BACKEND = os.environ.get("QS_BENCH_BACKEND", "nccl")   # "gloo": several ranks share one GPU, collectives staged through the host (tests only)
+BACKEND = os.environ.get("QS_BENCH_BACKEND") or os.environ.get("QS_DIST_BACKEND", "nccl")   # "gloo": several ranks share one GPU, collectives staged through the host (tests only)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 T lane-ops/s: one wave64 VALU op per 2 cycles per SIMD-32
 

@@ -137,11 +137,19 @@ def main(argv=None):
     if not torch.cuda.is_available():
         print("ERROR: no HIP device (quartetscores_amd has no CPU fallback)", file=sys.stderr)
         return 1
+    # QS_DIST_BACKEND=gloo (rehearsal, tests): the ranks share the visible GPUs and talk over gloo, device tensors staged through the
+    # host (collectives.py) -- RCCL refuses two ranks on one device
+    backend = os.environ.get("QS_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     say = print if rank == 0 else (lambda *a, **k: None)
     try:
         ref = flatten.flatten_reference(open(args.ref).read())

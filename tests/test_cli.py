@@ -615,3 +615,44 @@ def test_cpp_cli_gpus_mode_tree_and_table_agree_with_the_oracle(tmp_path):
     assert (tmp_path / "q.nwk").read_text() == outs["tree"] and q.stat().st_size > 0
     p = run("-r", str(r), "-e", str(e), "-o", str(tmp_path / "bad.nwk"), "--gpus", "2", "--mode", "sideways")
     assert p.returncode == 1 and "--mode takes" in p.stderr
+
+
+@pytest.mark.gpu
+def test_python_multi_gpu_driver_with_two_ranks_on_one_gpu_both_modes(tmp_path):
+    """quartetscores_amd.dist_cli under `python -m torch.distributed.run --nproc-per-node 2` with QS_DIST_BACKEND=gloo: two REAL ranks share
+    cuda:0 (collectives staged through the host, quartetscores_amd/collectives.py). `--mode tree` (trees / 2 per rank, reduce-scatter of
+    the wire words, sharded scoring), `--mode table` (all trees per rank into its cost-balanced shard, no table collective) and `--mode
+    auto` write the annotated tree the single-GPU C++ CLI writes, for binary trees and for a batch of mixed shapes."""
+    import socket
+    import sys
+    import numpy as np
+    from quartetscores_amd import native_ingest, synth
+    n = 33
+    ref_nw = synth.random_tree(n, np.random.default_rng(7100))
+    r = tmp_path / "r.nwk"
+    r.write_text(ref_nw + "\n")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["QS_DIST_BACKEND"] = "gloo"
+    for kind in ("binary", "mixed"):
+        e = tmp_path / f"e_{kind}.nwk"
+        if kind == "binary":
+            e.write_bytes(native_ingest.synth_trees(n, 500, 7101))
+        else:
+            e.write_text("\n".join(synth.tree_set(n, 70, 7102) + synth.tree_set(n, 90, 7103, collapse=0.2, dropout=0.1)) + "\n")
+        ref_out = tmp_path / f"cli_{kind}.nwk"
+        p = run("-r", str(r), "-e", str(e), "-o", str(ref_out))
+        assert p.returncode == 0, p.stderr
+        for mode in ("tree", "table", "auto"):
+            out = tmp_path / f"dist_{kind}_{mode}.nwk"
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            q = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                                "--master-port", str(port), "-m", "quartetscores_amd.dist_cli", "-r", str(r), "-e", str(e), "-o", str(out), "--mode", mode],
+                               capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+            assert q.returncode == 0, (kind, mode, q.stderr[-1500:])
+            assert ("no table collective" in q.stdout) == (mode != "tree"), (mode, q.stdout)    # (auto: a one-shot run pays for RCCL's communicators on the tree route)
+            assert out.read_text() == ref_out.read_text(), (kind, mode)
