@@ -1499,12 +1499,16 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
         // of count_bitslice3_fused_kernel -- one pass over the table, one wave prologue / epilogue, whatever the mix of modes ----
         std::vector<bool> done(n_cls, false);
         uint32_t fused_launch_groups = 0;
-        if (c->tune_fuse && !all_swar && n_cls > 1) {
+        if (c->tune_fuse && !all_swar) {
             const uint32_t *order = nullptr;
             for (uint32_t bb = 4; bb <= (uint32_t)kFusedMaxBits; ++bb) {
                 std::vector<uint32_t> ks;
                 for (uint32_t k = 0; k < n_cls; ++k) if (std::max(d.class_bits[k], 4u) == bb) ks.push_back(k);
-                if (ks.size() < 2) continue;
+                // a lone binary_partial class at 4 bits takes the fused binary kernel too (with an empty binary_full segment): under the one
+                // dispatch it needs 123 VGPRs and spills nothing at 4 waves per SIMD, where the one-class instance is held to 128 with 6-24
+                // spilled: 512 taxa x 1500 trees with 10 % of the taxa dropped 64.95 -> 63.7 ms (profiles/r06_experiments.md 3)
+                const bool lone_bp4 = ks.size() == 1 && bb == 4 && d.class_mode[ks[0]] == MODE_BINARY_PARTIAL;
+                if (ks.size() < 2 && !lone_bp4) continue;
                 if (!order) { int rc_o = tile_order(c, 0, &order); if (rc_o != QS_OK) return rc_o; }
                 struct Seg { uint32_t k, s_lo, trees, groups, mode, nw; bool part; size_t chunk_bytes; };
                 std::vector<Seg> segs;
@@ -1564,7 +1568,9 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
                 }
                 for (const Seg &sg : segs) {
                     done[sg.k] = true;
-                    std::string nm = std::string(mode_names[sg.mode]) + ".bitslice_b" + std::to_string(bb) + "x2:" + std::to_string(sg.trees);
+                    std::string nm = "bitslice_b" + std::to_string(bb) + "x2";          // (named as the class-by-class path names its classes)
+                    if (mixed) nm = std::string(mode_names[sg.mode]) + "." + nm;
+                    if (n_cls > 1) nm += ":" + std::to_string(sg.trees);
                     names += (names.empty() ? "" : "+") + nm;
                 }
                 ++fused_launch_groups;

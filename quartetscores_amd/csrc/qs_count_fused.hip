@@ -38,6 +38,7 @@ template <int B, bool GENK> constexpr int fused_waves() {
     if (GENK && B <= 5 && QS_FUSED_GEN_WAVES) return QS_FUSED_GEN_WAVES;
     if (GENK) return bs3_waves<B, MODE_PARTIAL>();
     if (B <= 4 && QS_FUSED_BIN4_WAVES) return QS_FUSED_BIN4_WAVES;
+    if (B == 7) return 3;   // (the one-class binary_partial instance takes 2 at 7 bits; under one dispatch the pair fits 168 VGPRs)
     return bs3_waves<B, MODE_BINARY_PARTIAL>();
 }
 template <int B, bool GENK> constexpr int fused_lds_uint4() {
