@@ -1504,10 +1504,10 @@ extern "C" int qs_count_batch(qs_ctx *c, const qs_device_batch *b, uint32_t algo
             for (uint32_t bb = 4; bb <= (uint32_t)kFusedMaxBits; ++bb) {
                 std::vector<uint32_t> ks;
                 for (uint32_t k = 0; k < n_cls; ++k) if (std::max(d.class_bits[k], 4u) == bb) ks.push_back(k);
-                // a lone binary_partial class at 4 bits takes the fused binary kernel too (with an empty binary_full segment): under the one
+                // a lone binary_partial class at 4 or 5 bits takes the fused binary kernel too (with an empty binary_full segment): under the one
                 // dispatch it needs 123 VGPRs and spills nothing at 4 waves per SIMD, where the one-class instance is held to 128 with 6-24
                 // spilled: 512 taxa x 1500 trees with 10 % of the taxa dropped 64.95 -> 63.7 ms (profiles/r06_experiments.md 3)
-                const bool lone_bp4 = ks.size() == 1 && bb == 4 && d.class_mode[ks[0]] == MODE_BINARY_PARTIAL;
+                const bool lone_bp4 = ks.size() == 1 && bb <= 5 && d.class_mode[ks[0]] == MODE_BINARY_PARTIAL;   // (5 bits: 4 waves instead of the one-class instance's 3)
                 if (ks.size() < 2 && !lone_bp4) continue;
                 if (!order) { int rc_o = tile_order(c, 0, &order); if (rc_o != QS_OK) return rc_o; }
                 struct Seg { uint32_t k, s_lo, trees, groups, mode, nw; bool part; size_t chunk_bytes; };

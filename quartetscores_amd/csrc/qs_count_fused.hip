@@ -31,6 +31,10 @@ namespace qs {
 #define QS_FUSED_BIN4_WAVES 0   /* 0 = as the binary_partial instance of the same depth bits (bs3_waves); else waves per SIMD of the binary-only fused kernel at 4 bits */
 #endif
 
+#ifndef QS_FUSED_BIN5_WAVES
+#define QS_FUSED_BIN5_WAVES 4   /* binary-only fused kernel at 5 bits: 121-127 VGPRs without spills (the one-class binary_partial instance needs 140-152: 3 waves);
+                                 * at 6 bits a fourth wave would cost 6-13 spilled registers, some inside the hot loop: not taken */
+#endif
 #ifndef QS_FUSED_GEN_WAVES
 #define QS_FUSED_GEN_WAVES 0    /* 0 = as the partial instance of the same depth bits; else waves per SIMD of the fused kernel with general segments (4 .. 5 bits) */
 #endif
@@ -38,6 +42,7 @@ template <int B, bool GENK> constexpr int fused_waves() {
     if (GENK && B <= 5 && QS_FUSED_GEN_WAVES) return QS_FUSED_GEN_WAVES;
     if (GENK) return bs3_waves<B, MODE_PARTIAL>();
     if (B <= 4 && QS_FUSED_BIN4_WAVES) return QS_FUSED_BIN4_WAVES;
+    if (B == 5) return QS_FUSED_BIN5_WAVES;
     if (B == 7) return 3;   // (the one-class binary_partial instance takes 2 at 7 bits; under one dispatch the pair fits 168 VGPRs)
     return bs3_waves<B, MODE_BINARY_PARTIAL>();
 }
