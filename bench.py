@@ -309,6 +309,8 @@ def cpu_child(spec_path):
                 r = run(th, max(2.0, budget / 10))
                 if best is None or r["value"] > best["value"]:
                     best = r
+                elif r["value"] < 0.95 * best["value"]:
+                    break                                               # past the best thread count: more threads only add remote accesses
             if best is not None and best["value"] > float(spec.get("beat") or 0.0):
                 best = run(best["threads"], max(10.0, budget / 2))   # a longer run is the figure, not the 3 s of the scan (half the budget: the default line stays within minutes)
         if best is None:
@@ -326,6 +328,8 @@ def cpu_child(spec_path):
                 r = run(th, max(2.0, budget / 10))
                 if scan is None or r["value"] > scan["value"]:
                     scan = r
+                elif r["value"] < 0.95 * scan["value"] and th >= 32:
+                    break                                               # ... which stops at the first count from 32 threads on that loses 5 % (the default line stays within minutes)
             if scan is not None:
                 r = run(scan["threads"], budget)                        # ... which then runs for the full budget
                 if r["value"] > best["value"]:
