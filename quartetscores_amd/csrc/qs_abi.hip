@@ -1219,6 +1219,14 @@ extern "C" int qs_shard_bounds(uint32_t n_taxa, uint32_t n_shards, uint32_t by, 
         if (cut(mid, nullptr)) hi_b = mid; else lo_b = mid;
     }
     if (!cut(hi_b, bounds)) return QS_ERR_STATE;
+    // fewer useful shards than asked for (tiny n): the greedy cut leaves the EMPTY ones at the bottom as [0, 0); move them to the top as
+    // [n, n) so that shard 0 (rank 0: the rank that writes the output) always holds quartets
+    uint32_t e = 0;
+    while (e < K && bounds[e + 1] == 0) ++e;
+    if (e) {
+        for (uint32_t k = 0; k + e <= K; ++k) bounds[k] = bounds[k + e];
+        for (uint32_t k = K - e + 1; k <= K; ++k) bounds[k] = n;
+    }
     return QS_OK;
 }
 

@@ -51,7 +51,7 @@ def _table_sharded(args, ref, world, rank, dev, say, t_begin):
     [d_lo, d_hi) of the largest taxon id), and the scores come from distributed.score_table_shards."""
     import torch
     import torch.distributed as dist
-    from . import _lib, distributed, engine, flatten, native_ingest, newick
+    from . import _lib, distributed, engine, flatten, native_ingest, newick, ranks
     n_shards = args.table_shards or world
     if n_shards < world:
         raise ValueError(f"--table-shards {n_shards}: fewer shards than ranks ({world})")
@@ -68,14 +68,17 @@ def _table_sharded(args, ref, world, rank, dev, say, t_begin):
         f"shard(s), no table collective.")
     t0 = time.perf_counter()
     stream = torch.cuda.current_stream(dev)
-    mine = distributed.shards_of_rank(n_shards, world, rank)
+    by = "cost" if n_shards == world and world > 1 else "c4"
+    bounds = distributed.shard_bounds(ref.n_taxa, n_shards, by)
+    # (tiny taxon counts leave some of many shards empty: a rank without a shard still takes part in the collectives of the scoring)
+    mine = [k for k in distributed.shards_of_rank(n_shards, world, rank) if ranks.n_quartets(bounds[k + 1]) > ranks.n_quartets(bounds[k])]
     counted = []
 
     def open_shard(k):
         if k is None:      # a rank without a shard: a context only for the host-side parts
             return engine.Context(ref.n_taxa, bits, device=dev.index or 0, stream=stream.cuda_stream)
         # one resident shard per rank: balanced by the count kernel's work; more shards than ranks: by the tuples held (memory decides)
-        d_lo, d_hi = distributed.shard_of_largest_id(ref.n_taxa, n_shards, k, by="cost" if n_shards == world and world > 1 else "c4")
+        d_lo, d_hi = bounds[k], bounds[k + 1]
         ctx = engine.Context(ref.n_taxa, bits, device=dev.index or 0, stream=stream.cuda_stream, d_lo=d_lo, d_hi=d_hi)
         ctx.table_alloc()
         ctx.count_trees(batch, engine.QS_ALGO_GATHER)
