@@ -23,7 +23,7 @@ contract; the upload-inclusive step is reported as e2e.upload_in_step_ms, +1 %):
 kernel class by class and slice by slice (first slice stores, the others accumulate), then for N > 1 the collective on the
 table. Exactly K steps are timed between barrier + torch.cuda.synchronize() on both sides; value = quartet-tree units counted
 by all ranks / max-over-ranks time. N > 1: `collective` = {ranks, proof (all-reduce of ones), comm_init_ms,
-collective_alone_ms}; rank 0 runs the cpu_baseline leg at every N.
+collective_alone_ms}; the cpu_baseline leg runs at N = 1 only (task statement 4; `--cpu-baseline-at-n` forces it on rank 0 of an N > 1 run).
 
 roofline: the dominant kernel is the count kernel. The gather formulation keeps every counter in a
 register and writes each table cell once per panel slice, so it is bound by VALU issue, not by HBM:
@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--count-bits", type=int, default=0)
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="seconds of CPU counting at -t 1 and at the best thread count of the cpu_baseline leg (the scan in between: a tenth each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-at-n", action="store_true", help="run the cpu_baseline leg on rank 0 of an N > 1 run too (default: N = 1 only)")
     ap.add_argument("--no-score", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the e2e legs (CLI child process; steps with the host-array upload inside)")
     ap.add_argument("--no-impl-check", action="store_true", help="skip the on-device comparison with the byte-SWAR implementation")
@@ -814,7 +815,8 @@ def main():
 
     # cpu_baseline leg first, in a child process, BEFORE this process touches the GPU (N = 1 only)
     cpu_baseline = None
-    if not args.no_cpu_baseline and rank == 0:          # rank 0 only; the other ranks wait at the rendezvous meanwhile
+    # (N = 1 only, as the measurement contract says: at N > 1 the other ranks would sit at the rendezvous for the two minutes it takes)
+    if not args.no_cpu_baseline and rank == 0 and (world == 1 or args.cpu_baseline_at_n):
         cpu_baseline = run_cpu_baseline(ref_nw, sample_text, n, m, ranks.n_quartets(n), args.cpu_budget_s)
 
     cli_e2e = None
@@ -1517,7 +1519,7 @@ def main():
 
     if p2p_leg is not None:
         out["config"]["p2p_leg"] = p2p_leg
-    if cpu_baseline is not None:                     # rank 0's host, at every N
+    if cpu_baseline is not None:                     # rank 0's host (N = 1)
         out["cpu_baseline"] = cpu_baseline
     if comm is not None:
         comm["collective_alone_ms"] = coll_alone_ms
