@@ -10,13 +10,16 @@ retry; `--dry-launch` prints the command). Started by torch.distributed.run itse
 
 Workloads (BASELINE.json `configs`; seeded synthetic trees from csrc/host/synth.hpp):
     --config 1   configs[1]: 128 taxa x 1 000 trees, u32 table (128 MB)
-    --config 2   configs[2]: 512 taxa x 10 000 trees, u32 table (34 GB)            <- default at N = 1
-    --config 3   configs[3]: 256 taxa x 100 000 trees SPLIT over the N ranks, u32 table per rank (2.1 GB) + one RCCL
-                 collective on the table per step                                   <- default at N > 1 (strong scaling)
+    --config 2   configs[2]: 512 taxa x 10 000 trees, u32 table (34 GB)            <- default at EVERY N (one workload per driver curve)
+    --config 3   configs[3]: 256 taxa x 100 000 trees, u32 table (2.1 GB)
     --config 4   configs[4]: 1024 taxa x 5 000 trees, u16 table sharded by the largest taxon id over max(N, 8) shards;
                  every rank counts all trees into its shard(s), no table collective
     --taxa/--trees/--count-bits override the sizes (the workload label then says "custom"); --dropout / --collapse / --mixed
     make binary trees with missing taxa / multifurcating trees / a third of each (numpy generator, small tree counts).
+N > 1: --mode table = every rank counts ALL trees into its shard of the table (by largest taxon id, cost-balanced bounds:
+qs_shard_bounds), no table collective; --mode tree = trees / N per rank into a full table + ONE RCCL collective on the table per step;
+--mode auto (default) = by the model of the one-GPU measurements (distributed.auto_mode: table for configs[2], tree for configs[3]).
+The line carries a few steps of the OTHER mode on the same trees as config.other_mode_leg.
 
 A step = one pass of the hot path over the rank's batch of trees, which is already resident in HBM (the task's measurement
 contract; the upload-inclusive step is reported as e2e.upload_in_step_ms, +1 %): build the pair-depth panel and run the count
