@@ -577,7 +577,6 @@ def valu_frac(variant, m, units, count_ms):
     return units * ops32 / 32.0 / (count_ms * 1e-3) / 1e12 / VALU_PEAK_TLOPS, ops32
 
 
-XGMI_LINK_GBS = 153.0            # MI355X_MICROARCH.md: per xGMI link and direction, 7 links per GPU
 
 
 def auto_mode(n, m_total, world, binary_full=True):
