@@ -179,6 +179,15 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
     return p;
 }
 
+#ifndef QS_SYNC_MODES
+#define QS_SYNC_MODES 0xDu   /* modes (bit = CountMode) whose four waves of a workgroup walk their 32-tree steps in step (one s_barrier per step, launched
+                             * with xcd_remap bit 1): binary_full -5 % at 512 taxa (round 2), partial and binary_partial unchanged, general_full
+                             * 3.5 % FASTER without it (round 6: profiles/r06_experiments.md 7) -> every mode but general_full (bit 1).
+                             * The flag must stay a RUN-TIME value (a kernel argument): with the barrier compiled out the general_full step
+                             * takes 153 instead of 84-87 ms -- the s_barrier at the top of a step is also the fence that keeps LLVM from sinking
+                             * the step's panel loads to their first use */
+#endif
+constexpr uint32_t kSyncModes = QS_SYNC_MODES;
 #ifndef QS_PROBE_ROWS
 #define QS_PROBE_ROWS kDB
 #endif

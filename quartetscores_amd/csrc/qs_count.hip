@@ -990,7 +990,7 @@ hipError_t launch_count_bitslice3(hipStream_t s, const CountGeometry &g_in, cons
 #define QS_BS3(BB, MM, CT)                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_kernel<BB, MM, CT>), grid, block, 0, s, (const uint4 *)panel, npairs, n_groups, \
                        m_trees, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk, g.total_tiles, g.dprefix, g.cprefix,           \
-                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 3u : 0u /* bit 0: XCD remap, bit 1: waves of a workgroup in step */, wire, g.perm)
+                       (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? (((kSyncModes >> (MM)) & 1u) ? 3u : 1u) : 0u /* bit 0: XCD remap, bit 1: waves of a workgroup in step (QS_SYNC_MODES) */, wire, g.perm)
 #define QS_BS3_B(MM, CT)                                                                                            \
     do {                                                                                                            \
         switch (depth_bits <= 4 ? 4 : depth_bits) {                                                                 \

@@ -66,7 +66,7 @@ template <int B, bool GENK, typename CT>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(fused_waves<B, GENK>(), fused_waves<B, GENK>()))) void count_bitslice3_fused_kernel(
     FusedSegs segs, uint32_t npairs, uint32_t d_start, uint32_t d_hi, uint64_t rank_lo, uint32_t n_dblk, uint32_t total_tiles,
     const uint32_t *__restrict__ dprefix, const uint32_t *__restrict__ cprefix, CT *__restrict__ table, uint32_t *__restrict__ overflow_flag,
-    uint32_t overwrite, uint32_t xcd_remap, const uint32_t *__restrict__ perm) {
+    uint32_t overwrite, uint32_t xcd_remap, const uint32_t *__restrict__ perm, uint32_t seg_sync) {
     __shared__ uint4 stage_all[kWavesPerBlock][fused_lds_uint4<B, GENK>()];
     Bs3Tile t;
     if (!bs3_decode_tile(t, d_start, d_hi, n_dblk, total_tiles, dprefix, cprefix, xcd_remap, perm)) return;
@@ -81,11 +81,13 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(f
     // the dearest segment needs alone -- scratch traffic inside the hot loops (profiles/r06_experiments.md).
     // (LDS operations of one wave execute in order: a segment's first stores follow the previous segment's last reads; the wave
     // barrier keeps the compiler from interleaving the two images)
+    // waves of a workgroup in step (the step's s_barrier) per segment: a run-time flag on purpose (QS_SYNC_MODES in qs_bitslice3.hpp)
+    auto remap_of = [&](int seg) { return ((seg_sync >> seg) & 1u) ? xcd_remap : (xcd_remap & ~2u); };
     auto all_segments = [&](auto var_tag) {
         constexpr int V = decltype(var_tag)::value;
-        if ((QS_FUSED_SEGMASK & 1) && segs.n_groups[0]) bs3_segment<B, MODE_BINARY_FULL, V>(t, segs.P[0], npairs, segs.n_groups[0], xcd_remap, lds, x0, x1, y0, y1, z0, z1);
+        if ((QS_FUSED_SEGMASK & 1) && segs.n_groups[0]) bs3_segment<B, MODE_BINARY_FULL, V>(t, segs.P[0], npairs, segs.n_groups[0], remap_of(0), lds, x0, x1, y0, y1, z0, z1);
         __builtin_amdgcn_wave_barrier();
-        if ((QS_FUSED_SEGMASK & 2) && segs.n_groups[1]) bs3_segment<B, MODE_BINARY_PARTIAL, V>(t, segs.P[1], npairs, segs.n_groups[1], xcd_remap, lds, x0, x1, y0, y1, z0, z1);
+        if ((QS_FUSED_SEGMASK & 2) && segs.n_groups[1]) bs3_segment<B, MODE_BINARY_PARTIAL, V>(t, segs.P[1], npairs, segs.n_groups[1], remap_of(1), lds, x0, x1, y0, y1, z0, z1);
         // third topology of the binary segments: the trees that hold all four taxa minus the two counted
 #pragma unroll
         for (int j = 0; j < kDB; ++j) {
@@ -94,9 +96,9 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(f
         }
         if (GENK) {
             __builtin_amdgcn_wave_barrier();
-            if ((QS_FUSED_SEGMASK & 4) && segs.n_groups[2]) bs3_segment<B, MODE_GENERAL_FULL, V>(t, segs.P[2], npairs, segs.n_groups[2], xcd_remap, lds, x0, x1, y0, y1, z0, z1);
+            if ((QS_FUSED_SEGMASK & 4) && segs.n_groups[2]) bs3_segment<B, MODE_GENERAL_FULL, V>(t, segs.P[2], npairs, segs.n_groups[2], remap_of(2), lds, x0, x1, y0, y1, z0, z1);
             __builtin_amdgcn_wave_barrier();
-            if ((QS_FUSED_SEGMASK & 8) && segs.n_groups[3]) bs3_segment<B, MODE_PARTIAL, V>(t, segs.P[3], npairs, segs.n_groups[3], xcd_remap, lds, x0, x1, y0, y1, z0, z1);
+            if ((QS_FUSED_SEGMASK & 8) && segs.n_groups[3]) bs3_segment<B, MODE_PARTIAL, V>(t, segs.P[3], npairs, segs.n_groups[3], remap_of(3), lds, x0, x1, y0, y1, z0, z1);
         }
     };
     switch (bs3_tile_variant(t)) {
@@ -120,11 +122,13 @@ hipError_t launch_count_bitslice3_fused(hipStream_t s, const CountGeometry &g, c
     for (int i = 0; i < 4; ++i) { fs.P[i] = (const uint4 *)seg_panel[order[i]]; fs.n_groups[i] = seg_groups[order[i]]; }
     fs.m_bf = seg_groups[MODE_BINARY_FULL] ? seg_trees[MODE_BINARY_FULL] : 0u;
     const bool genk = fs.n_groups[2] || fs.n_groups[3];
+    uint32_t seg_sync = 0;       // bit i: segment i keeps the four waves of a workgroup in step (QS_SYNC_MODES, by CountMode)
+    for (int i = 0; i < 4; ++i) seg_sync |= ((kSyncModes >> order[i]) & 1u) << i;
     const uint32_t npairs = (uint32_t)binom2(g.n);
     dim3 grid((g.total_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kCountThreads);
 #define QS_FUSED(BB, GG, CT)                                                                                                          \
     hipLaunchKernelGGL((count_bitslice3_fused_kernel<BB, GG, CT>), grid, block, 0, s, fs, npairs, g.d_lo, g.d_hi, g.rank_lo, g.n_dblk,  \
-                       g.total_tiles, g.dprefix, g.cprefix, (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 3u : 0u, g.perm)
+                       g.total_tiles, g.dprefix, g.cprefix, (CT *)table, overflow_flag, overwrite ? 1u : 0u, g.n >= 200 ? 3u : 0u, g.perm, seg_sync)
 #define QS_FUSED_B(GG, CT)                                                                                                            \
     do {                                                                                                                              \
         switch (depth_bits) {                                                                                                         \

@@ -3,7 +3,7 @@
 out=${1:?outdir}; shift
 mkdir -p "$out"
 common="--taxa 512 --trees 1500 --steps 8 --warmup 2 --no-cpu-baseline --no-e2e --no-score --secondary 0"
-for wl in "--collapse 0.2" "--collapse 0.2 --dropout 0.1" "--mixed"; do
+for wl in "--collapse 0.2" "--collapse 0.2 --dropout 0.1" "--dropout 0.1" "--mixed"; do
   tag=$(echo "$wl" | tr -d ' -' | tr '.' 'p')
   for lib in product "$@"; do
     if [ $lib = product ]; then unset QS_PY_LIB; else export QS_PY_LIB=$PWD/quartetscores_amd/lib/libqs_probe_$lib.so; fi
