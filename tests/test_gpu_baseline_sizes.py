@@ -244,3 +244,49 @@ def test_512_taxa_gene_tree_like_batches(eng, kind):
     ctx.batch_free(hb2)
     ctx.batch_free(hb)
     ctx.close()
+
+
+def test_fused_launch_at_the_size_of_configs2(eng):
+    """count_bitslice3_fused_kernel on the 34 GB table of configs[2] (512 taxa; 3.1 M wave tiles, XCD-remapped launch order, the per-step
+    barrier on for three segments and off for general_full): 360 trees of all four kernel modes interleaved -- one launch of four segments
+    -- give the table of the class-by-class launches (QS_TUNE_FUSE_CLASSES = 0) and of the independent byte-SWAR kernel, bit for bit; 5000 random qs_lookups equal the split-based brute force.
+    The reference's loop is shape-independent (QuartetCounterLookup.hpp:65-106,166-188)."""
+    import torch
+    n = 512
+    ref_nw = native_ingest.synth_trees(n, 1, 2000).decode().strip()
+    ref = flatten.flatten_reference(ref_nw)
+    kws = [dict(), dict(dropout=0.1), dict(collapse=0.2), dict(collapse=0.2, dropout=0.1)]
+    sets = [synth.tree_set(n, 90, 2600 + i, **kw) for i, kw in enumerate(kws)]
+    trees = [sets[i % 4][i // 4] for i in range(360)]
+    batch = flatten.flatten_eval_trees(trees, ref.name_to_id)
+    ctx = eng.Context(n, 32)
+    table = torch.zeros((ctx.table_bytes + 3) // 4, dtype=torch.int32, device="cuda")
+    ctx.table_attach(table)
+    hb = ctx.batch_upload(batch, with_nodes=False)
+    ctx.count_batch(hb, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE | eng.QS_COUNT_TIMED)
+    ctx.sync()
+    v = ctx.last_count_variant()
+    assert "/fused:1" in v and ctx.last_count_launches() == 1 and v.count("bitslice_b4x2") == 4, v
+    fused = table.clone()
+    ctx.set_tuning(_lib.QS_TUNE_FUSE_CLASSES, 0)
+    hb0 = ctx.batch_upload(batch, with_nodes=False)                      # (the class plan is made at upload time)
+    ctx.count_batch(hb0, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE | eng.QS_COUNT_TIMED)
+    ctx.sync()
+    assert "/fused" not in ctx.last_count_variant() and ctx.last_count_launches() >= 1
+    assert torch.equal(fused, table)
+    ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_SWAR)
+    ctx.count_batch(hb0, eng.QS_ALGO_GATHER | eng.QS_COUNT_OVERWRITE)
+    ctx.sync()
+    assert "depth_u" in ctx.last_count_variant()
+    assert torch.equal(fused, table)
+    ctx.set_tuning(_lib.QS_TUNE_GATHER_IMPL, _lib.QS_IMPL_AUTO)
+    del fused
+    # random quartets against the split-based brute force
+    rng = np.random.default_rng(26)
+    qs_ = np.sort(np.stack([rng.choice(n, size=4, replace=False) for _ in range(5000)]), axis=1).astype(np.uint16)
+    got = ctx.lookup(qs_)
+    want = bruteforce.quartet_counts_for(trees, ref.names, qs_.astype(np.int64))
+    assert (got == want).all()
+    ctx.batch_free(hb)
+    ctx.batch_free(hb0)
+    ctx.close()
