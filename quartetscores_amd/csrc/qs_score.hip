@@ -413,7 +413,14 @@ __device__ __forceinline__ double bundle_qic(const double *__restrict__ t1, cons
     const uint32_t s = n0 + n1 + n2;                       // (no wrap below: mx < 2^30)
     double qic;
     if (mx < (1u << 30) && s < sd.lds_n) {
+#if defined(QS_PROBE_SCORE_NOLDS)        /* timing probes only (wrong scores): what the three LDS look-ups cost (profiles/r06_experiments.md 5) */
+        const double acc = (double)n0 * 1.5 + (double)n1 * 2.5 + (double)n2 * 3.5;
+#elif defined(QS_PROBE_SCORE_F32LOG)
+        const float f0 = (float)n0, f1 = (float)n1, f2 = (float)n2;
+        const double acc = (double)(f0 * __builtin_amdgcn_logf(f0 + 1.0f) + f1 * __builtin_amdgcn_logf(f1 + 1.0f) + f2 * __builtin_amdgcn_logf(f2 + 1.0f)) * 0.6931471805599453;
+#else
         const double acc = t1[n0] + t1[n1] + t1[n2];       // sum_i n_i log n_i
+#endif
         if (s != qc.s) {                                   // 1/s and log s: kept while the tuple sum repeats
             qc.s = s;
             if (s == 0) { qc.r = 0.0; qc.ls = 1.0986122886681098; }   // all-zero tuple: QIC 0 (QuartetScoreComputer.hpp:136)
