@@ -188,6 +188,9 @@ template <int NW> __device__ __forceinline__ Planes buf_load_planes(__amdgpu_buf
                              * the step's panel loads to their first use */
 #endif
 constexpr uint32_t kSyncModes = QS_SYNC_MODES;
+#ifndef QS_BIN_PRIO
+#define QS_BIN_PRIO 1       /* binary modes: s_setprio 1 around the compare chains of a step (A/B: 0) */
+#endif
 #ifndef QS_PROBE_ROWS
 #define QS_PROBE_ROWS kDB
 #endif
@@ -486,6 +489,9 @@ __device__ __forceinline__ void bs3_segment(const Bs3Tile &t, const uint4 *__res
         // runs 10 % slower (table above): what looks like an exposed L2 round trip is covered by the other two waves.
         uint32_t colA1 = colA1_, colA2 = colA2_, colB = colB_;
         if (GEN && QS_GEN_OPAQUE) asm volatile("" : "+v"(colA1), "+v"(colA2), "+v"(colB));
+        // binary modes: the compare chains run at issue priority 1, the request / staging part of the step at 0 (round 6: -1 % on
+        // configs[2], -1.2 % for binary_partial; the general modes LOSE 0.6-4.5 % with it and keep priority 0: profiles/r06_experiments.md 8)
+        if (BIN && QS_BIN_PRIO) __builtin_amdgcn_s_setprio(1);
         const Planes L1 = sub_biased<B>(abc1, row0_load(cur, colA1)); // M[a1 b] - M[a1 c] + 2^B
         Planes L2 = L1, G1 = L1, G2 = L1;
         if (A2) L2 = sub_biased<B>(abc2, row0_load(cur, colA2));      // M[a2 b] - M[a2 c] + 2^B
@@ -560,6 +566,7 @@ __device__ __forceinline__ void bs3_segment(const Bs3Tile &t, const uint4 *__res
         // single-buffered image (cur == nxt): every read of this step above, every write of the next image below. LDS operations
         // of a wave execute in program order; the scheduling barrier keeps the compiler from moving a store above a load it
         // cannot prove disjoint (no instruction is emitted)
+        if (BIN && QS_BIN_PRIO) __builtin_amdgcn_s_setprio(0);   // (kept high through the staging stores as well: +2 %: worse)
         if (NBUF == 1) lds_order<QS_GEN_WBAR>();
         lstore(nxt, slot0, sub_biased<B>(st.x0, st.y));
         if (NR >= 2) lstore(nxt, slot1, sub_biased<B>(st.x1, st.y));
