@@ -122,3 +122,22 @@ def test_two_ranks_share_the_gpu_over_gloo_both_modes():
     assert leg["mode"] == "table" and leg["collective"] is None and leg["parity_tuple_sums_ok"] is True, leg
     # the same units of work in both lines: all trees x all quartets per step
     assert abs(table["value"] * table["ms_per_step"] / (tree["value"] * tree["ms_per_step"]) - 1.0) < 1e-9
+
+
+def test_four_ranks_share_the_gpu_table_mode_and_auto():
+    """Four ranks on cuda:0 over gloo (QS_BENCH_BACKEND=gloo): the table-sharded mode with four cost-balanced shards (qs_shard_bounds), the
+    tree-sharded leg with four chunks of the reduce-scatter, and `--mode auto`, which at this size (a 0.1 GB table) picks the tree cut."""
+    os.environ["QS_BENCH_BACKEND"] = "gloo"
+    common = ["--gpus", "4", "--taxa", "160", "--trees", "4000", "--steps", "4", "--warmup", "1", "--p2p-leg", "0", "--no-cpu-baseline", "--no-e2e"]
+    try:
+        table = run_bench(common + ["--mode", "table"])
+        auto = run_bench(common + ["--no-score"])
+    finally:
+        del os.environ["QS_BENCH_BACKEND"]
+    cfg = table["config"]
+    assert table["n_gpus"] == 4 and table["collective"]["proof"] == 4 and cfg["mode"] == "table" and cfg["parity_tuple_sums_ok"] is True
+    assert cfg["table_shard"][0] == 0 and cfg["parity_lookup_equals_bruteforce"] is True and "table shards" in cfg["score_mode"]
+    assert cfg["other_mode_leg"]["mode"] == "tree" and cfg["other_mode_leg"]["parity_tuple_sums_ok"] is True
+    cfg = auto["config"]
+    assert cfg["mode"] == "tree" and cfg["mode_decided_by"] == "auto (model)" and cfg["mode_model"]["table_extra_ms"] > cfg["mode_model"]["tree_collective_ms_ring_bound"]
+    assert cfg["parity_reduced_tuple_sums_ok"] is True and cfg["other_mode_leg"]["mode"] == "table" and cfg["other_mode_leg"]["parity_tuple_sums_ok"] is True
